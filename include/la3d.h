@@ -1,0 +1,111 @@
+/* la3d.h — C-ABI of the MI355X-native LabelAny3D geometric hot path (libla3d.so, gfx950).
+ *
+ * The reference has no FFI layer: the path is three module-level Python/NumPy functions
+ * resolved by name (reference src/batch_scripts/whole.py:10,15-16).  This ABI is what a
+ * binding for that path calls; labelany3d_amd/{util,util_3dbox}.py bind it with ctypes and
+ * keep the reference's Python signatures.
+ *
+ * Conventions
+ *  - every `const T* dev` / `T* dev` argument is a DEVICE pointer (tensor.data_ptr());
+ *    arguments documented as HOST are read synchronously before the call returns.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
+ *    asynchronous with respect to the host; the caller owns every buffer.
+ *  - no call throws, allocates device memory or synchronises the device.
+ *  - return value: LA3D_SUCCESS or a negative LA3D_ERR_*; la3d_last_error() gives text.
+ *  - per-box failures (the reference's ValueError cases) are reported in `status[B]`,
+ *    never as a failed call.
+ */
+#ifndef LA3D_H
+#define LA3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LA3D_ABI_VERSION 1
+#define LA3D_REC 39      /* doubles per box: center_cam[3] dimensions[3]=(dz,dy,dx) R_cam[9] bbox3D_cam[8][3] */
+#define LA3D_AUX 4       /* doubles per box: yaw, n_valid, n_in (mask pixels / cloud points), eigen-gap (l1-l2)/l1 */
+#define LA3D_NSAMPLE 500 /* reference src/util_3dbox.py:123-125 */
+
+/* call status */
+#define LA3D_SUCCESS 0
+#define LA3D_ERR_ARG (-1)
+#define LA3D_ERR_UNSUPPORTED (-2)
+#define LA3D_ERR_HIP (-3)
+
+/* per-box status (int32) — the reference's error behaviour, src/util_3dbox.py */
+#define LA3D_BOX_OK 0         /* a box was fitted                                                        */
+#define LA3D_BOX_EMPTY 1      /* ValueError("No valid points after removing NaN values")  (:142-143)     */
+#define LA3D_BOX_BAD_GROUND 2 /* ground parallel/antiparallel to [0,-1,0] or zero: NaN rotation (:37-55)   */
+#define LA3D_BOX_TOO_FEW 3    /* one valid point: scikit-learn PCA(2) ValueError (:183-184)              */
+#define LA3D_BOX_NONFINITE 4  /* +-inf coordinate reaches PCA: scikit-learn ValueError (:183-184)        */
+
+/* yaw method (reference src/util_3dbox.py:146-151) */
+#define LA3D_METHOD_PCA 0
+#define LA3D_METHOD_CONVEX_HULL 1
+
+int la3d_version(void);
+const char* la3d_last_error(void);
+
+/* Replaces depth_to_points(depth, K, R, t) — reference src/util.py:52-75 (caller
+ * src/batch_scripts/depth.py:154).  depth: dev f32 [H*W] (batch element 0, as the reference
+ * returns only that, :75).  K9: HOST f64[9] row-major pixel intrinsics.  Rt12: HOST f64[12]
+ * = R row-major (9) then t (3), or NULL for identity.  out: dev [H*W*3], f64 when
+ * out_is_f64 != 0 (the reference's dtype) else f32.  u = column, v = row, no half-pixel. */
+int la3d_unproject(const float* depth, const double* K9, const double* Rt12, int H, int W,
+                   void* out, int out_is_f64, void* stream);
+
+/* Number of True pixels per mask plane: what the reference sees as in_pc.shape[0]
+ * (src/util_3dbox.py:123) when fed pts[mask].  mask: dev u8 [B][H*W] (non-zero = True);
+ * counts: dev i32 [B].  The host needs it to draw np.random.randint(0, N, 500). */
+int la3d_mask_counts(const uint8_t* mask, int B, int H, int W, int32_t* counts, void* stream);
+
+/* Bytes of device scratch la3d_fit_instances needs for (B,H,W); may be 0. */
+size_t la3d_workspace_bytes(int B, int H, int W);
+
+/* The composed hot path, batched:
+ *     for n in range(B):
+ *         img  = image_index[n] if image_index else n
+ *         pts  = depth_to_points(depth[img][None], K[img])[mask[n]]     # src/util.py:52-75, :480-481
+ *         out[n] = estimate_bbox(pts, None, ground[n], 'pca')          # src/util_3dbox.py:106-178
+ * depth        dev f32, planes of H*W floats, plane p at depth + p*depth_plane_stride
+ *              (stride in floats; 0 = one shared plane)
+ * image_index  dev i32 [B] or NULL (instance n uses plane n)
+ * mask         dev u8 [B][H*W], non-zero = True (np.bool_ layout, src/util.py:367,382)
+ * K            dev f64, 9 per image, image p at K + p*k_stride (k_stride 0 = shared, else >= 9)
+ * ground       dev f64 [B][4] or NULL; only [:3] is used (src/util_3dbox.py:128-134); a row whose
+ *              first component is NaN means "no ground" for that instance
+ * sample_idx   dev i32 [B][500] or NULL.  NULL = full-mask mode (every masked pixel is used).
+ *              Non-NULL = reference-subsample mode: for an instance with N > 500 masked pixels
+ *              the 500 ranks (0 <= r < N, row-major order of True pixels) the reference would
+ *              draw at :124 select the points; rows of instances with N <= 500 are ignored.
+ * out          dev f64 [B][39]  (NaN where status != 0)
+ * status       dev i32 [B]
+ * aux          dev f64 [B][4] or NULL
+ * workspace    dev scratch of la3d_workspace_bytes(B,H,W) bytes (may be NULL when that is 0) */
+int la3d_fit_instances(const float* depth, int64_t depth_plane_stride, const int32_t* image_index,
+                       const uint8_t* mask, const double* K, int32_t k_stride,
+                       const double* ground, const int32_t* sample_idx,
+                       int B, int H, int W, double* out, int32_t* status, double* aux,
+                       void* workspace, void* stream);
+
+/* Replaces estimate_bbox(in_pc, cat_name, ground_equ, method) for B point clouds at once —
+ * reference src/util_3dbox.py:106-178 (caller :273-278, 500 mesh samples per object).
+ * points   dev f64 [total][3];  offsets dev i64 [B+1] (cloud n = rows offsets[n]..offsets[n+1])
+ * ground / sample_idx / out / status / aux as above (sample ranks index the cloud's rows).
+ * method   LA3D_METHOD_PCA or LA3D_METHOD_CONVEX_HULL (clouds of <= 500 rows after sampling). */
+int la3d_fit_points(const double* points, const int64_t* offsets, const double* ground,
+                    const int32_t* sample_idx, int method, int B,
+                    double* out, int32_t* status, double* aux, void* stream);
+
+/* Host-side helper exported for tests: float64 -> float16 (round-to-nearest-even, as NumPy's
+ * astype(float16), reference src/util_3dbox.py:165) -> float64, the same routine the kernels use. */
+double la3d_f16_round_host(double x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LA3D_H */

@@ -1,0 +1,23 @@
+"""labelany3d_amd — MI355X-native (gfx950) implementation of LabelAny3D's geometric hot path:
+depth back-projection (reference src/util.py:52-75) and oriented 3D box fitting (reference
+src/util_3dbox.py:106-178), behind the reference's own function signatures.
+
+    from labelany3d_amd import fit_instances            # batched: depth + masks -> (B,39) boxes on the GPU
+    from labelany3d_amd.util_3dbox import estimate_bbox # drop-in scalar signature
+    from labelany3d_amd.util import depth_to_points
+
+All compute goes through libla3d.so (hand-written HIP, C-ABI in include/la3d.h); there is no CPU path.
+"""
+from ._lib import REC, AUX, NSAMPLE, La3dError  # noqa: F401
+from .batched import (  # noqa: F401
+    InstanceFitter,
+    draw_sample_idx,
+    fit_instances,
+    fit_points,
+    mask_counts,
+    unproject,
+    unpack_boxes,
+)
+
+__all__ = ["fit_instances", "fit_points", "mask_counts", "unproject", "draw_sample_idx", "unpack_boxes",
+           "InstanceFitter", "La3dError", "REC", "AUX", "NSAMPLE"]

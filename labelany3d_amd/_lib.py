@@ -1,0 +1,56 @@
+"""ctypes binding of libla3d.so (C-ABI in include/la3d.h).  No CPU fallback: if the HIP library
+is missing, importing this module raises — the product path is the GPU path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from ._build import HERE, INCLUDE, LIB, ROOT, SRC, build  # noqa: F401
+
+REC, AUX, NSAMPLE = 39, 4, 500
+BOX_OK, BOX_EMPTY, BOX_BAD_GROUND, BOX_TOO_FEW, BOX_NONFINITE = 0, 1, 2, 3, 4
+METHOD_PCA, METHOD_CONVEX_HULL = 0, 1
+ERR_UNSUPPORTED = -2
+
+_SIGS = {
+    "la3d_version": (C.c_int, []),
+    "la3d_last_error": (C.c_char_p, []),
+    "la3d_unproject": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_int,
+                                 C.c_void_p, C.c_int, C.c_void_p]),
+    "la3d_mask_counts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "la3d_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "la3d_fit_instances": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                     C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "la3d_fit_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "la3d_f16_round_host": (C.c_double, [C.c_double]),
+}
+
+EXPORTS = tuple(_SIGS)
+
+
+def load() -> C.CDLL:
+    if not os.path.exists(LIB):
+        raise ImportError(
+            f"{LIB} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(needs hipcc; cross-compiles gfx950 without a GPU). There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = load()
+
+
+class La3dError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise La3dError(f"{what} failed ({rc}): {lib.la3d_last_error().decode()}")

@@ -1,0 +1,224 @@
+"""Batched, device-resident entry points over the C-ABI (include/la3d.h).
+
+PyTorch is used only for device memory and streams; every computation is a HIP kernel in
+libla3d.so.  Inputs may be torch tensors on the GPU (zero-copy) or NumPy arrays (uploaded).
+
+The composition these functions implement is defined in SURVEY.md §3.3:
+    boxes[n] = estimate_bbox(depth_to_points(depth[img(n)][None], K[img(n)])[masks[n]], None, ground[n], 'pca')
+with depth_to_points = reference src/util.py:52-75 and estimate_bbox = reference
+src/util_3dbox.py:106-178.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import AUX, NSAMPLE, REC, check, lib
+
+
+def _dev(device=None) -> torch.device:
+    if device is not None:
+        return torch.device(device)
+    if not torch.cuda.is_available():
+        raise _lib.La3dError("no GPU visible: labelany3d_amd has no CPU path (libla3d.so is a HIP library)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _as_dev(x, dtype, device) -> torch.Tensor:
+    if isinstance(x, torch.Tensor):
+        t = x
+        if t.dtype == torch.bool and dtype == torch.uint8:
+            t = t.view(torch.uint8) if t.is_contiguous() else t.contiguous().view(torch.uint8)
+        elif t.dtype != dtype:
+            t = t.to(dtype)
+        if t.device != device:
+            t = t.to(device)
+        return t.contiguous()
+    a = np.asarray(x)
+    if dtype == torch.uint8 and a.dtype == np.bool_:
+        a = a.view(np.uint8)
+    return torch.as_tensor(np.ascontiguousarray(a), device=device).to(dtype).contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(stream=None):
+    s = torch.cuda.current_stream() if stream is None else stream
+    return C.c_void_p(s.cuda_stream)
+
+
+def unpack_boxes(rec):
+    """(B,39) record -> dict of center_cam (B,3), dimensions (B,3) = [dz,dy,dx], R_cam (B,3,3),
+    bbox3D_cam (B,8,3): the four return values of the reference's estimate_bbox and the keys of its
+    3dbbox.json (reference src/util_3dbox.py:283-290)."""
+    return dict(center_cam=rec[..., 0:3], dimensions=rec[..., 3:6],
+                R_cam=rec[..., 6:15].reshape(*rec.shape[:-1], 3, 3),
+                bbox3D_cam=rec[..., 15:39].reshape(*rec.shape[:-1], 8, 3))
+
+
+def mask_counts(masks, stream=None) -> torch.Tensor:
+    """True pixels per mask plane (what the reference sees as in_pc.shape[0], :123)."""
+    dev = masks.device if isinstance(masks, torch.Tensor) and masks.is_cuda else _dev()
+    m = _as_dev(masks, torch.uint8, dev)
+    B, H, W = m.shape
+    out = torch.empty(B, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.la3d_mask_counts(_ptr(m), B, H, W, _ptr(out), _stream(stream)), "la3d_mask_counts")
+    return out
+
+
+def draw_sample_idx(counts, rng=None) -> np.ndarray:
+    """The indices the reference would draw, in instance order, from the global NumPy stream:
+    ``np.random.randint(0, N, 500)`` for every instance with N > 500 (reference
+    src/util_3dbox.py:123-125); instances with N <= 500 consume nothing (row left 0)."""
+    counts = np.asarray(counts.cpu() if isinstance(counts, torch.Tensor) else counts)
+    rng = np.random if rng is None else rng
+    idx = np.zeros((len(counts), NSAMPLE), np.int32)
+    for n, c in enumerate(counts):
+        if c > NSAMPLE:
+            idx[n] = rng.randint(0, int(c), NSAMPLE)
+    return idx
+
+
+class InstanceFitter:
+    """Reusable launch state for fit_instances on fixed (B,H,W): owns the output / status / aux /
+    workspace buffers so the steady-state call allocates nothing and is a pure enqueue."""
+
+    def __init__(self, B: int, H: int, W: int, device=None, slots: int = 1):
+        self.B, self.H, self.W = int(B), int(H), int(W)
+        self.device = _dev(device)
+        self.slots = slots
+        self.boxes = torch.empty((slots, B, REC), dtype=torch.float64, device=self.device)
+        self.status = torch.empty((slots, B), dtype=torch.int32, device=self.device)
+        self.aux = torch.empty((slots, B, AUX), dtype=torch.float64, device=self.device)
+        nbytes = int(lib.la3d_workspace_bytes(self.B, self.H, self.W))
+        self.workspace = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=self.device)
+
+    def run(self, depth: torch.Tensor, masks: torch.Tensor, K: torch.Tensor, ground=None, sample_idx=None,
+            image_index=None, slot: int = 0, stream=None):
+        """All arguments already on the device with the ABI's dtypes (f32 / u8 / f64 / f64 / i32 / i32)."""
+        B, H, W = self.B, self.H, self.W
+        planes = depth.shape[0] if depth.dim() == 3 else 1
+        dstride = H * W if planes > 1 else 0
+        kstride = 9 if (K.dim() == 3 and K.shape[0] > 1) else 0
+        rc = lib.la3d_fit_instances(_ptr(depth), dstride, _ptr(image_index), _ptr(masks), _ptr(K), kstride,
+                                    _ptr(ground), _ptr(sample_idx), B, H, W, _ptr(self.boxes[slot]),
+                                    _ptr(self.status[slot]), _ptr(self.aux[slot]), _ptr(self.workspace),
+                                    _stream(stream))
+        check(rc, "la3d_fit_instances")
+        return self.boxes[slot], self.status[slot], self.aux[slot]
+
+
+def fit_instances(depth, masks, K, ground=None, sample_idx=None, image_index=None, stream=None, device=None):
+    """Batched composed hot path on the GPU.
+
+    depth        (P,H,W) or (H,W) float32 — P planes; one plane = shared by all instances
+    masks        (B,H,W) bool / uint8 (non-zero = True), reference layout src/util.py:367,382
+    K            (P,3,3) or (3,3) float64 pixel intrinsics
+    ground       (B,4) float64 or None; rows whose first entry is NaN mean "no ground"
+    sample_idx   None = full-mask mode; (B,500) int = reference-subsample mode (see draw_sample_idx)
+    image_index  (B,) int — depth plane / K of each instance (default: instance n -> plane n, or 0)
+    Returns (boxes (B,39) f64, status (B,) i32, aux (B,4) f64 = yaw, n_valid, n_masked, eigen-gap), on the GPU.
+    """
+    if device is None and isinstance(masks, torch.Tensor) and masks.is_cuda:
+        device = masks.device
+    dev = _dev(device)
+    m = _as_dev(masks, torch.uint8, dev)
+    if m.dim() != 3:
+        raise ValueError("masks must be (B,H,W)")
+    B, H, W = m.shape
+    d = _as_dev(depth, torch.float32, dev)
+    if d.dim() == 2:
+        d = d[None]
+    if d.shape[1:] != (H, W):
+        raise ValueError(f"depth planes {tuple(d.shape[1:])} do not match masks {(H, W)}")
+    k = _as_dev(K, torch.float64, dev)
+    if k.dim() == 2:
+        k = k[None]
+    P = d.shape[0]
+    if k.shape[0] not in (1, P) or k.shape[1:] != (3, 3):
+        raise ValueError("K must be (3,3) or (P,3,3)")
+    ii = None
+    if image_index is not None:
+        ii = _as_dev(image_index, torch.int32, dev)
+        if ii.shape != (B,):
+            raise ValueError("image_index must be (B,)")
+        if B and (int(ii.min()) < 0 or int(ii.max()) >= P):
+            raise ValueError("image_index out of range")
+    elif P not in (1, B):
+        raise ValueError("without image_index, depth must have 1 or B planes")
+    g = None
+    if ground is not None:
+        g = _as_dev(ground, torch.float64, dev)
+        if g.shape != (B, 4):
+            raise ValueError("ground must be (B,4)")
+    si = None
+    if sample_idx is not None:
+        si = _as_dev(sample_idx, torch.int32, dev)
+        if si.shape != (B, NSAMPLE):
+            raise ValueError("sample_idx must be (B,500)")
+    with torch.cuda.device(dev):
+        f = InstanceFitter(B, H, W, dev)
+        if B == 0:
+            return f.boxes[0], f.status[0], f.aux[0]
+        if k.shape[0] == 1 and P > 1:
+            k = k.expand(P, 3, 3).contiguous()
+        return f.run(d if P > 1 else d[0], m, k, g, si, ii, stream=stream)
+
+
+def fit_points(clouds, ground=None, sample_idx=None, method: str = "pca", stream=None, device=None):
+    """estimate_bbox for a list of (N_i,3) clouds in one launch (reference src/util_3dbox.py:106-178).
+
+    clouds: list of arrays/tensors, or a tuple (points (T,3) f64, offsets (B+1,) i64).
+    Returns (boxes (B,39), status (B,), aux (B,4)) on the GPU.
+    """
+    dev = _dev(device)
+    if isinstance(clouds, tuple):
+        pts = _as_dev(clouds[0], torch.float64, dev)
+        off = _as_dev(clouds[1], torch.int64, dev)
+    else:
+        lens = [int(len(c)) for c in clouds]
+        off = torch.as_tensor(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64), device=dev)
+        if sum(lens):
+            pts = torch.cat([_as_dev(c, torch.float64, dev).reshape(-1, 3) for c in clouds if len(c)])
+        else:
+            pts = torch.zeros((1, 3), dtype=torch.float64, device=dev)
+    B = off.numel() - 1
+    meth = {"pca": _lib.METHOD_PCA, "convex_hull": _lib.METHOD_CONVEX_HULL}.get(method)
+    if meth is None:
+        raise ValueError(f"Unknown method: {method}. Use 'pca' or 'convex_hull'")  # reference :151
+    g = None if ground is None else _as_dev(ground, torch.float64, dev)
+    si = None if sample_idx is None else _as_dev(sample_idx, torch.int32, dev)
+    boxes = torch.empty((B, REC), dtype=torch.float64, device=dev)
+    status = torch.empty(B, dtype=torch.int32, device=dev)
+    aux = torch.empty((B, AUX), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.la3d_fit_points(_ptr(pts), _ptr(off), _ptr(g), _ptr(si), meth, B, _ptr(boxes), _ptr(status),
+                                  _ptr(aux), _stream(stream)), "la3d_fit_points")
+    return boxes, status, aux
+
+
+def unproject(depth, K, R=None, t=None, out_dtype=torch.float64, stream=None, device=None) -> torch.Tensor:
+    """depth (H,W) float32 -> (H,W,3) points on the GPU (reference src/util.py:52-75)."""
+    if device is None and isinstance(depth, torch.Tensor) and depth.is_cuda:
+        device = depth.device
+    dev = _dev(device)
+    d = _as_dev(depth, torch.float32, dev)
+    H, W = d.shape
+    K9 = (C.c_double * 9)(*np.asarray(K.cpu() if isinstance(K, torch.Tensor) else K, dtype=np.float64).ravel())
+    Rt = None
+    if R is not None or t is not None:
+        Rm = np.eye(3) if R is None else np.asarray(R, dtype=np.float64)
+        tv = np.zeros(3) if t is None else np.asarray(t, dtype=np.float64)
+        Rt = (C.c_double * 12)(*Rm.ravel(), *tv.ravel())
+    out = torch.empty((H, W, 3), dtype=out_dtype, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.la3d_unproject(_ptr(d), K9, Rt, H, W, _ptr(out), int(out_dtype == torch.float64), _stream(stream)),
+              "la3d_unproject")
+    return out

@@ -1,0 +1,941 @@
+// la3d.hip — MI355X (gfx950 / CDNA4) kernels and C-ABI for the LabelAny3D geometric hot path:
+// pinhole back-projection of masked depth pixels -> per-object moments -> closed-form PCA yaw
+// -> extents along the principal axes -> 39-double box record.
+//
+// Reference semantics (behaviour only; nothing is copied):
+//   depth_to_points   /root/reference/src/util.py:52-75
+//   estimate_bbox     /root/reference/src/util_3dbox.py:106-178   (+ helpers :20-103, PCA yaw :181-186)
+//
+// Memory-bound integer/byte + fp64 reduction work: no MFMA.  Layout and kernel design are
+// described in DESIGN.md; the short version for the fused kernel `fit_instances_kernel`:
+//   one 512-thread workgroup (8 wave64) per instance;
+//   phase 0  streams the u8 mask plane once with 16-byte non-temporal loads and packs it to a
+//            1-bit-per-pixel image in LDS (38.4 KB for 640x480);
+//   pass A   walks the bit image, 4 pixels per lane; only quads with a set bit load their
+//            float4 of depth (coalesced 1 KB per wave), unproject in fp64 and accumulate
+//            n, Sx, Sz, Sxx, Sxz, Szz, ymin, ymax per lane -> wave shuffle reduce -> LDS -> thread 0;
+//   yaw      closed-form 2x2 principal axis with scikit-learn's sign rule (thread 0);
+//   pass B   same walk (depth now L2/Infinity-Cache resident), min/max of the yaw-rotated x,z;
+//   epilog   thread 0 writes center / dims / R_cam / fp16-quantised vertices.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "la3d.h"
+
+namespace {
+
+constexpr int NT = 512;          // threads per workgroup (fit_instances)
+constexpr int NWAVE = NT / 64;   // wave64
+constexpr int NTP = 256;         // threads per workgroup (fit_points)
+constexpr int NWAVEP = NTP / 64;
+constexpr double PI_2 = 1.57079632679489661923;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // native vector: usable with nontemporal builtins
+
+thread_local char g_err[256] = "";
+
+void set_err(const char* fmt, const char* a = "") { snprintf(g_err, sizeof(g_err), fmt, a); }
+
+// ------------------------------------------------------------------------------------------
+// float64 -> float16 (round to nearest even, overflow to inf, gradual underflow) -> float64.
+// Mirrors numpy's astype(float16) applied to the 8 corners at reference src/util_3dbox.py:165.
+// ------------------------------------------------------------------------------------------
+__host__ __device__ inline double f16_round(double x) {
+  if (x != x) return x;
+  const double ax = fabs(x);
+  if (ax >= 65520.0) return x > 0 ? INFINITY : -INFINITY;  // halfway to 65536 rounds to even = overflow
+  double q;
+  if (ax < 6.103515625e-05) {  // below 2^-14: half subnormals, fixed quantum 2^-24
+    q = 5.9604644775390625e-08;
+  } else {
+    int e;
+    (void)frexp(ax, &e);       // ax = m * 2^e, m in [0.5, 1)  ->  floor(log2 ax) = e - 1
+    q = ldexp(1.0, e - 11);    // 10 explicit mantissa bits
+  }
+  return rint(x / q) * q;      // both scalings are exact powers of two; rint is RNE
+}
+
+// ------------------------------------------------------------------------------------------
+// small fp64 algebra, done by one thread per box
+// ------------------------------------------------------------------------------------------
+// 3x3 inverse by Gaussian elimination with partial pivoting on [A | I] (np.linalg.inv is LAPACK
+// gesv: same elimination order; reference src/util.py:56).
+__device__ inline void inv3(const double* A, double* X) {
+  double a[3][6];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      a[i][j] = A[i * 3 + j];
+      a[i][3 + j] = (i == j) ? 1.0 : 0.0;
+    }
+  for (int c = 0; c < 3; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < 3; ++r)
+      if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
+    if (piv != c)
+      for (int j = 0; j < 6; ++j) {
+        double t = a[c][j];
+        a[c][j] = a[piv][j];
+        a[piv][j] = t;
+      }
+    const double inv = 1.0 / a[c][c];
+    for (int r = c + 1; r < 3; ++r) {
+      const double f = a[r][c] * inv;
+      for (int j = c; j < 6; ++j) a[r][j] -= f * a[c][j];
+    }
+  }
+  for (int j = 0; j < 3; ++j) {  // back substitution per right-hand side
+    for (int r = 2; r >= 0; --r) {
+      double s = a[r][3 + j];
+      for (int k = r + 1; k < 3; ++k) s -= a[r][k] * X[k * 3 + j];
+      X[r * 3 + j] = s / a[r][r];
+    }
+  }
+}
+
+// Rg of reference src/util_3dbox.py:128-134 (+ :20-25, :37-55).  ground == nullptr or a NaN
+// first component selects the identity ("ground_equ is None").  Returns 1 when the matrix
+// is not finite (parallel / antiparallel / zero ground vector -> 0/0).
+__device__ inline int ground_rotation(const double* ground, double* Rg) {
+  for (int i = 0; i < 9; ++i) Rg[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  if (ground == nullptr) return 0;
+  double g0 = ground[0], g1 = ground[1], g2 = ground[2];
+  if (g0 != g0) return 0;
+  // dot([0,-1,0], g) = 0*g0 + (-1)*g1 + 0*g2  <= 0  -> negate           (:129-131)
+  const double dotp = 0.0 * g0 + (-1.0) * g1 + 0.0 * g2;
+  if (dotp <= 0) { g0 = -g0; g1 = -g1; g2 = -g2; }
+  const double nrm = sqrt(g0 * g0 + g1 * g1 + g2 * g2);  // normalize(): unchanged when 0 (:20-25)
+  if (nrm != 0) { g0 /= nrm; g1 /= nrm; g2 /= nrm; }
+  // vec1 = [0,-1,0];  axis = cross(vec1, vec2);  cos = dot(vec1, vec2)   (:43-44)
+  const double ax = (-1.0) * g2 - 0.0 * g1;
+  const double ay = 0.0 * g0 - 0.0 * g2;
+  const double az = 0.0 * g1 - (-1.0) * g0;
+  const double cs = 0.0 * g0 + (-1.0) * g1 + 0.0 * g2;
+  const double k[9] = {0, -az, ay, az, 0, -ax, -ay, ax, 0};
+  const double an = sqrt(ax * ax + ay * ay + az * az);
+  const double f = (1.0 - cs) / (an * an);
+  int bad = 0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double kk = 0;
+      for (int m = 0; m < 3; ++m) kk += k[i * 3 + m] * k[m * 3 + j];
+      const double r = ((i == j) ? 1.0 : 0.0) + k[i * 3 + j] + kk * f;
+      Rg[i * 3 + j] = r;
+      if (!(fabs(r) <= 1.79769313486231570815e308)) bad = 1;
+    }
+  return bad;
+}
+
+// scikit-learn PCA(2) first axis in closed form + svd_flip(u_based_decision=False)
+// (reference src/util_3dbox.py:181-186).  Raw sums -> (cos yaw, sin yaw), eigen-gap.
+// The reference goes eigenvector -> atan2 -> cos/sin; here the unit eigenvector (vx, vz) IS
+// (cos yaw, sin yaw), obtained without trigonometry from cos 2t = (a-c)/2r, sin 2t = b/r by the
+// stable half-angle form (agrees with the trig route to ~1 ulp; keeps fp64 libm range reduction out
+// of the streaming kernel's register budget and off the per-workgroup serial path).
+__device__ inline void axis_from_sums(double n, double sx, double sz, double sxx, double sxz, double szz,
+                                      double* cyaw, double* syaw, double* gap) {
+  const double a = sxx - sx * sx / n;
+  const double c = szz - sz * sz / n;
+  const double b = sxz - sx * sz / n;
+  const double half = 0.5 * (a - c);
+  const double rad = sqrt(half * half + b * b);
+  const double l1 = 0.5 * (a + c) + rad;
+  *gap = (l1 > 0) ? 2.0 * rad / l1 : 0.0;
+  if (b == 0 && a == c) {  // exact isotropy: eigh branch (n >= 20) -> yaw = pi/2; SVD branch recorded as 0
+    if (n >= 20) { *cyaw = 6.123233995736766e-17; *syaw = 1.0; }  // np.cos(pi/2), np.sin(pi/2)
+    else { *cyaw = 1.0; *syaw = 0.0; }
+    return;
+  }
+  const double c2 = half / rad, s2 = b / rad;
+  double vx, vz;  // (cos t, sin t), t in [-pi/2, pi/2]
+  if (c2 >= 0) { vx = sqrt(0.5 * (1.0 + c2)); vz = 0.5 * s2 / vx; }
+  else { vz = copysign(sqrt(0.5 * (1.0 - c2)), s2); vx = 0.5 * s2 / vz; }
+  if (fabs(vx) >= fabs(vz)) {   // svd_flip: the larger-|.| entry becomes positive, first index on ties
+    if (vx < 0) { vx = -vx; vz = -vz; }
+  } else if (vz < 0) {
+    vx = -vx; vz = -vz;
+  }
+  *cyaw = vx; *syaw = vz;
+}
+
+// Steps (6)-(12) of estimate_bbox (reference src/util_3dbox.py:157-176) from the extents.
+__device__ inline void write_box(double* out, const double* Rg, double cyaw, double syaw,
+                                 double xmin, double xmax, double ymin, double ymax, double zmin, double zmax) {
+  const double dx = xmax - xmin, dy = ymax - ymin, dz = zmax - zmin;
+  const double c[3] = {(xmin + xmax) / 2, (ymin + ymax) / 2, (zmin + zmax) / 2};
+  const double h[3] = {dx / 2, dy / 2, dz / 2};
+  // rotate_y(-yaw): cos(-y) = cos y, sin(-y) = -sin y                     (:28-34)
+  const double Ry[9] = {cyaw, 0, -syaw, 0, 1, 0, syaw, 0, cyaw};
+  // center_cam = Rg^T @ (rotate_y(-yaw) @ c)                              (:172-173)
+  double w[3];
+  for (int i = 0; i < 3; ++i) w[i] = Ry[i * 3] * c[0] + Ry[i * 3 + 1] * c[1] + Ry[i * 3 + 2] * c[2];
+  for (int i = 0; i < 3; ++i) out[i] = Rg[i] * w[0] + Rg[3 + i] * w[1] + Rg[6 + i] * w[2];
+  out[3] = dz; out[4] = dy; out[5] = dx;                                // dimension = [dz, dy, dx]  (:175)
+  // R_cam = Rg^T @ rotate_y(-yaw)                                         (:176)
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      out[6 + i * 3 + j] = Rg[i] * Ry[j] + Rg[3 + i] * Ry[3 + j] + Rg[6 + i] * Ry[6 + j];
+  // 8 corners, fixed sign order (:83-92), fp16 cast (:165), un-rotate with rotate_y(-yaw) then Rg (:168-169)
+  const int sg[8][3] = {{-1, -1, -1}, {1, -1, -1}, {1, 1, -1}, {-1, 1, -1}, {-1, -1, 1}, {1, -1, 1}, {1, 1, 1}, {-1, 1, 1}};
+  for (int v = 0; v < 8; ++v) {
+    double g[3], r[3];
+    for (int i = 0; i < 3; ++i) g[i] = f16_round(sg[v][i] * h[i] + c[i]);
+    for (int i = 0; i < 3; ++i) r[i] = Ry[i * 3] * g[0] + Ry[i * 3 + 1] * g[1] + Ry[i * 3 + 2] * g[2];
+    for (int i = 0; i < 3; ++i) out[15 + v * 3 + i] = r[0] * Rg[i * 3] + r[1] * Rg[i * 3 + 1] + r[2] * Rg[i * 3 + 2];
+  }
+}
+
+__device__ inline void write_nan_box(double* out) {
+  for (int i = 0; i < LA3D_REC; ++i) out[i] = NAN;
+}
+
+// ------------------------------------------------------------------------------------------
+// wave64 reductions (fixed butterfly order -> deterministic)
+// ------------------------------------------------------------------------------------------
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ inline double wave_min(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ inline double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ inline int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// XCD-aware block -> work-item map: the dispatcher is observed to place block b on XCD b % 8
+// (speed only, never correctness), so consecutive instances — which share an image's depth
+// plane in the shared-depth layout — land on one XCD's L2.  Bijective for any nb.
+__device__ inline int xcd_remap(int b, int nb) {
+  const int q = nb >> 3, r = nb & 7, x = b & 7;
+  const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + (b >> 3);
+}
+
+// 4 mask bytes -> 4 bits (bit k = byte k non-zero)
+__device__ inline unsigned nz4(unsigned w) {
+  const unsigned t = (((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u;  // high bit of each non-zero byte
+  return ((t >> 7) * 0x01020408u) >> 24;                                       // gather bits 0,8,16,24 -> 0..3
+}
+__device__ inline bool finite_f32(float d) { return (__float_as_uint(d) & 0x7f800000u) != 0x7f800000u; }
+
+struct FitParams {
+  const float* depth;
+  long long depth_plane_stride;
+  const int* image_index;
+  const unsigned char* mask;
+  const double* K;
+  int k_stride;
+  const double* ground;
+  const int* sample_idx;
+  int B, H, W, HW;
+  int nwords;          // ceil(HW / 32) bit-image words
+  int mask_lds_bytes;  // bit-image bytes in LDS (16-aligned), 0 when the image does not fit
+  int rows_aligned;    // W % 4 == 0: a 4-pixel quad never straddles a row
+  float rcpW;
+  double* geo;         // workspace: [B][GEO_D]
+  double* out;
+  int* status;
+  double* aux;
+};
+
+// per-instance geometry written by prep_kernel into the workspace (20 doubles = 160 B)
+constexpr int GEO_D = 20;  // M[9] (= Rg^T Kinv : p' = d * (M @ [u,v,1])), Rg[9], bad_ground, pad
+
+struct alignas(16) Shared {
+  double part[NWAVE][8];
+  double N0[3];   // row 0 of rotate_y(yaw) @ M
+  double N2[3];   // row 2 of rotate_y(yaw) @ M
+  double cyaw, syaw;
+  int cnt[NWAVE];
+  int nmask[NWAVE];
+  unsigned scan[NWAVE];
+  int n_valid;
+  int st;
+};
+
+__device__ inline void pix_uv(unsigned i, int W, float rcpW, unsigned* u, unsigned* v) {
+  unsigned vv = (unsigned)((float)i * rcpW);
+  int r = (int)i - (int)(vv * (unsigned)W);
+  if (r < 0) { vv -= 1; r += W; }
+  else if (r >= W) { vv += 1; r -= W; }
+  *u = (unsigned)r;
+  *v = vv;
+}
+
+// One walk over the instance's pixels, 4 per lane.  PASS 0: moments + y extent.  PASS 1: x/z extent
+// in the yaw frame.  A (3x3 row-major) maps [u,v,1] to the ray whose components are accumulated:
+// PASS 0 uses rows 0,1,2 of M; PASS 1 uses N0 (as row 0) and N2 (as row 2).
+template <bool VEC, bool LDSMASK, int PASS>
+__device__ inline void sweep(const FitParams& p, const float* __restrict__ dpl, const unsigned char* __restrict__ mpl,
+                             const unsigned* bits, const double* A0, const double* A1, const double* A2,
+                             int wave, int lane, double* acc, int* cnt, int* nmask) {
+  const int HW = p.HW, W = p.W;
+  const int nquads = (HW + 3) >> 2;
+  const int nchunks = (nquads + 63) >> 6;
+  const double a00 = A0[0], a01 = A0[1], a02 = A0[2];
+  const double a20 = A2[0], a21 = A2[1], a22 = A2[2];
+  double a10 = 0, a11 = 0, a12 = 0;
+  if (PASS == 0) { a10 = A1[0]; a11 = A1[1]; a12 = A1[2]; }
+  double s0 = acc[0], s1 = acc[1], s2 = acc[2], s3 = acc[3], s4 = acc[4], lo = acc[5], hi = acc[6];
+  double lo2 = acc[5], hi2 = acc[6];
+  if (PASS == 1) { lo = acc[0]; hi = acc[1]; lo2 = acc[2]; hi2 = acc[3]; }
+  int n = *cnt, nm = *nmask;
+  for (int ch = wave; ch < nchunks; ch += NWAVE) {
+    const int q = ch * 64 + lane;
+    unsigned nib = 0;
+    if (q < nquads) {
+      if (LDSMASK) {
+        nib = (bits[q >> 3] >> ((q & 7) * 4)) & 0xFu;
+      } else {
+        const int i0 = q * 4;
+        if (VEC) {
+          nib = nz4(*(const unsigned*)(mpl + i0));
+        } else {
+          for (int k = 0; k < 4; ++k)
+            if (i0 + k < HW && mpl[i0 + k]) nib |= 1u << k;
+        }
+        if (PASS == 0) nm += __popc(nib);
+      }
+    }
+    if (__ballot(nib != 0) == 0) continue;  // wave-uniform skip: nothing of this 256-pixel chunk is masked
+    if (nib) {
+      const unsigned i0 = (unsigned)q * 4u;
+      float dk[4];
+      if (VEC) {
+        const float4 t = *(const float4*)(dpl + i0);
+        dk[0] = t.x; dk[1] = t.y; dk[2] = t.z; dk[3] = t.w;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dk[k] = ((int)(i0 + k) < HW && ((nib >> k) & 1u)) ? dpl[i0 + k] : 0.f;
+      }
+      unsigned u0, v0;
+      pix_uv(i0, W, p.rcpW, &u0, &v0);
+      const double vd = (double)v0;
+      const double b0 = fma(a01, vd, a02), b2 = fma(a21, vd, a22);
+      double b1 = 0;
+      if (PASS == 0) b1 = fma(a11, vd, a12);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool ok = ((nib >> k) & 1u) && finite_f32(dk[k]);
+        double r0, r1 = 0, r2;
+        if (p.rows_aligned) {
+          const double ud = (double)(u0 + k);
+          r0 = fma(a00, ud, b0); r2 = fma(a20, ud, b2);
+          if (PASS == 0) r1 = fma(a10, ud, b1);
+        } else {
+          unsigned uk, vk;
+          pix_uv(i0 + k, W, p.rcpW, &uk, &vk);
+          const double ud = (double)uk, vdk = (double)vk;
+          r0 = fma(a00, ud, fma(a01, vdk, a02)); r2 = fma(a20, ud, fma(a21, vdk, a22));
+          if (PASS == 0) r1 = fma(a10, ud, fma(a11, vdk, a12));
+        }
+        const double d = ok ? (double)dk[k] : 0.0;
+        const double x = d * r0, z = d * r2;
+        if (PASS == 0) {
+          const double y = d * r1;
+          s0 += x; s1 += z;
+          s2 = fma(x, x, s2); s3 = fma(x, z, s3); s4 = fma(z, z, s4);
+          n += ok ? 1 : 0;
+          if (ok) { lo = fmin(lo, y); hi = fmax(hi, y); }
+        } else {
+          if (ok) { lo = fmin(lo, x); hi = fmax(hi, x); lo2 = fmin(lo2, z); hi2 = fmax(hi2, z); }
+        }
+      }
+    }
+  }
+  if (PASS == 0) {
+    acc[0] = s0; acc[1] = s1; acc[2] = s2; acc[3] = s3; acc[4] = s4; acc[5] = lo; acc[6] = hi;
+    *cnt = n; *nmask = nm;
+  } else {
+    acc[0] = lo; acc[1] = hi; acc[2] = lo2; acc[3] = hi2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-instance geometry: Kinv, Rg, M = Rg^T Kinv  (one thread per instance; keeps the 3x3
+// elimination and Rodrigues algebra out of the streaming kernel's register budget)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void prep_kernel(const FitParams p) {
+  const int inst = blockIdx.x * 64 + threadIdx.x;
+  if (inst >= p.B) return;
+  const int img = p.image_index ? p.image_index[inst] : inst;
+  double Kinv[9], Rg[9];
+  inv3(p.K + (long long)img * p.k_stride, Kinv);
+  const int bad = ground_rotation(p.ground ? p.ground + (long long)inst * 4 : nullptr, Rg);
+  double* g = p.geo + (long long)inst * GEO_D;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) g[i * 3 + j] = Rg[i] * Kinv[j] + Rg[3 + i] * Kinv[3 + j] + Rg[6 + i] * Kinv[6 + j];
+  for (int i = 0; i < 9; ++i) g[9 + i] = Rg[i];
+  g[18] = bad ? 1.0 : 0.0;
+  g[19] = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------
+// fused kernel: one workgroup per instance
+// ------------------------------------------------------------------------------------------
+template <bool VEC, bool LDSMASK, bool SAMPLE>
+__global__ __launch_bounds__(NT, 8) void fit_instances_kernel(const FitParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned* bits = reinterpret_cast<unsigned*>(smem);
+  Shared* sh = reinterpret_cast<Shared*>(smem + p.mask_lds_bytes);
+  unsigned* prefix = reinterpret_cast<unsigned*>(smem + p.mask_lds_bytes + sizeof(Shared));  // SAMPLE only
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int inst = xcd_remap(blockIdx.x, p.B);
+  const int img = p.image_index ? p.image_index[inst] : inst;
+  const int HW = p.HW;
+  const float* dpl = p.depth + (long long)img * p.depth_plane_stride;
+  const unsigned char* mpl = p.mask + (long long)inst * HW;
+
+  const double* geo = p.geo + (long long)inst * GEO_D;  // uniform address -> scalar loads
+  const double* Mg = geo;
+  const double* Rgg = geo + 9;
+
+  // ---- phase 0: u8 mask plane -> bit image in LDS --------------------------------------
+  int nmask = 0;
+  if (LDSMASK) {
+    unsigned short* b16 = reinterpret_cast<unsigned short*>(bits);
+    const int ngroups = (HW + 15) >> 4;
+    if (VEC) {
+      const u32x4* m4 = reinterpret_cast<const u32x4*>(mpl);
+#pragma unroll 4
+      for (int g = tid; g < ngroups; g += NT) {
+        const u32x4 w = __builtin_nontemporal_load(m4 + g);
+        const unsigned pat = nz4(w.x) | (nz4(w.y) << 4) | (nz4(w.z) << 8) | (nz4(w.w) << 12);
+        b16[g] = (unsigned short)pat;
+        nmask += __popc(pat);
+      }
+    } else {
+      for (int g = tid; g < ngroups; g += NT) {
+        unsigned pat = 0;
+        for (int k = 0; k < 16; ++k) {
+          const int i = g * 16 + k;
+          if (i < HW && mpl[i]) pat |= 1u << k;
+        }
+        b16[g] = (unsigned short)pat;
+        nmask += __popc(pat);
+      }
+    }
+    if ((ngroups & 1) && tid == 0) b16[ngroups] = 0;  // upper half of the last 32-bit word
+  }
+  __syncthreads();
+
+  // ---- pass A: moments ------------------------------------------------------------------
+  double acc[7] = {0, 0, 0, 0, 0, INFINITY, -INFINITY};
+  int cnt = 0;
+  // sampled-point state (SAMPLE only): the point of this thread in the ground-aligned frame
+  double px = 0, py = 0, pz = 0;
+  bool pok = false;
+  bool sampled = false;
+
+  if (SAMPLE) {
+    // the reference subsamples when in_pc.shape[0] > 500 (src/util_3dbox.py:123): needs N first
+    const int wsum = wave_sum_i(nmask);
+    if (lane == 0) sh->nmask[wave] = wsum;
+    __syncthreads();
+    int ntot = 0;
+    for (int w = 0; w < NWAVE; ++w) ntot += sh->nmask[w];
+    sampled = ntot > LA3D_NSAMPLE;
+    if (sampled) {
+      // exclusive prefix of per-word popcounts: thread t owns words [t*per, t*per+per)
+      const int per = (p.nwords + NT - 1) / NT;
+      const int w0 = tid * per;
+      unsigned local = 0;
+      for (int i = 0; i < per; ++i)
+        if (w0 + i < p.nwords) local += __popc(bits[w0 + i]);
+      unsigned incl = local;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+      }
+      if (lane == 63) sh->scan[wave] = incl;
+      __syncthreads();
+      unsigned base = 0;
+      for (int w = 0; w < wave; ++w) base += sh->scan[w];
+      unsigned run = base + incl - local;
+      for (int i = 0; i < per; ++i)
+        if (w0 + i < p.nwords) { prefix[w0 + i] = run; run += __popc(bits[w0 + i]); }
+      __syncthreads();
+      if (tid < LA3D_NSAMPLE) {
+        int r = p.sample_idx[(long long)inst * LA3D_NSAMPLE + tid];
+        r = r < 0 ? 0 : (r >= ntot ? ntot - 1 : r);
+        int lo = 0, hi = p.nwords - 1;
+        while (lo < hi) {  // last word whose exclusive prefix is <= r
+          const int mid = (lo + hi + 1) >> 1;
+          if (prefix[mid] <= (unsigned)r) lo = mid; else hi = mid - 1;
+        }
+        unsigned w = bits[lo];
+        for (int k = r - (int)prefix[lo]; k > 0; --k) w &= w - 1;  // drop k lowest set bits
+        const unsigned i = (unsigned)lo * 32u + (unsigned)(__ffs((int)w) - 1);
+        const float df = dpl[i];
+        unsigned u, v;
+        pix_uv(i, p.W, p.rcpW, &u, &v);
+        const double ud = (double)u, vd = (double)v;
+        pok = finite_f32(df);
+        const double d = pok ? (double)df : 0.0;
+        px = d * fma(Mg[0], ud, fma(Mg[1], vd, Mg[2]));
+        py = d * fma(Mg[3], ud, fma(Mg[4], vd, Mg[5]));
+        pz = d * fma(Mg[6], ud, fma(Mg[7], vd, Mg[8]));
+        if (pok) {
+          acc[0] = px; acc[1] = pz; acc[2] = px * px; acc[3] = px * pz; acc[4] = pz * pz;
+          acc[5] = py; acc[6] = py;
+          cnt = 1;
+        }
+      }
+    }
+  }
+  if (!sampled) sweep<VEC, LDSMASK, 0>(p, dpl, mpl, bits, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, &nmask);
+
+  {
+    const double r0 = wave_sum(acc[0]), r1 = wave_sum(acc[1]), r2 = wave_sum(acc[2]), r3 = wave_sum(acc[3]),
+                 r4 = wave_sum(acc[4]), r5 = wave_min(acc[5]), r6 = wave_max(acc[6]);
+    const int rc = wave_sum_i(cnt), rn = wave_sum_i(nmask);
+    if (lane == 0) {
+      double* pp = sh->part[wave];
+      pp[0] = r0; pp[1] = r1; pp[2] = r2; pp[3] = r3; pp[4] = r4; pp[5] = r5; pp[6] = r6;
+      sh->cnt[wave] = rc;
+      sh->nmask[wave] = rn;
+    }
+  }
+  __syncthreads();
+
+  double ymin = 0, ymax = 0;
+  if (tid == 0) {
+    double s[5] = {0, 0, 0, 0, 0};
+    ymin = INFINITY; ymax = -INFINITY;
+    int n = 0, nm = 0;
+#pragma unroll 1
+    for (int w = 0; w < NWAVE; ++w) {  // fixed order (not unrolled: keeps thread 0's live set small)
+      for (int k = 0; k < 5; ++k) s[k] += sh->part[w][k];
+      ymin = fmin(ymin, sh->part[w][5]);
+      ymax = fmax(ymax, sh->part[w][6]);
+      n += sh->cnt[w];
+      nm += sh->nmask[w];
+    }
+    int st = LA3D_BOX_OK;
+    if (geo[18] != 0.0) st = LA3D_BOX_BAD_GROUND;
+    else if (n == 0) st = LA3D_BOX_EMPTY;
+    else if (n == 1) st = LA3D_BOX_TOO_FEW;
+    double cy = NAN, sy = NAN, gap = NAN;
+    if (st == LA3D_BOX_OK) axis_from_sums((double)n, s[0], s[1], s[2], s[3], s[4], &cy, &sy, &gap);
+    sh->cyaw = cy; sh->syaw = sy;
+    for (int j = 0; j < 3; ++j) {  // rotate_y(yaw) @ M, rows 0 and 2   (reference :154)
+      sh->N0[j] = cy * Mg[j] + sy * Mg[6 + j];
+      sh->N2[j] = -sy * Mg[j] + cy * Mg[6 + j];
+    }
+    sh->st = st;
+    sh->n_valid = n;
+    if (p.aux) {
+      double* a = p.aux + (long long)inst * LA3D_AUX;
+      a[0] = atan2(sy, cy); a[1] = (double)n; a[2] = (double)nm; a[3] = gap;
+    }
+    p.status[inst] = st;
+    if (st != LA3D_BOX_OK) write_nan_box(p.out + (long long)inst * LA3D_REC);
+  }
+  __syncthreads();
+  if (sh->st != LA3D_BOX_OK) return;
+
+  // ---- pass B: extents along the principal axes -----------------------------------------
+  double ext[7] = {INFINITY, -INFINITY, INFINITY, -INFINITY, 0, 0, 0};
+  if (sampled) {
+    if (pok) {  // exactly the reference's arithmetic: rotate_y(yaw) applied to the stored point
+      const double x2 = sh->cyaw * px + sh->syaw * pz;
+      const double z2 = -sh->syaw * px + sh->cyaw * pz;
+      ext[0] = ext[1] = x2;
+      ext[2] = ext[3] = z2;
+    }
+  } else {
+    int d0 = 0, d1 = 0;
+    sweep<VEC, LDSMASK, 1>(p, dpl, mpl, bits, sh->N0, nullptr, sh->N2, wave, lane, ext, &d0, &d1);
+  }
+  {
+    const double r0 = wave_min(ext[0]), r1 = wave_max(ext[1]), r2 = wave_min(ext[2]), r3 = wave_max(ext[3]);
+    if (lane == 0) {
+      double* pp = sh->part[wave];
+      pp[0] = r0; pp[1] = r1; pp[2] = r2; pp[3] = r3;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double xmin = INFINITY, xmax = -INFINITY, zmin = INFINITY, zmax = -INFINITY;
+#pragma unroll 1
+    for (int w = 0; w < NWAVE; ++w) {
+      xmin = fmin(xmin, sh->part[w][0]); xmax = fmax(xmax, sh->part[w][1]);
+      zmin = fmin(zmin, sh->part[w][2]); zmax = fmax(zmax, sh->part[w][3]);
+    }
+    write_box(p.out + (long long)inst * LA3D_REC, Rgg, sh->cyaw, sh->syaw, xmin, xmax, ymin, ymax, zmin, zmax);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// point-cloud fit: one workgroup per cloud  (estimate_bbox on explicit (N,3) float64 input)
+// ------------------------------------------------------------------------------------------
+struct PtsParams {
+  const double* points;
+  const long long* offsets;
+  const double* ground;
+  const int* sample_idx;
+  int B;
+  double* out;
+  int* status;
+  double* aux;
+};
+
+struct alignas(16) SharedP {
+  double part[NWAVEP][8];
+  double Rg[9];
+  double cyaw, syaw;
+  int cnt[NWAVEP];
+  int inf[NWAVEP];
+  int bad_ground;
+  int st;
+};
+
+__global__ __launch_bounds__(NTP) void fit_points_kernel(const PtsParams p) {
+  __shared__ SharedP sh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = blockIdx.x;
+  const long long off = p.offsets[c];
+  const long long n_in = p.offsets[c + 1] - off;
+  const bool sampled = p.sample_idx != nullptr && n_in > LA3D_NSAMPLE;  // reference :123
+  const long long m = sampled ? LA3D_NSAMPLE : n_in;
+  const int* sidx = sampled ? p.sample_idx + (long long)c * LA3D_NSAMPLE : nullptr;
+  if (tid == 0) sh.bad_ground = ground_rotation(p.ground ? p.ground + (long long)c * 4 : nullptr, sh.Rg);
+  __syncthreads();
+  const double R00 = sh.Rg[0], R01 = sh.Rg[1], R02 = sh.Rg[2], R10 = sh.Rg[3], R11 = sh.Rg[4], R12 = sh.Rg[5],
+               R20 = sh.Rg[6], R21 = sh.Rg[7], R22 = sh.Rg[8];
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, ylo = INFINITY, yhi = -INFINITY;
+  int n = 0, ninf = 0;
+  for (long long i = tid; i < m; i += NTP) {
+    long long row = i;
+    if (sampled) {
+      long long r = sidx[i];
+      row = r < 0 ? 0 : (r >= n_in ? n_in - 1 : r);
+    }
+    const double* q = p.points + (off + row) * 3;
+    const double a = q[0], b = q[1], cc = q[2];
+    // rotated = in_pc @ Rg                                                (:136)
+    const double x = a * R00 + b * R10 + cc * R20;
+    const double y = a * R01 + b * R11 + cc * R21;
+    const double z = a * R02 + b * R12 + cc * R22;
+    const bool ok = !(x != x || y != y || z != z);                      // drop rows with any NaN (:139-140)
+    if (ok) {
+      if (isinf(x) || isinf(z)) ninf += 1;                              // scikit-learn rejects inf in X
+      s0 += x; s1 += z; s2 = fma(x, x, s2); s3 = fma(x, z, s3); s4 = fma(z, z, s4);
+      ylo = fmin(ylo, y); yhi = fmax(yhi, y);
+      n += 1;
+    }
+  }
+  {
+    const double r0 = wave_sum(s0), r1 = wave_sum(s1), r2 = wave_sum(s2), r3 = wave_sum(s3), r4 = wave_sum(s4),
+                 r5 = wave_min(ylo), r6 = wave_max(yhi);
+    const int rc = wave_sum_i(n), ri = wave_sum_i(ninf);
+    if (lane == 0) {
+      double* pp = sh.part[wave];
+      pp[0] = r0; pp[1] = r1; pp[2] = r2; pp[3] = r3; pp[4] = r4; pp[5] = r5; pp[6] = r6;
+      sh.cnt[wave] = rc; sh.inf[wave] = ri;
+    }
+  }
+  __syncthreads();
+  double ymin = 0, ymax = 0;
+  if (tid == 0) {
+    double s[5] = {0, 0, 0, 0, 0};
+    ymin = INFINITY; ymax = -INFINITY;
+    int nn = 0, ni = 0;
+    for (int w = 0; w < NWAVEP; ++w) {
+      for (int k = 0; k < 5; ++k) s[k] += sh.part[w][k];
+      ymin = fmin(ymin, sh.part[w][5]); ymax = fmax(ymax, sh.part[w][6]);
+      nn += sh.cnt[w]; ni += sh.inf[w];
+    }
+    int st = LA3D_BOX_OK;
+    if (sh.bad_ground) st = LA3D_BOX_BAD_GROUND;
+    else if (nn == 0) st = LA3D_BOX_EMPTY;
+    else if (ni > 0) st = LA3D_BOX_NONFINITE;
+    else if (nn == 1) st = LA3D_BOX_TOO_FEW;
+    double cy = NAN, sy = NAN, gap = NAN;
+    if (st == LA3D_BOX_OK) axis_from_sums((double)nn, s[0], s[1], s[2], s[3], s[4], &cy, &sy, &gap);
+    sh.cyaw = cy; sh.syaw = sy; sh.st = st;
+    if (p.aux) {
+      double* a = p.aux + (long long)c * LA3D_AUX;
+      a[0] = atan2(sy, cy); a[1] = (double)nn; a[2] = (double)n_in; a[3] = gap;
+    }
+    p.status[c] = st;
+    if (st != LA3D_BOX_OK) write_nan_box(p.out + (long long)c * LA3D_REC);
+  }
+  __syncthreads();
+  if (sh.st != LA3D_BOX_OK) return;
+  const double cy = sh.cyaw, sy = sh.syaw;
+  double xlo = INFINITY, xhi = -INFINITY, zlo = INFINITY, zhi = -INFINITY;
+  for (long long i = tid; i < m; i += NTP) {
+    long long row = i;
+    if (sampled) {
+      long long r = sidx[i];
+      row = r < 0 ? 0 : (r >= n_in ? n_in - 1 : r);
+    }
+    const double* q = p.points + (off + row) * 3;
+    const double a = q[0], b = q[1], cc = q[2];
+    const double x = a * R00 + b * R10 + cc * R20;
+    const double y = a * R01 + b * R11 + cc * R21;
+    const double z = a * R02 + b * R12 + cc * R22;
+    if (!(x != x || y != y || z != z)) {
+      const double x2 = cy * x + sy * z, z2 = -sy * x + cy * z;  // rotate_y(yaw) @ rotated^T  (:154)
+      xlo = fmin(xlo, x2); xhi = fmax(xhi, x2); zlo = fmin(zlo, z2); zhi = fmax(zhi, z2);
+    }
+  }
+  {
+    const double r0 = wave_min(xlo), r1 = wave_max(xhi), r2 = wave_min(zlo), r3 = wave_max(zhi);
+    if (lane == 0) {
+      double* pp = sh.part[wave];
+      pp[0] = r0; pp[1] = r1; pp[2] = r2; pp[3] = r3;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double xmin = INFINITY, xmax = -INFINITY, zmin = INFINITY, zmax = -INFINITY;
+    for (int w = 0; w < NWAVEP; ++w) {
+      xmin = fmin(xmin, sh.part[w][0]); xmax = fmax(xmax, sh.part[w][1]);
+      zmin = fmin(zmin, sh.part[w][2]); zmax = fmax(zmax, sh.part[w][3]);
+    }
+    write_box(p.out + (long long)c * LA3D_REC, sh.Rg, cy, sy, xmin, xmax, ymin, ymax, zmin, zmax);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// depth_to_points for a whole frame (write-bound: 4 B in, 24 B out per pixel)
+// ------------------------------------------------------------------------------------------
+struct UnprojParams {
+  double Kinv[9];
+  double R[9];
+  double t[3];
+  int has_rt;
+  int H, W, HW;
+  float rcpW;
+};
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void unproject_kernel(const float* __restrict__ depth, OutT* __restrict__ out,
+                                                        const UnprojParams p) {
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < p.HW; i += stride) {
+    unsigned u, v;
+    pix_uv((unsigned)i, p.W, p.rcpW, &u, &v);
+    const double d = (double)depth[i], ud = (double)u, vd = (double)v;
+    // (D * Kinv) @ [u, v, 1]   — precedence as in the reference, src/util.py:71-72
+    double q[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) q[r] = (d * p.Kinv[r * 3]) * ud + (d * p.Kinv[r * 3 + 1]) * vd + (d * p.Kinv[r * 3 + 2]);
+    if (p.has_rt) {  // R @ p + t  (:74)
+      double w[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) w[r] = p.R[r * 3] * q[0] + p.R[r * 3 + 1] * q[1] + p.R[r * 3 + 2] * q[2] + p.t[r];
+      q[0] = w[0]; q[1] = w[1]; q[2] = w[2];
+    } else {
+      // R = I, t = 0 in the reference still multiplies: 1*x + 0*y + 0*z + 0 — a NaN/inf component
+      // poisons its neighbours exactly as there
+      const double w0 = 1.0 * q[0] + 0.0 * q[1] + 0.0 * q[2] + 0.0;
+      const double w1 = 0.0 * q[0] + 1.0 * q[1] + 0.0 * q[2] + 0.0;
+      const double w2 = 0.0 * q[0] + 0.0 * q[1] + 1.0 * q[2] + 0.0;
+      q[0] = w0; q[1] = w1; q[2] = w2;
+    }
+    OutT* o = out + (long long)i * 3;
+    o[0] = (OutT)q[0]; o[1] = (OutT)q[1]; o[2] = (OutT)q[2];
+  }
+}
+
+__global__ __launch_bounds__(256) void mask_counts_kernel(const unsigned char* __restrict__ mask, int HW, int vec,
+                                                          int* __restrict__ counts) {
+  __shared__ int part[4];
+  const unsigned char* m = mask + (long long)blockIdx.x * HW;
+  int n = 0;
+  if (vec) {
+    const uint4* m4 = reinterpret_cast<const uint4*>(m);
+    for (int g = threadIdx.x; g < HW / 16; g += 256) {
+      const uint4 w = m4[g];
+      n += __popc(nz4(w.x)) + __popc(nz4(w.y)) + __popc(nz4(w.z)) + __popc(nz4(w.w));
+    }
+  } else {
+    for (int i = threadIdx.x; i < HW; i += 256) n += m[i] ? 1 : 0;
+  }
+  n = wave_sum_i(n);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+// host-side 3x3 inverse (same elimination as inv3 above)
+void inv3_host(const double* A, double* X) {
+  double a[3][6];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) { a[i][j] = A[i * 3 + j]; a[i][3 + j] = (i == j) ? 1.0 : 0.0; }
+  for (int c = 0; c < 3; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < 3; ++r) if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
+    if (piv != c) for (int j = 0; j < 6; ++j) { double t = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = t; }
+    const double inv = 1.0 / a[c][c];
+    for (int r = c + 1; r < 3; ++r) { const double f = a[r][c] * inv; for (int j = c; j < 6; ++j) a[r][j] -= f * a[c][j]; }
+  }
+  for (int j = 0; j < 3; ++j)
+    for (int r = 2; r >= 0; --r) {
+      double s = a[r][3 + j];
+      for (int k = r + 1; k < 3; ++k) s -= a[r][k] * X[k * 3 + j];
+      X[r * 3 + j] = s / a[r][r];
+    }
+}
+
+int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return LA3D_ERR_HIP;
+  }
+  return LA3D_SUCCESS;
+}
+
+constexpr int MAX_MASK_LDS = 128 * 1024;  // bit image budget; larger frames re-read the u8 mask instead
+
+template <bool VEC, bool LDSMASK, bool SAMPLE>
+int launch_fit(const FitParams& p, size_t lds, hipStream_t s) {
+  auto kern = fit_instances_kernel<VEC, LDSMASK, SAMPLE>;
+  static bool attr_done = false;  // one flag per instantiation
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess) {
+      (void)hipGetLastError();
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.B), dim3(NT), lds, s, p);
+  return check_launch("fit_instances_kernel");
+}
+
+}  // namespace
+
+// ==========================================================================================
+// C-ABI
+// ==========================================================================================
+extern "C" {
+
+int la3d_version(void) { return LA3D_ABI_VERSION; }
+
+const char* la3d_last_error(void) { return g_err; }
+
+double la3d_f16_round_host(double x) { return f16_round(x); }
+
+size_t la3d_workspace_bytes(int B, int H, int W) {
+  (void)H; (void)W;
+  return B > 0 ? (size_t)B * GEO_D * sizeof(double) : 0;  // per-instance geometry (prep_kernel)
+}
+
+int la3d_unproject(const float* depth, const double* K9, const double* Rt12, int H, int W, void* out,
+                   int out_is_f64, void* stream) {
+  if (!depth || !K9 || !out || H <= 0 || W <= 0 || (long long)H * W > 0x7fffffffLL / 4) {
+    set_err("la3d_unproject: bad argument");
+    return LA3D_ERR_ARG;
+  }
+  UnprojParams p;
+  inv3_host(K9, p.Kinv);
+  p.has_rt = Rt12 != nullptr;
+  for (int i = 0; i < 9; ++i) p.R[i] = Rt12 ? Rt12[i] : ((i % 4 == 0) ? 1.0 : 0.0);
+  for (int i = 0; i < 3; ++i) p.t[i] = Rt12 ? Rt12[9 + i] : 0.0;
+  p.H = H; p.W = W; p.HW = H * W; p.rcpW = 1.0f / (float)W;
+  const int blocks = (p.HW + 255) / 256 < 2048 ? (p.HW + 255) / 256 : 2048;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (out_is_f64) hipLaunchKernelGGL(unproject_kernel<double>, dim3(blocks), dim3(256), 0, s, depth, static_cast<double*>(out), p);
+  else hipLaunchKernelGGL(unproject_kernel<float>, dim3(blocks), dim3(256), 0, s, depth, static_cast<float*>(out), p);
+  return check_launch("unproject_kernel");
+}
+
+int la3d_mask_counts(const uint8_t* mask, int B, int H, int W, int32_t* counts, void* stream) {
+  if (!mask || !counts || B < 0 || H <= 0 || W <= 0) {
+    set_err("la3d_mask_counts: bad argument");
+    return LA3D_ERR_ARG;
+  }
+  if (B == 0) return LA3D_SUCCESS;
+  const int HW = H * W;
+  const int vec = (HW % 16 == 0) && ((reinterpret_cast<uintptr_t>(mask) & 15) == 0);
+  hipLaunchKernelGGL(mask_counts_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), mask, HW, vec, counts);
+  return check_launch("mask_counts_kernel");
+}
+
+int la3d_fit_instances(const float* depth, int64_t depth_plane_stride, const int32_t* image_index,
+                       const uint8_t* mask, const double* K, int32_t k_stride, const double* ground,
+                       const int32_t* sample_idx, int B, int H, int W, double* out, int32_t* status, double* aux,
+                       void* workspace, void* stream) {
+  if (!depth || !mask || !K || !out || !status || B < 0 || H <= 0 || W <= 0 || depth_plane_stride < 0 ||
+      (k_stride != 0 && k_stride < 9) || (long long)H * W > (1LL << 28)) {
+    set_err("la3d_fit_instances: bad argument");
+    return LA3D_ERR_ARG;
+  }
+  if (B == 0) return LA3D_SUCCESS;
+  if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 7)) {
+    set_err("la3d_fit_instances: workspace of la3d_workspace_bytes() bytes (8-aligned) required");
+    return LA3D_ERR_ARG;
+  }
+  FitParams p;
+  p.geo = static_cast<double*>(workspace);
+  p.depth = depth; p.depth_plane_stride = depth_plane_stride; p.image_index = image_index;
+  p.mask = mask; p.K = K; p.k_stride = k_stride; p.ground = ground; p.sample_idx = sample_idx;
+  p.B = B; p.H = H; p.W = W; p.HW = H * W;
+  p.nwords = (p.HW + 31) / 32;
+  p.rows_aligned = (W % 4 == 0);
+  p.rcpW = 1.0f / (float)W;
+  p.out = out; p.status = status; p.aux = aux;
+  const int bit_bytes = ((((p.HW + 15) / 16 + 1) / 2) * 4 + 15) & ~15;  // u16 per 16 px, padded to u32, 16-aligned
+  const bool ldsmask = bit_bytes <= MAX_MASK_LDS;
+  p.mask_lds_bytes = ldsmask ? bit_bytes : 0;
+  // 16-byte vector path: every plane base 16-aligned
+  const bool vec = (p.HW % 16 == 0) && ((reinterpret_cast<uintptr_t>(mask) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(depth) & 15) == 0) && (depth_plane_stride % 4 == 0);
+  const bool sample = sample_idx != nullptr;
+  size_t lds = (size_t)p.mask_lds_bytes + sizeof(Shared);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(prep_kernel, dim3((B + 63) / 64), dim3(64), 0, s, p);
+  if (int rc = check_launch("prep_kernel")) return rc;
+  if (sample) {
+    if (!ldsmask) {
+      set_err("la3d_fit_instances: reference-subsample mode needs the bit image in LDS (H*W <= 1048576)");
+      return LA3D_ERR_UNSUPPORTED;
+    }
+    lds += (size_t)p.nwords * 4 + 16;
+    if (lds > 160 * 1024 - 256) {
+      set_err("la3d_fit_instances: reference-subsample mode: frame too large for LDS");
+      return LA3D_ERR_UNSUPPORTED;
+    }
+    return vec ? launch_fit<true, true, true>(p, lds, s) : launch_fit<false, true, true>(p, lds, s);
+  }
+  if (ldsmask) return vec ? launch_fit<true, true, false>(p, lds, s) : launch_fit<false, true, false>(p, lds, s);
+  return vec ? launch_fit<true, false, false>(p, lds, s) : launch_fit<false, false, false>(p, lds, s);
+}
+
+int la3d_fit_points(const double* points, const int64_t* offsets, const double* ground, const int32_t* sample_idx,
+                    int method, int B, double* out, int32_t* status, double* aux, void* stream) {
+  if (!offsets || !out || !status || B < 0 || (B > 0 && !points && false)) {
+    set_err("la3d_fit_points: bad argument");
+    return LA3D_ERR_ARG;
+  }
+  if (method != LA3D_METHOD_PCA) {
+    set_err("la3d_fit_points: method not supported by this build");
+    return LA3D_ERR_UNSUPPORTED;
+  }
+  if (B == 0) return LA3D_SUCCESS;
+  PtsParams p;
+  p.points = points; p.offsets = reinterpret_cast<const long long*>(offsets); p.ground = ground;
+  p.sample_idx = sample_idx; p.B = B; p.out = out; p.status = status; p.aux = aux;
+  hipLaunchKernelGGL(fit_points_kernel, dim3(B), dim3(NTP), 0, static_cast<hipStream_t>(stream), p);
+  return check_launch("fit_points_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,390 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Every call goes through the C-ABI
+(libla3d.so via labelany3d_amd); the CPU oracle (oracle/la3d_oracle.py) and the committed fixtures
+generated from the reference (tests/golden) are the checkers.
+
+Stated tolerances.  BASELINE.json asks for center / dims / yaw within 1e-4 relative of the reference.
+The kernels accumulate in float64 like the reference, so the tests hold them to far tighter bounds:
+    center, dims, R_cam : |err| <= 1e-9 * scale   (scale = max(1, |coords|, dims))
+    yaw                 : 1e-9 rad where the footprint's eigen-gap (l1-l2)/l1 > 1e-6
+    bbox3D_cam          : one float16 ulp of the largest coordinate (the reference casts the 8
+                          corners to float16, src/util_3dbox.py:165; a 1e-16 input difference can
+                          flip that rounding)
+"""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+from oracle import la3d_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+K640 = np.array([[500.0, 0, 320], [0, 500.0, 240], [0, 0, 1]])
+
+
+@pytest.fixture(scope="module")
+def la():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import labelany3d_amd
+
+    return labelany3d_amd
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def assert_records(got, ref, tag="", rtol=1e-9, gap=None):
+    got, ref = np.asarray(got), np.asarray(ref)
+    assert got.shape == ref.shape
+    for i in range(len(ref)):
+        if np.isnan(ref[i]).all():
+            assert np.isnan(got[i]).all(), f"{tag}[{i}] expected NaN record"
+            continue
+        scale = max(1.0, np.abs(ref[i, :6]).max())
+        np.testing.assert_allclose(got[i, :6], ref[i, :6], rtol=0, atol=rtol * scale, err_msg=f"{tag}[{i}] center/dims")
+        if gap is None or gap[i] > 1e-6:
+            np.testing.assert_allclose(got[i, 6:15], ref[i, 6:15], rtol=0, atol=max(rtol, 1e-9), err_msg=f"{tag}[{i}] R_cam")
+        ulp = max(np.abs(ref[i, 15:]).max(), 1.0) * 2.0 ** -10
+        np.testing.assert_allclose(got[i, 15:], ref[i, 15:], rtol=0, atol=ulp, err_msg=f"{tag}[{i}] vertices")
+
+
+def rect_masks(rs, B, H, W, hmax=300, wmax=330):
+    masks = np.zeros((B, H, W), bool)
+    for i in range(B):
+        h, w = rs.randint(8, min(hmax, H) + 1), rs.randint(8, min(wmax, W) + 1)
+        r0, c0 = rs.randint(0, H - h + 1), rs.randint(0, W - w + 1)
+        masks[i, r0:r0 + h, c0:c0 + w] = True
+    return masks
+
+
+# ------------------------------------------------------------------------------------------
+# fixtures generated from the reference
+# ------------------------------------------------------------------------------------------
+def test_g1_depth_to_points(la, golden):
+    from labelany3d_amd.util import depth_to_points
+
+    g = golden("g1_depth_to_points.npz")
+    tol = dict(rtol=1e-13, atol=1e-13)
+    for depth, K, R, t, want in (
+        (g["a_depth"], g["a_K"], None, None, g["a_out"]),
+        (g["b_depth"], g["b_K"], None, None, g["b_out"]),
+        (g["b_depth"], g["b_K"], g["c_R"], g["c_t"], g["c_out"]),
+        (g["d_depth"], g["b_K"], None, None, g["d_out"]),
+        (g["b_depth"], g["e_K"], None, None, g["e_out"]),
+    ):
+        out = depth_to_points(depth, K, R, t)
+        assert isinstance(out, np.ndarray) and out.dtype == np.float64 and out.shape == want.shape
+        np.testing.assert_allclose(out, want, **tol)
+    out = depth_to_points(g["g_depth"], g["b_K"])  # NaN / +-inf depth
+    assert np.array_equal(np.isnan(out), np.isnan(g["g_out"]))
+    np.testing.assert_allclose(out, g["g_out"], **tol)
+    d640 = np.random.RandomState(0).uniform(0.5, 10, (1, 480, 640)).astype(np.float32)
+    full = depth_to_points(d640, K640)
+    np.testing.assert_allclose(full.reshape(-1, 3)[g["f_pick"]], g["f_out_pick"], **tol)
+    np.testing.assert_allclose(full.sum(axis=(0, 1)), g["f_sum"], rtol=1e-10)
+    with pytest.raises(TypeError):
+        depth_to_points(d640)
+
+
+def test_g1_torch_in_torch_out(la):
+    import torch
+
+    from labelany3d_amd.util import depth_to_points
+
+    d = torch.rand(1, 33, 47, device="cuda") * 5 + 0.5
+    out = depth_to_points(d, K640)
+    assert out.is_cuda and out.shape == (33, 47, 3)
+    np.testing.assert_allclose(np_(out), O.depth_to_points(np_(d), K640), rtol=1e-13, atol=1e-13)
+    out32 = la.unproject(d[0], K640, out_dtype=torch.float32)
+    np.testing.assert_allclose(np_(out32), np_(out), rtol=1e-6)
+
+
+def _run_estimate(U, pc, ground, method):
+    with contextlib.redirect_stdout(io.StringIO()) as buf:
+        v, c, d, R = U.estimate_bbox(pc, None, ground, method)
+    return v, c, d, R, buf.getvalue()
+
+
+def test_g2_estimate_bbox_dropin(la, golden):
+    from labelany3d_amd import util_3dbox as U
+
+    g = golden("g2_estimate_bbox.npz")
+    f32_case = int(g["f32_case"][0])
+    for i, tag in enumerate(g["tags"]):
+        tag, method = str(tag), str(g["methods"][i])
+        if method == "convex_hull":
+            continue  # covered by test_convex_hull_method
+        pc = g["pcs"][i, : g["lens"][i]]
+        if i == f32_case:
+            pc = pc.astype(np.float32)
+        ground = None if np.isnan(g["grounds"][i]).all() else g["grounds"][i]
+        v, c, d, R, printed = _run_estimate(U, pc, ground, method)
+        assert v.shape == (8, 3) and v.dtype == np.float64 and c.shape == (3,) and R.shape == (3, 3)
+        assert isinstance(d, list) and len(d) == 3 and all(isinstance(x, np.float64) for x in d)
+        assert printed == f"[{method}] dx={d[2]:.3f}, dy={d[1]:.3f}, dz={d[0]:.3f}\n"  # reference :162
+        rec = O.pack39(v, c, d, R)
+        rtol = 1e-7 if tag == "far" else 1e-9  # 'far': ill-conditioned raw moments in the reference itself
+        assert_records(rec[None], g["outs"][i][None], tag, rtol=rtol)
+
+
+def test_g3_error_behaviour(la, golden):
+    from labelany3d_amd import util_3dbox as U
+
+    g = golden("g3_errors.npz")
+    for name in g["names"]:
+        name = str(name)
+        ground = None if np.isnan(g[name + "_ground"]).all() else g[name + "_ground"]
+        with pytest.raises(ValueError) as ei:
+            _run_estimate(U, g[name + "_pc"], ground, str(g[name + "_method"]))
+        if name in ("empty", "allnan", "ground_down", "ground_up", "ground_zero", "badmethod"):
+            assert str(ei.value) == str(g[name + "_msg"]), name
+
+
+def _g4_cloud(seed, n, yaw):
+    rs = np.random.RandomState(seed)
+    p = rs.randn(n, 3) * np.array((1.0, 0.3, 0.5))
+    c, s = np.cos(yaw), np.sin(yaw)
+    return p @ np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]]).T + np.array((0.5, -0.2, 5.0))
+
+
+def test_g4_subsample_global_rng(la, golden):
+    from labelany3d_amd import util_3dbox as U
+
+    g = golden("g4_subsample.npz")
+    for j in range(3):
+        pc = _g4_cloud(int(g[f"s{j}_cloud_seed"]), int(g[f"s{j}_n"]), float(g[f"s{j}_yaw"]))
+        np.random.seed(int(g[f"s{j}_rng_seed"]))
+        v, c, d, R, _ = _run_estimate(U, pc, None, "pca")
+        assert_records(O.pack39(v, c, d, R)[None], g[f"s{j}_out"][None], f"s{j}")
+    np.random.seed(77)  # three consecutive calls: the 300-point one must not consume the stream
+    for j, n in enumerate(g["seq_n"]):
+        v, c, d, R, _ = _run_estimate(U, _g4_cloud(200 + j, int(n), 0.1 + j), None, "pca")
+        assert_records(O.pack39(v, c, d, R)[None], g["seq_out"][j][None], f"seq{j}")
+
+
+def test_g5_composed_path(la, golden):
+    g = golden("g5_composed.npz")
+    for ground, key in ((None, "out_noground"), (g["ground"], "out_ground")):
+        boxes, status, aux = la.fit_instances(g["depth"], g["masks"], g["K"], ground=ground, sample_idx=g["idx_fixed"])
+        assert (np_(status) == 0).all()
+        assert_records(np_(boxes), g[key], key)
+    boxes, status, aux = la.fit_instances(g["depth"], g["masks"], g["K"], ground=g["ground"], sample_idx=g["sample_idx"])
+    assert_records(np_(boxes), g["out_sampled"], "sampled")
+    # n_masked reported by the kernel / la3d_mask_counts == what the reference sees as in_pc.shape[0]
+    want = g["masks"].reshape(8, -1).sum(1)
+    np.testing.assert_array_equal(np_(aux)[:, 2].astype(int), want)
+    np.testing.assert_array_equal(np_(la.mask_counts(g["masks"])), want)
+    # host helper reproduces the stream the reference consumed for 'out_sampled'
+    np.random.seed(9)
+    np.testing.assert_array_equal(la.draw_sample_idx(want)[want > 500], g["sample_idx"][want > 500])
+
+
+# ------------------------------------------------------------------------------------------
+# oracle comparisons on seeded inputs
+# ------------------------------------------------------------------------------------------
+def test_full_mask_mode_vs_oracle_640x480(la):
+    """BASELINE config-2 shaped inputs (private 480x640 depth planes, rectangular masks), 48 instances."""
+    rs = np.random.RandomState(1234)
+    B, H, W = 48, 480, 640
+    depth = rs.uniform(0.5, 10, (B, H, W)).astype(np.float32)
+    masks = rect_masks(rs, B, H, W)
+    ground = np.array([[0.02, -0.98, 0.1, 1.5]] * B) + 0.03 * rs.randn(B, 4)
+    ground[::3, 0] = np.nan  # every third instance: no ground
+    boxes, status, aux = la.fit_instances(depth, masks, K640, ground=ground)
+    gl = [None if np.isnan(g[0]) else g for g in ground]
+    ref = [O.fit_instance(depth[i], masks[i], K640, gl[i]) for i in range(B)]
+    assert (np_(status) == [r[1] for r in ref]).all()
+    a = np_(aux)
+    assert_records(np_(boxes), np.array([r[0] for r in ref]), "cfg2", gap=a[:, 3])
+    np.testing.assert_allclose(a[:, 0], [r[2]["yaw"] for r in ref], atol=1e-9)
+    np.testing.assert_array_equal(a[:, 1], [r[2]["n_valid"] for r in ref])
+    np.testing.assert_array_equal(a[:, 2], masks.reshape(B, -1).sum(1))
+
+
+def test_smooth_depth_compact_objects(la):
+    """Compact objects (smooth depth): small eigen-gaps and strong moment cancellation."""
+    rs = np.random.RandomState(7)
+    B, H, W = 32, 480, 640
+    vv, uu = np.mgrid[0:H, 0:W]
+    base = 4.0 + 0.004 * uu + 0.006 * vv
+    depth = (base[None] + 0.02 * rs.randn(B, H, W)).astype(np.float32)
+    masks = rect_masks(rs, B, H, W, 120, 120)
+    boxes, status, aux = la.fit_instances(depth, masks, K640)
+    ref = [O.fit_instance(depth[i], masks[i], K640) for i in range(B)]
+    assert (np_(status) == 0).all()
+    assert_records(np_(boxes), np.array([r[0] for r in ref]), "smooth", gap=np_(aux)[:, 3])
+
+
+def test_shared_depth_with_image_index_and_per_image_K(la):
+    rs = np.random.RandomState(3)
+    P, B, H, W = 3, 10, 96, 128
+    depth = rs.uniform(1, 6, (P, H, W)).astype(np.float32)
+    Ks = np.array([[[100.0 + 7 * p, 0.5 * p, 64 + p], [0, 110.0 - 3 * p, 48 - p], [0, 0, 1]] for p in range(P)])
+    img = rs.randint(0, P, B).astype(np.int32)
+    masks = rect_masks(rs, B, H, W, 60, 80)
+    boxes, status, _ = la.fit_instances(depth, masks, Ks, image_index=img)
+    ref, rst, _, _ = O.fit_instances(depth, masks, Ks, depth_index=img)
+    assert (np_(status) == rst).all()
+    assert_records(np_(boxes), ref, "shared")
+    # one shared plane, one K
+    boxes1, _, _ = la.fit_instances(depth[1], masks, Ks[1])
+    ref1, _, _, _ = O.fit_instances(depth[1], masks, Ks[1])
+    assert_records(np_(boxes1), ref1, "single-plane")
+
+
+def test_irregular_masks_u8_values_and_nonfinite_depth(la):
+    rs = np.random.RandomState(5)
+    B, H, W = 6, 64, 80
+    depth = rs.uniform(1, 5, (B, H, W)).astype(np.float32)
+    depth[:, 10, 10] = np.nan
+    depth[:, 20, 30] = np.inf
+    depth[:, 21, 31] = -np.inf
+    masks = (rs.rand(B, H, W) < np.linspace(0.02, 0.9, B)[:, None, None])
+    m8 = masks.astype(np.uint8) * np.array([1, 255, 7, 128, 2, 1], np.uint8)[:, None, None]  # any non-zero byte = True
+    boxes, status, aux = la.fit_instances(depth, m8, K640)
+    ref, rst, _, rn = O.fit_instances(depth, masks, K640)
+    assert (np_(status) == rst).all()
+    assert_records(np_(boxes), ref, "irregular")
+    np.testing.assert_array_equal(np_(aux)[:, 1], rn)  # NaN / inf pixels dropped exactly as the reference drops them
+
+
+def test_status_codes_batched(la):
+    H, W = 32, 48
+    depth = np.full((H, W), 2.0, np.float32)
+    masks = np.zeros((6, H, W), bool)
+    masks[1, 5, 5] = True                      # one pixel -> PCA needs 2 samples
+    masks[2, 4:10, 4:10] = True                # fine
+    masks[3, 4:10, 4:10] = True                # ground parallel to [0,-1,0]
+    masks[4, 4:10, 4:10] = True                # all-NaN depth under the mask -> empty
+    masks[5, 3, 3:5] = True                    # two pixels -> fine
+    ground = np.full((6, 4), np.nan)
+    ground[3] = [0, -2.0, 0, 1]
+    d = np.repeat(depth[None], 6, 0)
+    d[4, 4:10, 4:10] = np.nan
+    boxes, status, aux = la.fit_instances(d, masks, K640[None].repeat(6, 0), ground=ground)
+    st = np_(status)
+    assert st.tolist() == [O.ST_EMPTY, O.ST_TOO_FEW, O.ST_OK, O.ST_BAD_GROUND, O.ST_EMPTY, O.ST_OK]
+    b = np_(boxes)
+    assert np.isnan(b[[0, 1, 3, 4]]).all() and np.isfinite(b[[2, 5]]).all()
+    ref, rst, _, _ = O.fit_instances(d, masks, K640[None].repeat(6, 0), ground=[None, None, None, ground[3], None, None])
+    assert (rst == st).all()
+    assert_records(b, ref, "status")
+
+
+@pytest.mark.parametrize("H,W", [(37, 53), (30, 50), (64, 66), (1000, 1100)])
+def test_odd_frame_sizes(la, H, W):
+    """Unaligned planes (scalar path), rows not a multiple of 4, and a frame whose bit image does
+    not fit LDS (H*W > 1M -> the kernel re-reads the u8 mask instead)."""
+    rs = np.random.RandomState(H * W)
+    B = 3
+    depth = rs.uniform(1, 5, (B, H, W)).astype(np.float32)
+    masks = rect_masks(rs, B, H, W, H // 2, W // 2)
+    masks[2] = rs.rand(H, W) < 0.01
+    K = np.array([[0.8 * W, 0, W / 2], [0, 0.8 * W, H / 2], [0, 0, 1]])
+    g = np.array([[0.1, -0.9, 0.2, 1.0]] * B)
+    boxes, status, aux = la.fit_instances(depth, masks, K, ground=g)
+    ref, rst, _, _ = O.fit_instances(depth, masks, K, ground=g)
+    assert (np_(status) == rst).all()
+    assert_records(np_(boxes), ref, f"{H}x{W}")
+    np.testing.assert_array_equal(np_(la.mask_counts(masks)), masks.reshape(B, -1).sum(1))
+    np.testing.assert_array_equal(np_(aux)[:, 2], masks.reshape(B, -1).sum(1))
+
+
+def test_reference_subsample_mode_640x480(la):
+    rs = np.random.RandomState(11)
+    B, H, W = 12, 480, 640
+    depth = rs.uniform(0.5, 10, (B, H, W)).astype(np.float32)
+    masks = rect_masks(rs, B, H, W)
+    masks[0] = False
+    masks[0, 100:110, 100:120] = True  # 200 px: below the threshold, not sampled
+    counts = np_(la.mask_counts(masks))
+    np.random.seed(2024)
+    idx = la.draw_sample_idx(counts)
+    boxes, status, aux = la.fit_instances(depth, masks, K640, sample_idx=idx)
+    ref, rst, _, rn = O.fit_instances(depth, masks, K640, sample_idx=idx)
+    assert (np_(status) == rst).all()
+    assert_records(np_(boxes), ref, "sampled640", gap=np_(aux)[:, 3])
+    np.testing.assert_array_equal(np_(aux)[:, 1], rn)
+
+
+def test_fit_points_batched_vs_oracle(la):
+    rs = np.random.RandomState(21)
+    clouds, grounds = [], []
+    for i in range(40):
+        n = int(rs.choice([2, 3, 19, 20, 21, 100, 500, 501, 3000]))
+        pc = rs.randn(n, 3) * rs.uniform(0.1, 2, 3) + rs.uniform(-3, 3, 3) + [0, 0, 6]
+        pc = pc @ O.rotate_y(rs.uniform(-3, 3)).T
+        if i % 5 == 0:
+            pc[rs.randint(0, n)] = np.nan
+        clouds.append(pc)
+        grounds.append([np.nan] * 4 if i % 2 else list(rs.randn(3) * 0.2 + [0, -1, 0]) + [1.0])
+    grounds = np.array(grounds)
+    idx = np.zeros((40, 500), np.int32)
+    for i, c in enumerate(clouds):
+        if len(c) > 500:
+            idx[i] = rs.randint(0, len(c), 500)
+    boxes, status, aux = la.fit_points(clouds, grounds, idx)
+    for i, c in enumerate(clouds):
+        g = None if np.isnan(grounds[i, 0]) else grounds[i]
+        rec, st, a = O.fit_points(c, g, idx[i] if len(c) > 500 else False)
+        assert int(status[i]) == st
+        assert_records(np_(boxes[i])[None], rec[None], f"cloud{i}")
+        assert float(aux[i, 0]) == pytest.approx(a["yaw"], abs=1e-9)
+
+
+# ------------------------------------------------------------------------------------------
+# full-size, size-independent properties (B = 1024 at 640x480: BASELINE config 2)
+# ------------------------------------------------------------------------------------------
+def test_full_size_properties(la):
+    import torch
+
+    torch.manual_seed(0)
+    rs = np.random.RandomState(1234)
+    B, H, W = 1024, 480, 640
+    depth = torch.rand((B, H, W), device="cuda") * 9.5 + 0.5
+    masks = torch.zeros((B, H, W), dtype=torch.uint8, device="cuda")
+    rects = []
+    for i in range(B):
+        h, w = rs.randint(8, 301), rs.randint(8, 331)
+        r0, c0 = rs.randint(0, H - h + 1), rs.randint(0, W - w + 1)
+        masks[i, r0:r0 + h, c0:c0 + w] = 1
+        rects.append((r0, c0, h, w))
+    boxes, status, aux = la.fit_instances(depth, masks, K640)
+    b1, a1 = boxes.clone(), aux.clone()
+    assert int(status.abs().sum()) == 0
+    # (1) deterministic: a second run is bit-identical
+    boxes2, _, aux2 = la.fit_instances(depth, masks, K640)
+    assert torch.equal(b1, boxes2) and torch.equal(a1, aux2)
+    # (2) permuting the instances permutes the records bit-exactly (no cross-instance state)
+    perm = torch.randperm(B, device="cuda")
+    boxes3, _, _ = la.fit_instances(depth[perm].contiguous(), masks[perm].contiguous(), K640)
+    assert torch.equal(boxes3, b1[perm])
+    # (3) doubling every depth doubles centers and dims exactly (power-of-two scaling commutes with
+    #     every rounding on the path before the fp16 cast) and leaves R_cam untouched
+    boxes4, _, _ = la.fit_instances(depth * 2, masks, K640)
+    assert torch.equal(boxes4[:, :6], b1[:, :6] * 2) and torch.equal(boxes4[:, 6:15], b1[:, 6:15])
+    # (4) n_masked is the rectangle area; every pixel valid
+    area = torch.tensor([h * w for (_, _, h, w) in rects], dtype=torch.float64, device="cuda")
+    assert torch.equal(a1[:, 2], area) and torch.equal(a1[:, 1], area)
+    # (5) R_cam is a rotation about y; the box contains the object's points: check 16 instances
+    #     against points recomputed by the unprojection kernel
+    R = b1[:, 6:15].reshape(B, 3, 3)
+    eye = torch.eye(3, dtype=torch.float64, device="cuda")
+    assert torch.allclose(R @ R.transpose(1, 2), eye.expand(B, 3, 3), atol=1e-12)
+    for i in range(0, B, 64):
+        r0, c0, h, w = rects[i]
+        pts = la.unproject(depth[i], K640)[r0:r0 + h, c0:c0 + w].reshape(-1, 3)
+        local = (pts - b1[i, 0:3]) @ R[i]  # box frame (R_cam maps box axes to camera axes)
+        half = torch.stack([b1[i, 5], b1[i, 4], b1[i, 3]]) / 2  # dims are [dz,dy,dx]
+        assert (local.abs() <= half * (1 + 1e-9) + 1e-9).all()
+        # ... and is tight: some point touches each face
+        assert torch.allclose(local.abs().max(0).values, half, rtol=1e-9, atol=1e-9)
+    # (6) spot-check 8 instances of the big batch against the oracle
+    for i in range(0, B, 128):
+        rec, st, a = O.fit_instance(np_(depth[i]), np_(masks[i]), K640)
+        assert_records(np_(b1[i])[None], rec[None], f"big{i}")
