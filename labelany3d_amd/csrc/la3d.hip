@@ -245,6 +245,9 @@ struct FitParams {
   int rows_aligned;    // W % 4 == 0: a 4-pixel quad never straddles a row
   float rcpW;
   double* geo;         // workspace: [B][GEO_D]
+  int ntx, nty;        // TILED: tiles of 32 px x 8 rows (ntx = W/32, nty = ceil(H/8))
+  int tiles_per_wave;  // TILED: ceil(ntx*nty / NWAVE)
+  int list_cap;        // TILED: entries of the active-tile list that fit the LDS budget
   double* out;
   int* status;
   double* aux;
@@ -254,7 +257,7 @@ struct FitParams {
 constexpr int GEO_D = 20;  // M[9] (= Rg^T Kinv : p' = d * (M @ [u,v,1])), Rg[9], bad_ground, pad
 
 struct alignas(16) Shared {
-  double part[NWAVE][8];
+  double part[NWAVE][7];
   double N0[3];   // row 0 of rotate_y(yaw) @ M
   double N2[3];   // row 2 of rotate_y(yaw) @ M
   double cyaw, syaw;
@@ -363,6 +366,69 @@ __device__ inline void sweep(const FitParams& p, const float* __restrict__ dpl, 
   }
 }
 
+// TILED walk (W % 32 == 0): a wave owns one tile of 32 px x 8 rows per step — lane = (row r = lane>>3,
+// quad cq = lane&7).  One bit-image word per tile row (broadcast to its 8 lanes), one full 128-B depth
+// line per tile row, (u,v) from the tile coordinates without any division.  Only tiles on the
+// compacted active list are visited, interleaved over the 8 waves.
+template <int PASS>
+__device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__ dpl, const unsigned* bits,
+                                   const unsigned short* list, int nactive, const double* A0, const double* A1,
+                                   const double* A2, int wave, int lane, double* acc, int* cnt) {
+  const int W = p.W, H = p.H, ntx = p.ntx;
+  const int r = lane >> 3, cq = lane & 7;
+  const double a00 = A0[0], a01 = A0[1], a02 = A0[2];
+  const double a20 = A2[0], a21 = A2[1], a22 = A2[2];
+  double a10 = 0, a11 = 0, a12 = 0;
+  if (PASS == 0) { a10 = A1[0]; a11 = A1[1]; a12 = A1[2]; }
+  double s0 = acc[0], s1 = acc[1], s2 = acc[2], s3 = acc[3], s4 = acc[4], lo = acc[5], hi = acc[6];
+  double lo2 = acc[5], hi2 = acc[6];
+  if (PASS == 1) { lo = acc[0]; hi = acc[1]; lo2 = acc[2]; hi2 = acc[3]; }
+  int n = *cnt;
+  const bool dense = nactive < 0;                  // list overflow: walk every tile, skip empty ones
+  const int nsteps = dense ? ntx * p.nty : nactive;
+  for (int j = wave; j < nsteps; j += NWAVE) {
+    int tx, ty;
+    if (dense) { ty = j / ntx; tx = j - ty * ntx; }
+    else { const unsigned t = list[j]; tx = (int)(t & 0xffu); ty = (int)(t >> 8); }  // wave-uniform
+    const int row = ty * 8 + r;
+    unsigned nib = 0;
+    if (row < H) nib = (bits[row * ntx + tx] >> (cq * 4)) & 0xFu;
+    if (dense && __ballot(nib != 0) == 0) continue;
+    if (nib) {
+      const int u0 = tx * 32 + cq * 4;
+      const float4 dq = *reinterpret_cast<const float4*>(dpl + (long long)row * W + u0);
+      const float dk[4] = {dq.x, dq.y, dq.z, dq.w};
+      const double vd = (double)row;
+      const double b0 = fma(a01, vd, a02), b2 = fma(a21, vd, a22);
+      double b1 = 0;
+      if (PASS == 0) b1 = fma(a11, vd, a12);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool ok = ((nib >> k) & 1u) && finite_f32(dk[k]);
+        const double ud = (double)(u0 + k);
+        const double r0 = fma(a00, ud, b0), r2 = fma(a20, ud, b2);
+        const double d = ok ? (double)dk[k] : 0.0;
+        const double x = d * r0, z = d * r2;
+        if (PASS == 0) {
+          const double y = d * fma(a10, ud, b1);
+          s0 += x; s1 += z;
+          s2 = fma(x, x, s2); s3 = fma(x, z, s3); s4 = fma(z, z, s4);
+          n += ok ? 1 : 0;
+          if (ok) { lo = fmin(lo, y); hi = fmax(hi, y); }
+        } else {
+          if (ok) { lo = fmin(lo, x); hi = fmax(hi, x); lo2 = fmin(lo2, z); hi2 = fmax(hi2, z); }
+        }
+      }
+    }
+  }
+  if (PASS == 0) {
+    acc[0] = s0; acc[1] = s1; acc[2] = s2; acc[3] = s3; acc[4] = s4; acc[5] = lo; acc[6] = hi;
+    *cnt = n;
+  } else {
+    acc[0] = lo; acc[1] = hi; acc[2] = lo2; acc[3] = hi2;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // per-instance geometry: Kinv, Rg, M = Rg^T Kinv  (one thread per instance; keeps the 3x3
 // elimination and Rodrigues algebra out of the streaming kernel's register budget)
@@ -385,12 +451,14 @@ __global__ __launch_bounds__(64) void prep_kernel(const FitParams p) {
 // ------------------------------------------------------------------------------------------
 // fused kernel: one workgroup per instance
 // ------------------------------------------------------------------------------------------
-template <bool VEC, bool LDSMASK, bool SAMPLE>
+template <bool VEC, bool LDSMASK, bool SAMPLE, bool TILED>
 __global__ __launch_bounds__(NT, 8) void fit_instances_kernel(const FitParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned* bits = reinterpret_cast<unsigned*>(smem);
   Shared* sh = reinterpret_cast<Shared*>(smem + p.mask_lds_bytes);
   unsigned* prefix = reinterpret_cast<unsigned*>(smem + p.mask_lds_bytes + sizeof(Shared));  // SAMPLE only
+  // TILED only: compacted list of active tile ids
+  unsigned short* list = reinterpret_cast<unsigned short*>(smem + p.mask_lds_bytes + sizeof(Shared));
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int inst = xcd_remap(blockIdx.x, p.B);
@@ -431,6 +499,43 @@ __global__ __launch_bounds__(NT, 8) void fit_instances_kernel(const FitParams p)
     if ((ngroups & 1) && tid == 0) b16[ngroups] = 0;  // upper half of the last 32-bit word
   }
   __syncthreads();
+
+  // ---- active-tile list (deterministic two-pass compaction: count, prefix, write) ----------------
+  int nactive = 0;
+  if (TILED) {
+    const int ntiles = p.ntx * p.nty, per = p.tiles_per_wave;
+    const int tbeg = wave * per, tend = min(tbeg + per, ntiles);
+    int base = 0;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      int wcount = 0;
+      for (int t0 = tbeg; t0 < tend; t0 += 64) {   // wave-uniform trip count
+        const int t = t0 + lane;
+        unsigned any = 0, packed = 0;
+        if (t < tend) {
+          const int ty = t / p.ntx, tx = t - ty * p.ntx;
+          const int rows = min(8, p.H - ty * 8);
+          const unsigned* bw = bits + (ty * 8) * p.ntx + tx;
+          for (int rr = 0; rr < rows; ++rr) any |= bw[rr * p.ntx];
+          packed = ((unsigned)ty << 8) | (unsigned)tx;
+        }
+        const unsigned long long bal = __ballot(any != 0);
+        if (pass == 1 && any) list[base + wcount + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)packed;
+        wcount += __popcll(bal);
+      }
+      if (pass == 0) {
+        if (lane == 0) sh->scan[wave] = (unsigned)wcount;
+        __syncthreads();
+        for (int w = 0; w < NWAVE; ++w) {
+          const int c = (int)sh->scan[w];
+          if (w < wave) base += c;
+          nactive += c;
+        }
+        if (nactive > p.list_cap) { nactive = -1; break; }  // uniform: every thread sees the same total
+      }
+    }
+    __syncthreads();
+  }
 
   // ---- pass A: moments ------------------------------------------------------------------
   double acc[7] = {0, 0, 0, 0, 0, INFINITY, -INFINITY};
@@ -497,7 +602,10 @@ __global__ __launch_bounds__(NT, 8) void fit_instances_kernel(const FitParams p)
       }
     }
   }
-  if (!sampled) sweep<VEC, LDSMASK, 0>(p, dpl, mpl, bits, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, &nmask);
+  if (!sampled) {
+    if (TILED) sweep_tiled<0>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt);
+    else sweep<VEC, LDSMASK, 0>(p, dpl, mpl, bits, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, &nmask);
+  }
 
   {
     const double r0 = wave_sum(acc[0]), r1 = wave_sum(acc[1]), r2 = wave_sum(acc[2]), r3 = wave_sum(acc[3]),
@@ -559,7 +667,8 @@ __global__ __launch_bounds__(NT, 8) void fit_instances_kernel(const FitParams p)
     }
   } else {
     int d0 = 0, d1 = 0;
-    sweep<VEC, LDSMASK, 1>(p, dpl, mpl, bits, sh->N0, nullptr, sh->N2, wave, lane, ext, &d0, &d1);
+    if (TILED) sweep_tiled<1>(p, dpl, bits, list, nactive, sh->N0, nullptr, sh->N2, wave, lane, ext, &d0);
+    else sweep<VEC, LDSMASK, 1>(p, dpl, mpl, bits, sh->N0, nullptr, sh->N2, wave, lane, ext, &d0, &d1);
   }
   {
     const double r0 = wave_min(ext[0]), r1 = wave_max(ext[1]), r2 = wave_min(ext[2]), r3 = wave_max(ext[3]);
@@ -806,9 +915,9 @@ int check_launch(const char* what) {
 
 constexpr int MAX_MASK_LDS = 128 * 1024;  // bit image budget; larger frames re-read the u8 mask instead
 
-template <bool VEC, bool LDSMASK, bool SAMPLE>
+template <bool VEC, bool LDSMASK, bool SAMPLE, bool TILED = false>
 int launch_fit(const FitParams& p, size_t lds, hipStream_t s) {
-  auto kern = fit_instances_kernel<VEC, LDSMASK, SAMPLE>;
+  auto kern = fit_instances_kernel<VEC, LDSMASK, SAMPLE, TILED>;
   static bool attr_done = false;  // one flag per instantiation
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -893,6 +1002,7 @@ int la3d_fit_instances(const float* depth, int64_t depth_plane_stride, const int
   p.rows_aligned = (W % 4 == 0);
   p.rcpW = 1.0f / (float)W;
   p.out = out; p.status = status; p.aux = aux;
+  p.ntx = p.nty = p.tiles_per_wave = p.list_cap = 0;
   const int bit_bytes = ((((p.HW + 15) / 16 + 1) / 2) * 4 + 15) & ~15;  // u16 per 16 px, padded to u32, 16-aligned
   const bool ldsmask = bit_bytes <= MAX_MASK_LDS;
   p.mask_lds_bytes = ldsmask ? bit_bytes : 0;
@@ -915,6 +1025,26 @@ int la3d_fit_instances(const float* depth, int64_t depth_plane_stride, const int
       return LA3D_ERR_UNSUPPORTED;
     }
     return vec ? launch_fit<true, true, true>(p, lds, s) : launch_fit<false, true, true>(p, lds, s);
+  }
+  // tiled fast path: 32-px-wide tiles map to exactly one bit-image word / one 128-B depth line per row
+  p.ntx = W / 32; p.nty = (H + 7) / 8;
+  p.tiles_per_wave = (p.ntx * p.nty + NWAVE - 1) / NWAVE;
+  if (ldsmask && vec && W % 32 == 0 && p.ntx <= 255 && p.nty <= 255) {
+    // LDS per workgroup: the largest number of workgroups per CU (160 KiB LDS) that still leaves room
+    // for a useful list; masks with more active tiles than the cap take the dense walk
+    const size_t fixed = lds;
+    const long ntiles = (long)p.ntx * p.nty;
+    const long want = ntiles < 256 ? ntiles : 256;
+    long cap = 0;
+    for (int wg_per_cu = 4; wg_per_cu >= 1 && cap < want; --wg_per_cu) {
+      const long budget = (160 * 1024 / wg_per_cu) & ~15L;
+      cap = (budget - (long)fixed) / 2;
+    }
+    if (cap > ntiles) cap = ntiles;
+    if (cap >= 64) {
+      p.list_cap = (int)cap;
+      return launch_fit<true, true, false, true>(p, fixed + (size_t)cap * 2, s);
+    }
   }
   if (ldsmask) return vec ? launch_fit<true, true, false>(p, lds, s) : launch_fit<false, true, false>(p, lds, s);
   return vec ? launch_fit<true, false, false>(p, lds, s) : launch_fit<false, false, false>(p, lds, s);
