@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU per step (config 2: 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams the independent steps are issued on round-robin (1 = strictly serial steps)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -111,8 +113,9 @@ def main():
 
     B, steps, warmup = args.batch, args.steps, args.warmup
     depth, masks, K, n_masked = make_inputs(B, device, 1234 + rank)
-    fitter = InstanceFitter(B, H, W, device, slots=max(steps, 1))
+    fitter = InstanceFitter(B, H, W, device, slots=max(steps, 1), ws_slots=max(args.streams, 1))
     stream = torch.cuda.current_stream()
+    streams = [stream] + [torch.cuda.Stream(device=device) for _ in range(max(args.streams, 1) - 1)]
 
     def barrier():
         torch.cuda.synchronize()
@@ -128,8 +131,16 @@ def main():
     barrier()
     t0 = time.perf_counter()
     ev0.record(stream)
-    for k in range(steps):
-        fitter.run(depth, masks, K, slot=k, stream=stream)
+    if len(streams) == 1:
+        for k in range(steps):
+            fitter.run(depth, masks, K, slot=k, stream=stream)
+    else:
+        for st in streams[1:]:
+            st.wait_stream(stream)
+        for k in range(steps):
+            fitter.run(depth, masks, K, slot=k, stream=streams[k % len(streams)], ws_slot=k % len(streams))
+        for st in streams[1:]:
+            stream.wait_stream(st)
     ev1.record(stream)
     gathered = None
     if dist is not None:

@@ -90,7 +90,7 @@ class InstanceFitter:
     """Reusable launch state for fit_instances on fixed (B,H,W): owns the output / status / aux /
     workspace buffers so the steady-state call allocates nothing and is a pure enqueue."""
 
-    def __init__(self, B: int, H: int, W: int, device=None, slots: int = 1):
+    def __init__(self, B: int, H: int, W: int, device=None, slots: int = 1, ws_slots: int = 1):
         self.B, self.H, self.W = int(B), int(H), int(W)
         self.device = _dev(device)
         self.slots = slots
@@ -98,10 +98,11 @@ class InstanceFitter:
         self.status = torch.empty((slots, B), dtype=torch.int32, device=self.device)
         self.aux = torch.empty((slots, B, AUX), dtype=torch.float64, device=self.device)
         nbytes = int(lib.la3d_workspace_bytes(self.B, self.H, self.W))
-        self.workspace = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=self.device)
+        # one workspace per concurrently running call (calls on different streams must not share it)
+        self.workspace = torch.empty((ws_slots, max((nbytes + 255) // 256 * 256, 256)), dtype=torch.uint8, device=self.device)
 
     def run(self, depth: torch.Tensor, masks: torch.Tensor, K: torch.Tensor, ground=None, sample_idx=None,
-            image_index=None, slot: int = 0, stream=None):
+            image_index=None, slot: int = 0, stream=None, ws_slot: int = 0):
         """All arguments already on the device with the ABI's dtypes (f32 / u8 / f64 / f64 / i32 / i32)."""
         B, H, W = self.B, self.H, self.W
         planes = depth.shape[0] if depth.dim() == 3 else 1
@@ -109,7 +110,7 @@ class InstanceFitter:
         kstride = 9 if (K.dim() == 3 and K.shape[0] > 1) else 0
         rc = lib.la3d_fit_instances(_ptr(depth), dstride, _ptr(image_index), _ptr(masks), _ptr(K), kstride,
                                     _ptr(ground), _ptr(sample_idx), B, H, W, _ptr(self.boxes[slot]),
-                                    _ptr(self.status[slot]), _ptr(self.aux[slot]), _ptr(self.workspace),
+                                    _ptr(self.status[slot]), _ptr(self.aux[slot]), _ptr(self.workspace[ws_slot]),
                                     _stream(stream))
         check(rc, "la3d_fit_instances")
         return self.boxes[slot], self.status[slot], self.aux[slot]

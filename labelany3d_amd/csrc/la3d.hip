@@ -214,6 +214,13 @@ __device__ inline int wave_sum_i(int v) {
   return v;
 }
 
+// wave-uniform double -> SGPR pair (the value is identical in every lane by construction)
+__device__ inline double uniform_f64(double v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const unsigned hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double((int)hi, (int)lo);
+}
+
 // XCD-aware block -> work-item map: the dispatcher is observed to place block b on XCD b % 8
 // (speed only, never correctness), so consecutive instances — which share an image's depth
 // plane in the shared-depth layout — land on one XCD's L2.  Bijective for any nb.
@@ -229,6 +236,22 @@ __device__ inline unsigned nz4(unsigned w) {
   return ((t >> 7) * 0x01020408u) >> 24;                                       // gather bits 0,8,16,24 -> 0..3
 }
 __device__ inline bool finite_f32(float d) { return (__float_as_uint(d) & 0x7f800000u) != 0x7f800000u; }
+
+// Raw fp64 min/max.  fmin()/fmax() on a loop-carried accumulator make hipcc emit a canonicalising
+// v_max_f64 x,x before every use (it cannot prove the accumulator is not a signalling NaN): +1 DP
+// instruction per min/max.  The hardware instructions already implement IEEE minNum/maxNum — a quiet
+// NaN operand returns the OTHER operand — which is exactly what the masked walk relies on: pixels
+// that are unmasked or non-finite carry a NaN depth and are ignored by the extents.
+__device__ inline double dmin(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ inline double dmax(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 
 struct FitParams {
   const float* depth;
@@ -258,8 +281,6 @@ constexpr int GEO_D = 20;  // M[9] (= Rg^T Kinv : p' = d * (M @ [u,v,1])), Rg[9]
 
 struct alignas(16) Shared {
   double part[NWAVE][7];
-  double N0[3];   // row 0 of rotate_y(yaw) @ M
-  double N2[3];   // row 2 of rotate_y(yaw) @ M
   double cyaw, syaw;
   int cnt[NWAVE];
   int nmask[NWAVE];
@@ -277,9 +298,10 @@ __device__ inline void pix_uv(unsigned i, int W, float rcpW, unsigned* u, unsign
   *v = vv;
 }
 
-// One walk over the instance's pixels, 4 per lane.  PASS 0: moments + y extent.  PASS 1: x/z extent
-// in the yaw frame.  A (3x3 row-major) maps [u,v,1] to the ray whose components are accumulated:
-// PASS 0 uses rows 0,1,2 of M; PASS 1 uses N0 (as row 0) and N2 (as row 2).
+// Generic walk (any W, unaligned planes, frames whose bit image does not fit LDS): row-linear chunks of
+// 256 pixels per wave, 4 per lane.  PASS 0: count + moments of (x', z').  PASS 1: extents of all three
+// axes in the yaw frame.  A0/A1/A2 are the rows mapping [u,v,1] to the ray components: PASS 0 uses rows 0
+// and 2 of M; PASS 1 uses N0, M row 1, N2.
 template <bool VEC, bool LDSMASK, int PASS>
 __device__ inline void sweep(const FitParams& p, const float* __restrict__ dpl, const unsigned char* __restrict__ mpl,
                              const unsigned* bits, const double* A0, const double* A1, const double* A2,
@@ -290,10 +312,9 @@ __device__ inline void sweep(const FitParams& p, const float* __restrict__ dpl, 
   const double a00 = A0[0], a01 = A0[1], a02 = A0[2];
   const double a20 = A2[0], a21 = A2[1], a22 = A2[2];
   double a10 = 0, a11 = 0, a12 = 0;
-  if (PASS == 0) { a10 = A1[0]; a11 = A1[1]; a12 = A1[2]; }
-  double s0 = acc[0], s1 = acc[1], s2 = acc[2], s3 = acc[3], s4 = acc[4], lo = acc[5], hi = acc[6];
-  double lo2 = acc[5], hi2 = acc[6];
-  if (PASS == 1) { lo = acc[0]; hi = acc[1]; lo2 = acc[2]; hi2 = acc[3]; }
+  if (PASS == 1) { a10 = A1[0]; a11 = A1[1]; a12 = A1[2]; }
+  double s0 = acc[0], s1 = acc[1], s2 = acc[2], s3 = acc[3], s4 = acc[4];
+  double xlo = acc[0], xhi = acc[1], ylo = acc[2], yhi = acc[3], zlo = acc[4], zhi = acc[5];
   int n = *cnt, nm = *nmask;
   for (int ch = wave; ch < nchunks; ch += NWAVE) {
     const int q = ch * 64 + lane;
@@ -328,7 +349,7 @@ __device__ inline void sweep(const FitParams& p, const float* __restrict__ dpl, 
       const double vd = (double)v0;
       const double b0 = fma(a01, vd, a02), b2 = fma(a21, vd, a22);
       double b1 = 0;
-      if (PASS == 0) b1 = fma(a11, vd, a12);
+      if (PASS == 1) b1 = fma(a11, vd, a12);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const bool ok = ((nib >> k) & 1u) && finite_f32(dk[k]);
@@ -336,40 +357,49 @@ __device__ inline void sweep(const FitParams& p, const float* __restrict__ dpl, 
         if (p.rows_aligned) {
           const double ud = (double)(u0 + k);
           r0 = fma(a00, ud, b0); r2 = fma(a20, ud, b2);
-          if (PASS == 0) r1 = fma(a10, ud, b1);
+          if (PASS == 1) r1 = fma(a10, ud, b1);
         } else {
           unsigned uk, vk;
           pix_uv(i0 + k, W, p.rcpW, &uk, &vk);
           const double ud = (double)uk, vdk = (double)vk;
           r0 = fma(a00, ud, fma(a01, vdk, a02)); r2 = fma(a20, ud, fma(a21, vdk, a22));
-          if (PASS == 0) r1 = fma(a10, ud, fma(a11, vdk, a12));
+          if (PASS == 1) r1 = fma(a10, ud, fma(a11, vdk, a12));
         }
-        const double d = ok ? (double)dk[k] : 0.0;
-        const double x = d * r0, z = d * r2;
         if (PASS == 0) {
-          const double y = d * r1;
+          const double d = ok ? (double)dk[k] : 0.0;
+          const double x = d * r0, z = d * r2;
           s0 += x; s1 += z;
           s2 = fma(x, x, s2); s3 = fma(x, z, s3); s4 = fma(z, z, s4);
           n += ok ? 1 : 0;
-          if (ok) { lo = fmin(lo, y); hi = fmax(hi, y); }
         } else {
-          if (ok) { lo = fmin(lo, x); hi = fmax(hi, x); lo2 = fmin(lo2, z); hi2 = fmax(hi2, z); }
+          const double d = ok ? (double)dk[k] : (double)NAN;  // NaN is ignored by v_min/v_max_f64
+          const double x = d * r0, y = d * r1, z = d * r2;
+          xlo = dmin(xlo, x); xhi = dmax(xhi, x);
+          ylo = dmin(ylo, y); yhi = dmax(yhi, y);
+          zlo = dmin(zlo, z); zhi = dmax(zhi, z);
         }
       }
     }
   }
   if (PASS == 0) {
-    acc[0] = s0; acc[1] = s1; acc[2] = s2; acc[3] = s3; acc[4] = s4; acc[5] = lo; acc[6] = hi;
+    acc[0] = s0; acc[1] = s1; acc[2] = s2; acc[3] = s3; acc[4] = s4;
     *cnt = n; *nmask = nm;
   } else {
-    acc[0] = lo; acc[1] = hi; acc[2] = lo2; acc[3] = hi2;
+    acc[0] = xlo; acc[1] = xhi; acc[2] = ylo; acc[3] = yhi; acc[4] = zlo; acc[5] = zhi;
   }
 }
 
 // TILED walk (W % 32 == 0): a wave owns one tile of 32 px x 8 rows per step — lane = (row r = lane>>3,
 // quad cq = lane&7).  One bit-image word per tile row (broadcast to its 8 lanes), one full 128-B depth
 // line per tile row, (u,v) from the tile coordinates without any division.  Only tiles on the
-// compacted active list are visited, interleaved over the 8 waves.
+// compacted active list are visited.  Each wave takes TG consecutive list entries per step and issues
+// all TG depth loads before computing (a single load per wave in flight leaves the walk bound by
+// memory latency: ~2.5 us per tile under load).
+// Branch-free pixel math: validity (mask bit AND finite depth) is a 0/-1 word; PASS 0 (moments) ANDs it
+// into the depth bits (invalid -> +0.0 contributes nothing to the sums); PASS 1 (extents of all three
+// axes) ORs its complement (invalid -> NaN, ignored by v_min/v_max_f64).
+constexpr int TG = 4;
+
 template <int PASS>
 __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__ dpl, const unsigned* bits,
                                    const unsigned short* list, int nactive, const double* A0, const double* A1,
@@ -379,53 +409,73 @@ __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__
   const double a00 = A0[0], a01 = A0[1], a02 = A0[2];
   const double a20 = A2[0], a21 = A2[1], a22 = A2[2];
   double a10 = 0, a11 = 0, a12 = 0;
-  if (PASS == 0) { a10 = A1[0]; a11 = A1[1]; a12 = A1[2]; }
-  double s0 = acc[0], s1 = acc[1], s2 = acc[2], s3 = acc[3], s4 = acc[4], lo = acc[5], hi = acc[6];
-  double lo2 = acc[5], hi2 = acc[6];
-  if (PASS == 1) { lo = acc[0]; hi = acc[1]; lo2 = acc[2]; hi2 = acc[3]; }
+  if (PASS == 1) { a10 = A1[0]; a11 = A1[1]; a12 = A1[2]; }
+  double s0 = acc[0], s1 = acc[1], s2 = acc[2], s3 = acc[3], s4 = acc[4];
+  double xlo = acc[0], xhi = acc[1], ylo = acc[2], yhi = acc[3], zlo = acc[4], zhi = acc[5];
   int n = *cnt;
   const bool dense = nactive < 0;                  // list overflow: walk every tile, skip empty ones
   const int nsteps = dense ? ntx * p.nty : nactive;
-  for (int j = wave; j < nsteps; j += NWAVE) {
-    int tx, ty;
-    if (dense) { ty = j / ntx; tx = j - ty * ntx; }
-    else { const unsigned t = list[j]; tx = (int)(t & 0xffu); ty = (int)(t >> 8); }  // wave-uniform
-    const int row = ty * 8 + r;
-    unsigned nib = 0;
-    if (row < H) nib = (bits[row * ntx + tx] >> (cq * 4)) & 0xFu;
-    if (dense && __ballot(nib != 0) == 0) continue;
-    if (nib) {
-      const int u0 = tx * 32 + cq * 4;
-      const float4 dq = *reinterpret_cast<const float4*>(dpl + (long long)row * W + u0);
-      const float dk[4] = {dq.x, dq.y, dq.z, dq.w};
-      const double vd = (double)row;
-      const double b0 = fma(a01, vd, a02), b2 = fma(a21, vd, a22);
-      double b1 = 0;
-      if (PASS == 0) b1 = fma(a11, vd, a12);
+  for (int j0 = wave * TG; j0 < nsteps; j0 += NWAVE * TG) {
+    unsigned nib[TG];
+    int txs[TG], tys[TG];
+    uint4 dq[TG];
+#pragma unroll
+    for (int g = 0; g < TG; ++g) {   // stage 1: bit-image nibbles, then all depth loads back to back
+      const int j = j0 + g;
+      nib[g] = 0; txs[g] = 0; tys[g] = 0;
+      dq[g] = make_uint4(0u, 0u, 0u, 0u);
+      if (j < nsteps) {
+        int tx, ty;
+        if (dense) { ty = j / ntx; tx = j - ty * ntx; }
+        else {
+          const unsigned t = __builtin_amdgcn_readfirstlane((unsigned)list[j]);  // wave-uniform -> SGPR
+          tx = (int)(t & 0xffu); ty = (int)(t >> 8);
+        }
+        txs[g] = tx; tys[g] = ty;
+        const int row = ty * 8 + r;
+        if (row < H) nib[g] = (bits[row * ntx + tx] >> (cq * 4)) & 0xFu;
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < TG; ++g)
+      if (nib[g]) dq[g] = *reinterpret_cast<const uint4*>(dpl + (long long)(tys[g] * 8 + r) * W + txs[g] * 32 + cq * 4);
+#pragma unroll
+    for (int g = 0; g < TG; ++g) {   // stage 2: compute (all lanes; unmasked lanes carry zeros / NaNs)
+      if (dense && __ballot(nib[g] != 0) == 0) continue;
+      const unsigned db[4] = {dq[g].x, dq[g].y, dq[g].z, dq[g].w};
+      const double vd = (double)(tys[g] * 8 + r), ud = (double)(txs[g] * 32 + cq * 4);
+      double r0 = fma(a00, ud, fma(a01, vd, a02));
+      double r2 = fma(a20, ud, fma(a21, vd, a22));
+      double r1 = 0;
+      if (PASS == 1) r1 = fma(a10, ud, fma(a11, vd, a12));
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const bool ok = ((nib >> k) & 1u) && finite_f32(dk[k]);
-        const double ud = (double)(u0 + k);
-        const double r0 = fma(a00, ud, b0), r2 = fma(a20, ud, b2);
-        const double d = ok ? (double)dk[k] : 0.0;
-        const double x = d * r0, z = d * r2;
+        // 0 / -1 validity word: mask bit k set AND exponent field != 0xff
+        const int fin = ((int)(db[k] & 0x7fffffffu) - 0x7f800000) >> 31;
+        const int m = fin & -(int)((nib[g] >> k) & 1u);
         if (PASS == 0) {
-          const double y = d * fma(a10, ud, b1);
+          const double d = (double)__uint_as_float(db[k] & (unsigned)m);
+          const double x = d * r0, z = d * r2;
           s0 += x; s1 += z;
           s2 = fma(x, x, s2); s3 = fma(x, z, s3); s4 = fma(z, z, s4);
-          n += ok ? 1 : 0;
-          if (ok) { lo = fmin(lo, y); hi = fmax(hi, y); }
+          n -= m;
         } else {
-          if (ok) { lo = fmin(lo, x); hi = fmax(hi, x); lo2 = fmin(lo2, z); hi2 = fmax(hi2, z); }
+          const double d = (double)__uint_as_float(db[k] | ~(unsigned)m);
+          const double x = d * r0, y = d * r1, z = d * r2;
+          xlo = dmin(xlo, x); xhi = dmax(xhi, x);
+          ylo = dmin(ylo, y); yhi = dmax(yhi, y);
+          zlo = dmin(zlo, z); zhi = dmax(zhi, z);
         }
+        r0 += a00; r2 += a20;           // next pixel of the row: u + 1
+        if (PASS == 1) r1 += a10;
       }
     }
   }
   if (PASS == 0) {
-    acc[0] = s0; acc[1] = s1; acc[2] = s2; acc[3] = s3; acc[4] = s4; acc[5] = lo; acc[6] = hi;
+    acc[0] = s0; acc[1] = s1; acc[2] = s2; acc[3] = s3; acc[4] = s4;
     *cnt = n;
   } else {
-    acc[0] = lo; acc[1] = hi; acc[2] = lo2; acc[3] = hi2;
+    acc[0] = xlo; acc[1] = xhi; acc[2] = ylo; acc[3] = yhi; acc[4] = zlo; acc[5] = zhi;
   }
 }
 
@@ -468,8 +518,12 @@ __global__ __launch_bounds__(NT, 8) void fit_instances_kernel(const FitParams p)
   const unsigned char* mpl = p.mask + (long long)inst * HW;
 
   const double* geo = p.geo + (long long)inst * GEO_D;  // uniform address -> scalar loads
-  const double* Mg = geo;
   const double* Rgg = geo + 9;
+  // read before the first barrier: the compiler only keeps uniform loads on the scalar path (SGPRs)
+  // while nothing in the kernel can have clobbered them
+  double Mg[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Mg[i] = geo[i];
 
   // ---- phase 0: u8 mask plane -> bit image in LDS --------------------------------------
   int nmask = 0;
@@ -538,7 +592,7 @@ __global__ __launch_bounds__(NT, 8) void fit_instances_kernel(const FitParams p)
   }
 
   // ---- pass A: moments ------------------------------------------------------------------
-  double acc[7] = {0, 0, 0, 0, 0, INFINITY, -INFINITY};
+  double acc[5] = {0, 0, 0, 0, 0};
   int cnt = 0;
   // sampled-point state (SAMPLE only): the point of this thread in the ground-aligned frame
   double px = 0, py = 0, pz = 0;
@@ -596,40 +650,39 @@ __global__ __launch_bounds__(NT, 8) void fit_instances_kernel(const FitParams p)
         pz = d * fma(Mg[6], ud, fma(Mg[7], vd, Mg[8]));
         if (pok) {
           acc[0] = px; acc[1] = pz; acc[2] = px * px; acc[3] = px * pz; acc[4] = pz * pz;
-          acc[5] = py; acc[6] = py;
           cnt = 1;
         }
       }
     }
   }
+#ifndef LA3D_ABL_NO_PASSA
   if (!sampled) {
     if (TILED) sweep_tiled<0>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt);
     else sweep<VEC, LDSMASK, 0>(p, dpl, mpl, bits, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, &nmask);
   }
+#else
+  if (tid == 0) { cnt = 2; acc[0] = 1; acc[1] = 2; acc[2] = 3; acc[3] = 1; acc[4] = 5; }
+#endif
 
   {
     const double r0 = wave_sum(acc[0]), r1 = wave_sum(acc[1]), r2 = wave_sum(acc[2]), r3 = wave_sum(acc[3]),
-                 r4 = wave_sum(acc[4]), r5 = wave_min(acc[5]), r6 = wave_max(acc[6]);
+                 r4 = wave_sum(acc[4]);
     const int rc = wave_sum_i(cnt), rn = wave_sum_i(nmask);
     if (lane == 0) {
       double* pp = sh->part[wave];
-      pp[0] = r0; pp[1] = r1; pp[2] = r2; pp[3] = r3; pp[4] = r4; pp[5] = r5; pp[6] = r6;
+      pp[0] = r0; pp[1] = r1; pp[2] = r2; pp[3] = r3; pp[4] = r4;
       sh->cnt[wave] = rc;
       sh->nmask[wave] = rn;
     }
   }
   __syncthreads();
 
-  double ymin = 0, ymax = 0;
   if (tid == 0) {
     double s[5] = {0, 0, 0, 0, 0};
-    ymin = INFINITY; ymax = -INFINITY;
     int n = 0, nm = 0;
 #pragma unroll 1
     for (int w = 0; w < NWAVE; ++w) {  // fixed order (not unrolled: keeps thread 0's live set small)
       for (int k = 0; k < 5; ++k) s[k] += sh->part[w][k];
-      ymin = fmin(ymin, sh->part[w][5]);
-      ymax = fmax(ymax, sh->part[w][6]);
       n += sh->cnt[w];
       nm += sh->nmask[w];
     }
@@ -640,10 +693,6 @@ __global__ __launch_bounds__(NT, 8) void fit_instances_kernel(const FitParams p)
     double cy = NAN, sy = NAN, gap = NAN;
     if (st == LA3D_BOX_OK) axis_from_sums((double)n, s[0], s[1], s[2], s[3], s[4], &cy, &sy, &gap);
     sh->cyaw = cy; sh->syaw = sy;
-    for (int j = 0; j < 3; ++j) {  // rotate_y(yaw) @ M, rows 0 and 2   (reference :154)
-      sh->N0[j] = cy * Mg[j] + sy * Mg[6 + j];
-      sh->N2[j] = -sy * Mg[j] + cy * Mg[6 + j];
-    }
     sh->st = st;
     sh->n_valid = n;
     if (p.aux) {
@@ -657,35 +706,50 @@ __global__ __launch_bounds__(NT, 8) void fit_instances_kernel(const FitParams p)
   if (sh->st != LA3D_BOX_OK) return;
 
   // ---- pass B: extents along the principal axes -----------------------------------------
-  double ext[7] = {INFINITY, -INFINITY, INFINITY, -INFINITY, 0, 0, 0};
+  double ext[6] = {INFINITY, -INFINITY, INFINITY, -INFINITY, INFINITY, -INFINITY};  // x, y, z : lo, hi
   if (sampled) {
     if (pok) {  // exactly the reference's arithmetic: rotate_y(yaw) applied to the stored point
       const double x2 = sh->cyaw * px + sh->syaw * pz;
       const double z2 = -sh->syaw * px + sh->cyaw * pz;
       ext[0] = ext[1] = x2;
-      ext[2] = ext[3] = z2;
+      ext[2] = ext[3] = py;
+      ext[4] = ext[5] = z2;
     }
   } else {
+#ifndef LA3D_ABL_NO_PASSB
+    // rows 0 and 2 of rotate_y(yaw) @ M (reference :154), recomputed per wave into SGPRs; row 1 is M's
+    const double cy = uniform_f64(sh->cyaw), sy = uniform_f64(sh->syaw);
+    double N0[3], N2[3];
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+      N0[jj] = uniform_f64(cy * Mg[jj] + sy * Mg[6 + jj]);
+      N2[jj] = uniform_f64(-sy * Mg[jj] + cy * Mg[6 + jj]);
+    }
     int d0 = 0, d1 = 0;
-    if (TILED) sweep_tiled<1>(p, dpl, bits, list, nactive, sh->N0, nullptr, sh->N2, wave, lane, ext, &d0);
-    else sweep<VEC, LDSMASK, 1>(p, dpl, mpl, bits, sh->N0, nullptr, sh->N2, wave, lane, ext, &d0, &d1);
+    if (TILED) sweep_tiled<1>(p, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0);
+    else sweep<VEC, LDSMASK, 1>(p, dpl, mpl, bits, N0, Mg + 3, N2, wave, lane, ext, &d0, &d1);
+#else
+    ext[0] = 0; ext[1] = 1; ext[2] = 0; ext[3] = 1; ext[4] = 0; ext[5] = 1;
+#endif
   }
   {
-    const double r0 = wave_min(ext[0]), r1 = wave_max(ext[1]), r2 = wave_min(ext[2]), r3 = wave_max(ext[3]);
+    const double r0 = wave_min(ext[0]), r1 = wave_max(ext[1]), r2 = wave_min(ext[2]), r3 = wave_max(ext[3]),
+                 r4 = wave_min(ext[4]), r5 = wave_max(ext[5]);
     if (lane == 0) {
       double* pp = sh->part[wave];
-      pp[0] = r0; pp[1] = r1; pp[2] = r2; pp[3] = r3;
+      pp[0] = r0; pp[1] = r1; pp[2] = r2; pp[3] = r3; pp[4] = r4; pp[5] = r5;
     }
   }
   __syncthreads();
   if (tid == 0) {
-    double xmin = INFINITY, xmax = -INFINITY, zmin = INFINITY, zmax = -INFINITY;
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
 #pragma unroll 1
-    for (int w = 0; w < NWAVE; ++w) {
-      xmin = fmin(xmin, sh->part[w][0]); xmax = fmax(xmax, sh->part[w][1]);
-      zmin = fmin(zmin, sh->part[w][2]); zmax = fmax(zmax, sh->part[w][3]);
-    }
-    write_box(p.out + (long long)inst * LA3D_REC, Rgg, sh->cyaw, sh->syaw, xmin, xmax, ymin, ymax, zmin, zmax);
+    for (int w = 0; w < NWAVE; ++w)
+      for (int k = 0; k < 3; ++k) {
+        lo[k] = fmin(lo[k], sh->part[w][2 * k]);
+        hi[k] = fmax(hi[k], sh->part[w][2 * k + 1]);
+      }
+    write_box(p.out + (long long)inst * LA3D_REC, Rgg, sh->cyaw, sh->syaw, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]);
   }
 }
 
