@@ -27,7 +27,9 @@ extern "C" {
 
 #define LA3D_ABI_VERSION 1
 #define LA3D_REC 39      /* doubles per box: center_cam[3] dimensions[3]=(dz,dy,dx) R_cam[9] bbox3D_cam[8][3] */
-#define LA3D_AUX 4       /* doubles per box: yaw, n_valid, n_in (mask pixels / cloud points), eigen-gap (l1-l2)/l1 */
+#define LA3D_AUX 4       /* doubles per box: yaw, n_valid, n_in (mask pixels / cloud points), eigen-gap (l1-l2)/l1;
+                            with LA3D_METHOD_CONVEX_HULL aux[3] = -(hull vertices) when the hull decided the yaw
+                            and stays >= 0 when the reference's PCA fallback was taken (:222-224) */
 #define LA3D_NSAMPLE 500 /* reference src/util_3dbox.py:123-125 */
 
 /* call status */
@@ -42,6 +44,7 @@ extern "C" {
 #define LA3D_BOX_BAD_GROUND 2 /* ground parallel/antiparallel to [0,-1,0] or zero: NaN rotation (:37-55)   */
 #define LA3D_BOX_TOO_FEW 3    /* one valid point: scikit-learn PCA(2) ValueError (:183-184)              */
 #define LA3D_BOX_NONFINITE 4  /* +-inf coordinate reaches PCA: scikit-learn ValueError (:183-184)        */
+#define LA3D_BOX_UNSUPPORTED 5 /* convex_hull on more than 512 valid points (the reference feeds it <= 500)  */
 
 /* yaw method (reference src/util_3dbox.py:146-151) */
 #define LA3D_METHOD_PCA 0
@@ -96,7 +99,8 @@ int la3d_fit_instances(const float* depth, int64_t depth_plane_stride, const int
  * reference src/util_3dbox.py:106-178 (caller :273-278, 500 mesh samples per object).
  * points   dev f64 [total][3];  offsets dev i64 [B+1] (cloud n = rows offsets[n]..offsets[n+1])
  * ground / sample_idx / out / status / aux as above (sample ranks index the cloud's rows).
- * method   LA3D_METHOD_PCA or LA3D_METHOD_CONVEX_HULL (clouds of <= 500 rows after sampling). */
+ * method   LA3D_METHOD_PCA or LA3D_METHOD_CONVEX_HULL (_estimate_yaw_convex_hull, :189-224; at most 512
+ *          valid rows per cloud after sampling, else that box gets LA3D_BOX_UNSUPPORTED). */
 int la3d_fit_points(const double* points, const int64_t* offsets, const double* ground,
                     const int32_t* sample_idx, int method, int B,
                     double* out, int32_t* status, double* aux, void* stream);

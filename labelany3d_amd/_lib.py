@@ -8,7 +8,7 @@ import os
 from ._build import HERE, INCLUDE, LIB, ROOT, SRC, build  # noqa: F401
 
 REC, AUX, NSAMPLE = 39, 4, 500
-BOX_OK, BOX_EMPTY, BOX_BAD_GROUND, BOX_TOO_FEW, BOX_NONFINITE = 0, 1, 2, 3, 4
+BOX_OK, BOX_EMPTY, BOX_BAD_GROUND, BOX_TOO_FEW, BOX_NONFINITE, BOX_UNSUPPORTED = 0, 1, 2, 3, 4, 5
 METHOD_PCA, METHOD_CONVEX_HULL = 0, 1
 ERR_UNSUPPORTED = -2
 

@@ -389,6 +389,34 @@ __device__ inline void sweep(const FitParams& p, const float* __restrict__ dpl, 
   }
 }
 
+// one pixel quad of a tile: PASS 0 accumulates count + moments, PASS 1 the six extents.
+// r0/r1/r2: ray components at the quad's first pixel; a00/a10/a20: their per-pixel (u+1) increments.
+template <int PASS>
+__device__ inline void quad_math(unsigned nib, const unsigned* db, double r0, double r1, double r2, double a00,
+                                 double a10, double a20, double* s, int* n) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    // 0 / -1 validity word: mask bit k set AND exponent field != 0xff
+    const int fin = ((int)(db[k] & 0x7fffffffu) - 0x7f800000) >> 31;
+    const int m = fin & -(int)((nib >> k) & 1u);
+    if (PASS == 0) {
+      const double d = (double)__uint_as_float(db[k] & (unsigned)m);   // invalid -> +0.0
+      const double x = d * r0, z = d * r2;
+      s[0] += x; s[1] += z;
+      s[2] = fma(x, x, s[2]); s[3] = fma(x, z, s[3]); s[4] = fma(z, z, s[4]);
+      *n -= m;
+    } else {
+      const double d = (double)__uint_as_float(db[k] | ~(unsigned)m);  // invalid -> NaN, ignored by min/max
+      const double x = d * r0, y = d * r1, z = d * r2;
+      s[0] = dmin(s[0], x); s[1] = dmax(s[1], x);
+      s[2] = dmin(s[2], y); s[3] = dmax(s[3], y);
+      s[4] = dmin(s[4], z); s[5] = dmax(s[5], z);
+      r1 += a10;
+    }
+    r0 += a00; r2 += a20;   // next pixel of the row: u + 1
+  }
+}
+
 // TILED walk (W % 32 == 0): a wave owns one tile of 32 px x 8 rows per step — lane = (row r = lane>>3,
 // quad cq = lane&7).  One bit-image word per tile row (broadcast to its 8 lanes), one full 128-B depth
 // line per tile row, (u,v) from the tile coordinates without any division.  Only tiles on the
@@ -410,8 +438,9 @@ __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__
   const double a20 = A2[0], a21 = A2[1], a22 = A2[2];
   double a10 = 0, a11 = 0, a12 = 0;
   if (PASS == 1) { a10 = A1[0]; a11 = A1[1]; a12 = A1[2]; }
-  double s0 = acc[0], s1 = acc[1], s2 = acc[2], s3 = acc[3], s4 = acc[4];
-  double xlo = acc[0], xhi = acc[1], ylo = acc[2], yhi = acc[3], zlo = acc[4], zhi = acc[5];
+  double sv[6];
+#pragma unroll
+  for (int i = 0; i < (PASS == 0 ? 5 : 6); ++i) sv[i] = acc[i];
   int n = *cnt;
   const bool dense = nactive < 0;                  // list overflow: walk every tile, skip empty ones
   const int nsteps = dense ? ntx * p.nty : nactive;
@@ -444,38 +473,97 @@ __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__
       if (dense && __ballot(nib[g] != 0) == 0) continue;
       const unsigned db[4] = {dq[g].x, dq[g].y, dq[g].z, dq[g].w};
       const double vd = (double)(tys[g] * 8 + r), ud = (double)(txs[g] * 32 + cq * 4);
-      double r0 = fma(a00, ud, fma(a01, vd, a02));
-      double r2 = fma(a20, ud, fma(a21, vd, a22));
+      const double r0 = fma(a00, ud, fma(a01, vd, a02));
+      const double r2 = fma(a20, ud, fma(a21, vd, a22));
       double r1 = 0;
       if (PASS == 1) r1 = fma(a10, ud, fma(a11, vd, a12));
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        // 0 / -1 validity word: mask bit k set AND exponent field != 0xff
-        const int fin = ((int)(db[k] & 0x7fffffffu) - 0x7f800000) >> 31;
-        const int m = fin & -(int)((nib[g] >> k) & 1u);
-        if (PASS == 0) {
-          const double d = (double)__uint_as_float(db[k] & (unsigned)m);
-          const double x = d * r0, z = d * r2;
-          s0 += x; s1 += z;
-          s2 = fma(x, x, s2); s3 = fma(x, z, s3); s4 = fma(z, z, s4);
-          n -= m;
-        } else {
-          const double d = (double)__uint_as_float(db[k] | ~(unsigned)m);
-          const double x = d * r0, y = d * r1, z = d * r2;
-          xlo = dmin(xlo, x); xhi = dmax(xhi, x);
-          ylo = dmin(ylo, y); yhi = dmax(yhi, y);
-          zlo = dmin(zlo, z); zhi = dmax(zhi, z);
-        }
-        r0 += a00; r2 += a20;           // next pixel of the row: u + 1
-        if (PASS == 1) r1 += a10;
-      }
+      quad_math<PASS>(nib[g], db, r0, r1, r2, a00, a10, a20, sv, &n);
     }
   }
-  if (PASS == 0) {
-    acc[0] = s0; acc[1] = s1; acc[2] = s2; acc[3] = s3; acc[4] = s4;
-    *cnt = n;
-  } else {
-    acc[0] = xlo; acc[1] = xhi; acc[2] = ylo; acc[3] = yhi; acc[4] = zlo; acc[5] = zhi;
+#pragma unroll
+  for (int i = 0; i < (PASS == 0 ? 5 : 6); ++i) acc[i] = sv[i];
+  if (PASS == 0) *cnt = n;
+}
+
+// ------------------------------------------------------------------------------------------
+// workgroup stages shared by the fit kernels (every thread of the workgroup must call them)
+// ------------------------------------------------------------------------------------------
+// moments of all waves -> thread 0 (fixed order: bit-reproducible) -> status, yaw axis, aux.
+// On return sh->st / sh->cyaw / sh->syaw are valid for every thread.
+__device__ inline void stage_moments_to_axis(Shared* sh, const FitParams& p, int inst, const double* geo,
+                                             const double* acc, int cnt, int nmask, int tid, int wave, int lane,
+                                             int nw = NWAVE) {
+  {
+    const double r0 = wave_sum(acc[0]), r1 = wave_sum(acc[1]), r2 = wave_sum(acc[2]), r3 = wave_sum(acc[3]),
+                 r4 = wave_sum(acc[4]);
+    const int rc = wave_sum_i(cnt), rn = wave_sum_i(nmask);
+    if (lane == 0) {
+      double* pp = sh->part[wave];
+      pp[0] = r0; pp[1] = r1; pp[2] = r2; pp[3] = r3; pp[4] = r4;
+      sh->cnt[wave] = rc;
+      sh->nmask[wave] = rn;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double s[5] = {0, 0, 0, 0, 0};
+    int n = 0, nm = 0;
+#pragma unroll 1
+    for (int w = 0; w < nw; ++w) {  // fixed order (not unrolled: keeps thread 0's live set small)
+      for (int k = 0; k < 5; ++k) s[k] += sh->part[w][k];
+      n += sh->cnt[w];
+      nm += sh->nmask[w];
+    }
+    int st = LA3D_BOX_OK;
+    if (geo[18] != 0.0) st = LA3D_BOX_BAD_GROUND;
+    else if (n == 0) st = LA3D_BOX_EMPTY;
+    else if (n == 1) st = LA3D_BOX_TOO_FEW;
+    double cy = NAN, sy = NAN, gap = NAN;
+    if (st == LA3D_BOX_OK) axis_from_sums((double)n, s[0], s[1], s[2], s[3], s[4], &cy, &sy, &gap);
+    sh->cyaw = cy; sh->syaw = sy;
+    sh->st = st;
+    sh->n_valid = n;
+    if (p.aux) {
+      double* a = p.aux + (long long)inst * LA3D_AUX;
+      a[0] = atan2(sy, cy); a[1] = (double)n; a[2] = (double)nm; a[3] = gap;
+    }
+    p.status[inst] = st;
+    if (st != LA3D_BOX_OK) write_nan_box(p.out + (long long)inst * LA3D_REC);
+  }
+  __syncthreads();
+}
+
+// extents (x,y,z : lo,hi) of all waves -> thread 0 -> the 39-double record
+__device__ inline void stage_extents_to_box(Shared* sh, const FitParams& p, int inst, const double* Rgg,
+                                            const double* ext, int tid, int wave, int lane, int nw = NWAVE) {
+  {
+    const double r0 = wave_min(ext[0]), r1 = wave_max(ext[1]), r2 = wave_min(ext[2]), r3 = wave_max(ext[3]),
+                 r4 = wave_min(ext[4]), r5 = wave_max(ext[5]);
+    if (lane == 0) {
+      double* pp = sh->part[wave];
+      pp[0] = r0; pp[1] = r1; pp[2] = r2; pp[3] = r3; pp[4] = r4; pp[5] = r5;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll 1
+    for (int w = 0; w < nw; ++w)
+      for (int k = 0; k < 3; ++k) {
+        lo[k] = fmin(lo[k], sh->part[w][2 * k]);
+        hi[k] = fmax(hi[k], sh->part[w][2 * k + 1]);
+      }
+    write_box(p.out + (long long)inst * LA3D_REC, Rgg, sh->cyaw, sh->syaw, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]);
+  }
+}
+
+// rows 0 and 2 of rotate_y(yaw) @ M (reference :154) as wave-uniform SGPR values; row 1 is M's row 1
+__device__ inline void yaw_rows(const Shared* sh, const double* Mg, double* N0, double* N2) {
+  const double cy = uniform_f64(sh->cyaw), sy = uniform_f64(sh->syaw);
+#pragma unroll
+  for (int jj = 0; jj < 3; ++jj) {
+    N0[jj] = uniform_f64(cy * Mg[jj] + sy * Mg[6 + jj]);
+    N2[jj] = uniform_f64(-sy * Mg[jj] + cy * Mg[6 + jj]);
   }
 }
 
@@ -664,45 +752,7 @@ __global__ __launch_bounds__(NT, 8) void fit_instances_kernel(const FitParams p)
   if (tid == 0) { cnt = 2; acc[0] = 1; acc[1] = 2; acc[2] = 3; acc[3] = 1; acc[4] = 5; }
 #endif
 
-  {
-    const double r0 = wave_sum(acc[0]), r1 = wave_sum(acc[1]), r2 = wave_sum(acc[2]), r3 = wave_sum(acc[3]),
-                 r4 = wave_sum(acc[4]);
-    const int rc = wave_sum_i(cnt), rn = wave_sum_i(nmask);
-    if (lane == 0) {
-      double* pp = sh->part[wave];
-      pp[0] = r0; pp[1] = r1; pp[2] = r2; pp[3] = r3; pp[4] = r4;
-      sh->cnt[wave] = rc;
-      sh->nmask[wave] = rn;
-    }
-  }
-  __syncthreads();
-
-  if (tid == 0) {
-    double s[5] = {0, 0, 0, 0, 0};
-    int n = 0, nm = 0;
-#pragma unroll 1
-    for (int w = 0; w < NWAVE; ++w) {  // fixed order (not unrolled: keeps thread 0's live set small)
-      for (int k = 0; k < 5; ++k) s[k] += sh->part[w][k];
-      n += sh->cnt[w];
-      nm += sh->nmask[w];
-    }
-    int st = LA3D_BOX_OK;
-    if (geo[18] != 0.0) st = LA3D_BOX_BAD_GROUND;
-    else if (n == 0) st = LA3D_BOX_EMPTY;
-    else if (n == 1) st = LA3D_BOX_TOO_FEW;
-    double cy = NAN, sy = NAN, gap = NAN;
-    if (st == LA3D_BOX_OK) axis_from_sums((double)n, s[0], s[1], s[2], s[3], s[4], &cy, &sy, &gap);
-    sh->cyaw = cy; sh->syaw = sy;
-    sh->st = st;
-    sh->n_valid = n;
-    if (p.aux) {
-      double* a = p.aux + (long long)inst * LA3D_AUX;
-      a[0] = atan2(sy, cy); a[1] = (double)n; a[2] = (double)nm; a[3] = gap;
-    }
-    p.status[inst] = st;
-    if (st != LA3D_BOX_OK) write_nan_box(p.out + (long long)inst * LA3D_REC);
-  }
-  __syncthreads();
+  stage_moments_to_axis(sh, p, inst, geo, acc, cnt, nmask, tid, wave, lane);
   if (sh->st != LA3D_BOX_OK) return;
 
   // ---- pass B: extents along the principal axes -----------------------------------------
@@ -717,14 +767,8 @@ __global__ __launch_bounds__(NT, 8) void fit_instances_kernel(const FitParams p)
     }
   } else {
 #ifndef LA3D_ABL_NO_PASSB
-    // rows 0 and 2 of rotate_y(yaw) @ M (reference :154), recomputed per wave into SGPRs; row 1 is M's
-    const double cy = uniform_f64(sh->cyaw), sy = uniform_f64(sh->syaw);
     double N0[3], N2[3];
-#pragma unroll
-    for (int jj = 0; jj < 3; ++jj) {
-      N0[jj] = uniform_f64(cy * Mg[jj] + sy * Mg[6 + jj]);
-      N2[jj] = uniform_f64(-sy * Mg[jj] + cy * Mg[6 + jj]);
-    }
+    yaw_rows(sh, Mg, N0, N2);
     int d0 = 0, d1 = 0;
     if (TILED) sweep_tiled<1>(p, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0);
     else sweep<VEC, LDSMASK, 1>(p, dpl, mpl, bits, N0, Mg + 3, N2, wave, lane, ext, &d0, &d1);
@@ -732,25 +776,7 @@ __global__ __launch_bounds__(NT, 8) void fit_instances_kernel(const FitParams p)
     ext[0] = 0; ext[1] = 1; ext[2] = 0; ext[3] = 1; ext[4] = 0; ext[5] = 1;
 #endif
   }
-  {
-    const double r0 = wave_min(ext[0]), r1 = wave_max(ext[1]), r2 = wave_min(ext[2]), r3 = wave_max(ext[3]),
-                 r4 = wave_min(ext[4]), r5 = wave_max(ext[5]);
-    if (lane == 0) {
-      double* pp = sh->part[wave];
-      pp[0] = r0; pp[1] = r1; pp[2] = r2; pp[3] = r3; pp[4] = r4; pp[5] = r5;
-    }
-  }
-  __syncthreads();
-  if (tid == 0) {
-    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-#pragma unroll 1
-    for (int w = 0; w < NWAVE; ++w)
-      for (int k = 0; k < 3; ++k) {
-        lo[k] = fmin(lo[k], sh->part[w][2 * k]);
-        hi[k] = fmax(hi[k], sh->part[w][2 * k + 1]);
-      }
-    write_box(p.out + (long long)inst * LA3D_REC, Rgg, sh->cyaw, sh->syaw, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]);
-  }
+  stage_extents_to_box(sh, p, inst, Rgg, ext, tid, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -762,10 +788,13 @@ struct PtsParams {
   const double* ground;
   const int* sample_idx;
   int B;
+  int method;
   double* out;
   int* status;
   double* aux;
 };
+
+constexpr int HULL_MAX = 512;  // points the convex-hull method holds in LDS (the reference feeds it <= 500, :123)
 
 struct alignas(16) SharedP {
   double part[NWAVEP][8];
@@ -775,10 +804,94 @@ struct alignas(16) SharedP {
   int inf[NWAVEP];
   int bad_ground;
   int st;
+  int nvalid;
+  int hull_n;       // number of hull vertices found (0 = method not run)
+  int fill;
+  int pad;
 };
 
+// LDS of the convex-hull method (separate struct: only the hull instantiation pays for it)
+struct alignas(16) SharedHull {
+  double x[HULL_MAX], z[HULL_MAX];      // valid (x', z') footprint, sorted lexicographically
+  double area[HULL_MAX];                // enclosing-rectangle area per hull edge
+  double yaw[HULL_MAX];
+  unsigned short hull[2 * HULL_MAX + 2];
+};
+
+// Minimum-area enclosing rectangle over hull-edge directions — reference src/util_3dbox.py:189-224
+// (SciPy/Qhull there; here: bitonic sort in LDS, Andrew's monotone chain, one thread per hull edge).
+// Reproduces the reference's conventions: yaw = atan2(edge_z, edge_x); points rotated by
+// [[cos,-sin],[sin,cos]] (:204-208); area of the axis-aligned extent; the FIRST strict minimum wins
+// (:216) in counter-clockwise vertex order.  Returns false when there is no 2-D hull (fewer than 3
+// vertices: Qhull raises there and the reference falls back to PCA, :222-224).
+__device__ inline bool hull_yaw(SharedHull* hs, SharedP* sh, int tid, double* yaw_out) {
+  const int n = sh->nvalid;
+  // pad to a power of two for the bitonic network
+  for (int i = n + tid; i < HULL_MAX; i += NTP) { hs->x[i] = INFINITY; hs->z[i] = INFINITY; }
+  __syncthreads();
+  for (int k = 2; k <= HULL_MAX; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < HULL_MAX; i += NTP) {
+        const int l = i ^ j;
+        if (l > i) {
+          const double xi = hs->x[i], zi = hs->z[i], xl = hs->x[l], zl = hs->z[l];
+          const bool gt = (xi > xl) || (xi == xl && zi > zl);
+          if (((i & k) == 0) ? gt : !gt) { hs->x[i] = xl; hs->z[i] = zl; hs->x[l] = xi; hs->z[l] = zi; }
+        }
+      }
+      __syncthreads();
+    }
+  if (tid == 0) {  // monotone chain: lower hull left->right, then upper hull right->left (counter-clockwise)
+    unsigned short* H = hs->hull;
+    int k = 0;
+    auto cross = [&](int o, int a, int b) {
+      return (hs->x[a] - hs->x[o]) * (hs->z[b] - hs->z[o]) - (hs->z[a] - hs->z[o]) * (hs->x[b] - hs->x[o]);
+    };
+    for (int i = 0; i < n; ++i) {
+      while (k >= 2 && cross(H[k - 2], H[k - 1], i) <= 0) --k;
+      H[k++] = (unsigned short)i;
+    }
+    for (int i = n - 2, t = k + 1; i >= 0; --i) {
+      while (k >= t && cross(H[k - 2], H[k - 1], i) <= 0) --k;
+      H[k++] = (unsigned short)i;
+    }
+    sh->hull_n = k - 1;  // last vertex repeats the first
+  }
+  __syncthreads();
+  const int h = sh->hull_n;
+  if (h < 3) return false;
+  for (int e = tid; e < h; e += NTP) {
+    const int i0 = hs->hull[e], i1 = hs->hull[(e + 1 == h) ? 0 : e + 1];
+    const double yaw = atan2(hs->z[i1] - hs->z[i0], hs->x[i1] - hs->x[i0]);
+    const double cs = cos(yaw), sn = sin(yaw);
+    double xlo = INFINITY, xhi = -INFINITY, zlo = INFINITY, zhi = -INFINITY;
+    for (int j = 0; j < n; ++j) {
+      const double px = hs->x[j], pz = hs->z[j];
+      const double rx = cs * px - sn * pz, rz = sn * px + cs * pz;
+      xlo = fmin(xlo, rx); xhi = fmax(xhi, rx); zlo = fmin(zlo, rz); zhi = fmax(zhi, rz);
+    }
+    hs->area[e] = (xhi - xlo) * (zhi - zlo);
+    hs->yaw[e] = yaw;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double best = INFINITY, by = 0.0;
+    for (int e = 0; e < h; ++e)
+      if (hs->area[e] < best) { best = hs->area[e]; by = hs->yaw[e]; }
+    hs->yaw[0] = by;
+  }
+  __syncthreads();
+  *yaw_out = hs->yaw[0];
+  return true;
+}
+
+template <bool HULL> struct HullStore {};
+template <> struct HullStore<true> { SharedHull h; };
+
+template <bool HULL>
 __global__ __launch_bounds__(NTP) void fit_points_kernel(const PtsParams p) {
   __shared__ SharedP sh;
+  __shared__ HullStore<HULL> hstore;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = blockIdx.x;
   const long long off = p.offsets[c];
@@ -786,7 +899,11 @@ __global__ __launch_bounds__(NTP) void fit_points_kernel(const PtsParams p) {
   const bool sampled = p.sample_idx != nullptr && n_in > LA3D_NSAMPLE;  // reference :123
   const long long m = sampled ? LA3D_NSAMPLE : n_in;
   const int* sidx = sampled ? p.sample_idx + (long long)c * LA3D_NSAMPLE : nullptr;
-  if (tid == 0) sh.bad_ground = ground_rotation(p.ground ? p.ground + (long long)c * 4 : nullptr, sh.Rg);
+  if (tid == 0) {
+    sh.bad_ground = ground_rotation(p.ground ? p.ground + (long long)c * 4 : nullptr, sh.Rg);
+    sh.fill = 0;
+    sh.hull_n = 0;
+  }
   __syncthreads();
   const double R00 = sh.Rg[0], R01 = sh.Rg[1], R02 = sh.Rg[2], R10 = sh.Rg[3], R11 = sh.Rg[4], R12 = sh.Rg[5],
                R20 = sh.Rg[6], R21 = sh.Rg[7], R22 = sh.Rg[8];
@@ -810,6 +927,10 @@ __global__ __launch_bounds__(NTP) void fit_points_kernel(const PtsParams p) {
       s0 += x; s1 += z; s2 = fma(x, x, s2); s3 = fma(x, z, s3); s4 = fma(z, z, s4);
       ylo = fmin(ylo, y); yhi = fmax(yhi, y);
       n += 1;
+      if constexpr (HULL) {  // footprint for the hull method (order is irrelevant: it is sorted next)
+        const int slot = atomicAdd(&sh.fill, 1);
+        if (slot < HULL_MAX) { hstore.h.x[slot] = x; hstore.h.z[slot] = z; }
+      }
     }
   }
   {
@@ -840,7 +961,8 @@ __global__ __launch_bounds__(NTP) void fit_points_kernel(const PtsParams p) {
     else if (nn == 1) st = LA3D_BOX_TOO_FEW;
     double cy = NAN, sy = NAN, gap = NAN;
     if (st == LA3D_BOX_OK) axis_from_sums((double)nn, s[0], s[1], s[2], s[3], s[4], &cy, &sy, &gap);
-    sh.cyaw = cy; sh.syaw = sy; sh.st = st;
+    if (HULL && st == LA3D_BOX_OK && nn > HULL_MAX) st = LA3D_BOX_UNSUPPORTED;
+    sh.cyaw = cy; sh.syaw = sy; sh.st = st; sh.nvalid = nn;
     if (p.aux) {
       double* a = p.aux + (long long)c * LA3D_AUX;
       a[0] = atan2(sy, cy); a[1] = (double)nn; a[2] = (double)n_in; a[3] = gap;
@@ -850,6 +972,22 @@ __global__ __launch_bounds__(NTP) void fit_points_kernel(const PtsParams p) {
   }
   __syncthreads();
   if (sh.st != LA3D_BOX_OK) return;
+  if constexpr (HULL) {
+    double yaw;
+    if (hull_yaw(&hstore.h, &sh, tid, &yaw)) {   // else: degenerate hull -> the PCA axis stands (reference :222-224)
+      if (tid == 0) {
+        double sy_, cy_;
+        sincos(yaw, &sy_, &cy_);
+        sh.cyaw = cy_; sh.syaw = sy_;
+        if (p.aux) {
+          double* a = p.aux + (long long)c * LA3D_AUX;
+          a[0] = yaw;
+          a[3] = -(double)sh.hull_n;  // negative: the hull decided the yaw (value = number of hull vertices)
+        }
+      }
+      __syncthreads();
+    }
+  }
   const double cy = sh.cyaw, sy = sh.syaw;
   double xlo = INFINITY, xhi = -INFINITY, zlo = INFINITY, zhi = -INFINITY;
   for (long long i = tid; i < m; i += NTP) {
@@ -1120,15 +1258,18 @@ int la3d_fit_points(const double* points, const int64_t* offsets, const double* 
     set_err("la3d_fit_points: bad argument");
     return LA3D_ERR_ARG;
   }
-  if (method != LA3D_METHOD_PCA) {
-    set_err("la3d_fit_points: method not supported by this build");
-    return LA3D_ERR_UNSUPPORTED;
+  if (method != LA3D_METHOD_PCA && method != LA3D_METHOD_CONVEX_HULL) {
+    set_err("la3d_fit_points: unknown method");
+    return LA3D_ERR_ARG;
   }
   if (B == 0) return LA3D_SUCCESS;
   PtsParams p;
   p.points = points; p.offsets = reinterpret_cast<const long long*>(offsets); p.ground = ground;
-  p.sample_idx = sample_idx; p.B = B; p.out = out; p.status = status; p.aux = aux;
-  hipLaunchKernelGGL(fit_points_kernel, dim3(B), dim3(NTP), 0, static_cast<hipStream_t>(stream), p);
+  p.sample_idx = sample_idx; p.B = B; p.method = method; p.out = out; p.status = status; p.aux = aux;
+  if (method == LA3D_METHOD_CONVEX_HULL)
+    hipLaunchKernelGGL(fit_points_kernel<true>, dim3(B), dim3(NTP), 0, static_cast<hipStream_t>(stream), p);
+  else
+    hipLaunchKernelGGL(fit_points_kernel<false>, dim3(B), dim3(NTP), 0, static_cast<hipStream_t>(stream), p);
   return check_launch("fit_points_kernel");
 }
 

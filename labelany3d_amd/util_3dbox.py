@@ -27,6 +27,7 @@ _MESSAGES = {
     _lib.BOX_BAD_GROUND: "No valid points after removing NaN values",  # NaN rotation -> every row NaN -> :143
     _lib.BOX_TOO_FEW: "n_components=2 must be between 0 and min(n_samples, n_features)=1 with svd_solver='full'",
     _lib.BOX_NONFINITE: "Input X contains infinity or a value too large for dtype('float64').",
+    _lib.BOX_UNSUPPORTED: "convex_hull on more than 512 valid points is not supported (the reference subsamples to 500)",
 }
 
 
@@ -87,7 +88,10 @@ def _fit_one(in_pc, ground_equ, method):
     st = int(status[0])
     if st != _lib.BOX_OK:
         raise ValueError(_MESSAGES[st])
-    return boxes[0].cpu().numpy(), aux[0].cpu().numpy()
+    aux = aux[0].cpu().numpy()
+    if method == "convex_hull" and aux[3] >= 0:  # no 2-D hull: the kernel took the reference's PCA fallback (:222-224)
+        print("ConvexHull failed: degenerate footprint (fewer than 3 hull vertices), falling back to PCA")
+    return boxes[0].cpu().numpy(), aux
 
 
 def estimate_bbox(in_pc, cat_name=None, ground_equ=None, method="pca"):
@@ -111,12 +115,8 @@ def _estimate_yaw_pca(rotated_pc):
 
 def _estimate_yaw_convex_hull(rotated_pc):
     """Yaw of the minimum-area enclosing rectangle over hull edges (reference :189-224)."""
-    try:
-        _, aux = _fit_one(rotated_pc, None, "convex_hull")
-        return np.float64(aux[0])
-    except Exception as e:  # noqa: BLE001 — the reference falls back on any failure (:222-224)
-        print(f"ConvexHull failed: {e}, falling back to PCA")
-        return _estimate_yaw_pca(rotated_pc)
+    _, aux = _fit_one(rotated_pc, None, "convex_hull")  # PCA fallback (:222-224) happens inside the kernel
+    return np.float64(aux[0])
 
 
 # ---- scene harness (reference :231-294) ----------------------------------------------------------

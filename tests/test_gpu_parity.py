@@ -117,8 +117,6 @@ def test_g2_estimate_bbox_dropin(la, golden):
     f32_case = int(g["f32_case"][0])
     for i, tag in enumerate(g["tags"]):
         tag, method = str(tag), str(g["methods"][i])
-        if method == "convex_hull":
-            continue  # covered by test_convex_hull_method
         pc = g["pcs"][i, : g["lens"][i]]
         if i == f32_case:
             pc = pc.astype(np.float32)
@@ -336,6 +334,50 @@ def test_fit_points_batched_vs_oracle(la):
         assert_records(np_(boxes[i])[None], rec[None], f"cloud{i}")
         if st == O.ST_OK:
             assert float(aux[i, 0]) == pytest.approx(a["yaw"], abs=1e-9)
+
+
+def test_convex_hull_method(la):
+    """method='convex_hull' (reference src/util_3dbox.py:189-224) — the reference's own outputs are in
+    the G2 fixtures (test_g2_estimate_bbox_dropin); here: random clouds vs the oracle, the PCA fallback
+    on a degenerate footprint, sampling above 500 points, and the 512-point limit."""
+    from labelany3d_amd import util_3dbox as U
+
+    rs = np.random.RandomState(31)
+    clouds, grounds = [], []
+    for i in range(24):
+        n = int(rs.choice([3, 4, 10, 60, 200, 500]))
+        pc = rs.rand(n, 3) * rs.uniform(0.2, 3, 3) + rs.uniform(-2, 2, 3) + [0, 0, 5]  # uniform box: many hull vertices
+        pc = pc @ O.rotate_y(rs.uniform(-3, 3)).T
+        clouds.append(pc)
+        grounds.append([np.nan] * 4 if i % 2 else list(rs.randn(3) * 0.2 + [0, -1, 0]) + [1.0])
+    grounds = np.array(grounds)
+    boxes, status, aux = la.fit_points(clouds, grounds, None, "convex_hull")
+    for i, c in enumerate(clouds):
+        g = None if np.isnan(grounds[i, 0]) else grounds[i]
+        rec, st, a = O.fit_points(c, g, False, "convex_hull")
+        assert int(status[i]) == st == 0
+        assert_records(np_(boxes[i])[None], rec[None], f"hull{i}")
+        assert float(aux[i, 0]) == pytest.approx(a["yaw"], abs=1e-9)
+        assert float(aux[i, 3]) <= -3  # the hull decided (>= 3 vertices)
+    # collinear footprint -> no 2-D hull -> PCA fallback, with the reference's printed notice
+    line = np.stack([np.linspace(-1, 1, 9), rs.randn(9) * 0.1, 5 + 0.5 * np.linspace(-1, 1, 9)], 1)
+    v, c, d, R, printed = _run_estimate(U, line, None, "convex_hull")
+    assert "falling back to PCA" in printed
+    ref = O.pack39(*O.estimate_bbox(line, None, None, "pca"))
+    assert_records(O.pack39(v, c, d, R)[None], ref[None], "hull-fallback")
+    assert U._estimate_yaw_convex_hull(clouds[5]) == pytest.approx(O.yaw_convex_hull(clouds[5]), abs=1e-9)
+    assert U._estimate_yaw_pca(clouds[5]) == pytest.approx(O.yaw_pca_closed_form(clouds[5]), abs=1e-9)
+    # above 500 points the scalar path subsamples first (global RNG), like the reference
+    big = rs.rand(3000, 3) * [2, 1, 1] + [0, 0, 4]
+    np.random.seed(5)
+    idx = np.random.randint(0, 3000, 500)
+    np.random.seed(5)
+    v, c, d, R, _ = _run_estimate(U, big, None, "convex_hull")
+    ref = O.pack39(*O.estimate_bbox(big, None, None, "convex_hull", rand_ind=idx))
+    assert_records(O.pack39(v, c, d, R)[None], ref[None], "hull-sampled")
+    # batched ABI without sampling: more than 512 valid points is reported per box, not as a failed call
+    _, st, _ = la.fit_points([big, clouds[0]], None, None, "convex_hull")
+    assert np_(st).tolist() == [5, 0]
 
 
 # ------------------------------------------------------------------------------------------
