@@ -1,0 +1,356 @@
+// la3d_device.hpp — device-side building blocks shared by the fit engines (la3d.hip: one workgroup per
+// instance; la3d_split.hip: band scan + tile-range-balanced passes).  Reference semantics cited per
+// function (paths relative to /root/reference).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "la3d.h"
+
+namespace la3d {
+
+
+constexpr int NT = 512;          // threads per workgroup (fit_instances)
+constexpr int NWAVE = NT / 64;   // wave64
+constexpr int NTP = 256;         // threads per workgroup (fit_points)
+constexpr int NWAVEP = NTP / 64;
+constexpr double PI_2 = 1.57079632679489661923;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // native vector: usable with nontemporal builtins
+
+extern thread_local char g_err[256];
+inline void set_err(const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
+
+// ------------------------------------------------------------------------------------------
+// float64 -> float16 (round to nearest even, overflow to inf, gradual underflow) -> float64.
+// Mirrors numpy's astype(float16) applied to the 8 corners at reference src/util_3dbox.py:165.
+// ------------------------------------------------------------------------------------------
+__host__ __device__ inline double f16_round(double x) {
+  if (x != x) return x;
+  const double ax = fabs(x);
+  if (ax >= 65520.0) return x > 0 ? INFINITY : -INFINITY;  // halfway to 65536 rounds to even = overflow
+  double q;
+  if (ax < 6.103515625e-05) {  // below 2^-14: half subnormals, fixed quantum 2^-24
+    q = 5.9604644775390625e-08;
+  } else {
+    int e;
+    (void)frexp(ax, &e);       // ax = m * 2^e, m in [0.5, 1)  ->  floor(log2 ax) = e - 1
+    q = ldexp(1.0, e - 11);    // 10 explicit mantissa bits
+  }
+  return rint(x / q) * q;      // both scalings are exact powers of two; rint is RNE
+}
+
+// ------------------------------------------------------------------------------------------
+// small fp64 algebra, done by one thread per box
+// ------------------------------------------------------------------------------------------
+// 3x3 inverse by Gaussian elimination with partial pivoting on [A | I] (np.linalg.inv is LAPACK
+// gesv: same elimination order; reference src/util.py:56).
+__device__ inline void inv3(const double* A, double* X) {
+  double a[3][6];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      a[i][j] = A[i * 3 + j];
+      a[i][3 + j] = (i == j) ? 1.0 : 0.0;
+    }
+  for (int c = 0; c < 3; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < 3; ++r)
+      if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
+    if (piv != c)
+      for (int j = 0; j < 6; ++j) {
+        double t = a[c][j];
+        a[c][j] = a[piv][j];
+        a[piv][j] = t;
+      }
+    const double inv = 1.0 / a[c][c];
+    for (int r = c + 1; r < 3; ++r) {
+      const double f = a[r][c] * inv;
+      for (int j = c; j < 6; ++j) a[r][j] -= f * a[c][j];
+    }
+  }
+  for (int j = 0; j < 3; ++j) {  // back substitution per right-hand side
+    for (int r = 2; r >= 0; --r) {
+      double s = a[r][3 + j];
+      for (int k = r + 1; k < 3; ++k) s -= a[r][k] * X[k * 3 + j];
+      X[r * 3 + j] = s / a[r][r];
+    }
+  }
+}
+
+// Rg of reference src/util_3dbox.py:128-134 (+ :20-25, :37-55).  ground == nullptr or a NaN
+// first component selects the identity ("ground_equ is None").  Returns 1 when the matrix
+// is not finite (parallel / antiparallel / zero ground vector -> 0/0).
+__device__ inline int ground_rotation(const double* ground, double* Rg) {
+  for (int i = 0; i < 9; ++i) Rg[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  if (ground == nullptr) return 0;
+  double g0 = ground[0], g1 = ground[1], g2 = ground[2];
+  if (g0 != g0) return 0;
+  // dot([0,-1,0], g) = 0*g0 + (-1)*g1 + 0*g2  <= 0  -> negate           (:129-131)
+  const double dotp = 0.0 * g0 + (-1.0) * g1 + 0.0 * g2;
+  if (dotp <= 0) { g0 = -g0; g1 = -g1; g2 = -g2; }
+  const double nrm = sqrt(g0 * g0 + g1 * g1 + g2 * g2);  // normalize(): unchanged when 0 (:20-25)
+  if (nrm != 0) { g0 /= nrm; g1 /= nrm; g2 /= nrm; }
+  // vec1 = [0,-1,0];  axis = cross(vec1, vec2);  cos = dot(vec1, vec2)   (:43-44)
+  const double ax = (-1.0) * g2 - 0.0 * g1;
+  const double ay = 0.0 * g0 - 0.0 * g2;
+  const double az = 0.0 * g1 - (-1.0) * g0;
+  const double cs = 0.0 * g0 + (-1.0) * g1 + 0.0 * g2;
+  const double k[9] = {0, -az, ay, az, 0, -ax, -ay, ax, 0};
+  const double an = sqrt(ax * ax + ay * ay + az * az);
+  const double f = (1.0 - cs) / (an * an);
+  int bad = 0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double kk = 0;
+      for (int m = 0; m < 3; ++m) kk += k[i * 3 + m] * k[m * 3 + j];
+      const double r = ((i == j) ? 1.0 : 0.0) + k[i * 3 + j] + kk * f;
+      Rg[i * 3 + j] = r;
+      if (!(fabs(r) <= 1.79769313486231570815e308)) bad = 1;
+    }
+  return bad;
+}
+
+// scikit-learn PCA(2) first axis in closed form + svd_flip(u_based_decision=False)
+// (reference src/util_3dbox.py:181-186).  Raw sums -> (cos yaw, sin yaw), eigen-gap.
+// The reference goes eigenvector -> atan2 -> cos/sin; here the unit eigenvector (vx, vz) IS
+// (cos yaw, sin yaw), obtained without trigonometry from cos 2t = (a-c)/2r, sin 2t = b/r by the
+// stable half-angle form (agrees with the trig route to ~1 ulp; keeps fp64 libm range reduction out
+// of the streaming kernel's register budget and off the per-workgroup serial path).
+__device__ inline void axis_from_sums(double n, double sx, double sz, double sxx, double sxz, double szz,
+                                      double* cyaw, double* syaw, double* gap) {
+  const double a = sxx - sx * sx / n;
+  const double c = szz - sz * sz / n;
+  const double b = sxz - sx * sz / n;
+  const double half = 0.5 * (a - c);
+  const double rad = sqrt(half * half + b * b);
+  const double l1 = 0.5 * (a + c) + rad;
+  *gap = (l1 > 0) ? 2.0 * rad / l1 : 0.0;
+  if (b == 0 && a == c) {  // exact isotropy: eigh branch (n >= 20) -> yaw = pi/2; SVD branch recorded as 0
+    if (n >= 20) { *cyaw = 6.123233995736766e-17; *syaw = 1.0; }  // np.cos(pi/2), np.sin(pi/2)
+    else { *cyaw = 1.0; *syaw = 0.0; }
+    return;
+  }
+  const double c2 = half / rad, s2 = b / rad;
+  double vx, vz;  // (cos t, sin t), t in [-pi/2, pi/2]
+  if (c2 >= 0) { vx = sqrt(0.5 * (1.0 + c2)); vz = 0.5 * s2 / vx; }
+  else { vz = copysign(sqrt(0.5 * (1.0 - c2)), s2); vx = 0.5 * s2 / vz; }
+  if (fabs(vx) >= fabs(vz)) {   // svd_flip: the larger-|.| entry becomes positive, first index on ties
+    if (vx < 0) { vx = -vx; vz = -vz; }
+  } else if (vz < 0) {
+    vx = -vx; vz = -vz;
+  }
+  *cyaw = vx; *syaw = vz;
+}
+
+// Steps (6)-(12) of estimate_bbox (reference src/util_3dbox.py:157-176) from the extents.
+__device__ inline void write_box(double* out, const double* Rg, double cyaw, double syaw,
+                                 double xmin, double xmax, double ymin, double ymax, double zmin, double zmax) {
+  const double dx = xmax - xmin, dy = ymax - ymin, dz = zmax - zmin;
+  const double c[3] = {(xmin + xmax) / 2, (ymin + ymax) / 2, (zmin + zmax) / 2};
+  const double h[3] = {dx / 2, dy / 2, dz / 2};
+  // rotate_y(-yaw): cos(-y) = cos y, sin(-y) = -sin y                     (:28-34)
+  const double Ry[9] = {cyaw, 0, -syaw, 0, 1, 0, syaw, 0, cyaw};
+  // center_cam = Rg^T @ (rotate_y(-yaw) @ c)                              (:172-173)
+  double w[3];
+  for (int i = 0; i < 3; ++i) w[i] = Ry[i * 3] * c[0] + Ry[i * 3 + 1] * c[1] + Ry[i * 3 + 2] * c[2];
+  for (int i = 0; i < 3; ++i) out[i] = Rg[i] * w[0] + Rg[3 + i] * w[1] + Rg[6 + i] * w[2];
+  out[3] = dz; out[4] = dy; out[5] = dx;                                // dimension = [dz, dy, dx]  (:175)
+  // R_cam = Rg^T @ rotate_y(-yaw)                                         (:176)
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      out[6 + i * 3 + j] = Rg[i] * Ry[j] + Rg[3 + i] * Ry[3 + j] + Rg[6 + i] * Ry[6 + j];
+  // 8 corners, fixed sign order (:83-92), fp16 cast (:165), un-rotate with rotate_y(-yaw) then Rg (:168-169)
+  const int sg[8][3] = {{-1, -1, -1}, {1, -1, -1}, {1, 1, -1}, {-1, 1, -1}, {-1, -1, 1}, {1, -1, 1}, {1, 1, 1}, {-1, 1, 1}};
+  for (int v = 0; v < 8; ++v) {
+    double g[3], r[3];
+    for (int i = 0; i < 3; ++i) g[i] = f16_round(sg[v][i] * h[i] + c[i]);
+    for (int i = 0; i < 3; ++i) r[i] = Ry[i * 3] * g[0] + Ry[i * 3 + 1] * g[1] + Ry[i * 3 + 2] * g[2];
+    for (int i = 0; i < 3; ++i) out[15 + v * 3 + i] = r[0] * Rg[i * 3] + r[1] * Rg[i * 3 + 1] + r[2] * Rg[i * 3 + 2];
+  }
+}
+
+// Same record, written by one wave: lanes 0..7 take one corner each, lane 8 center + dims, lanes 9..11 one
+// R_cam row each (the single-thread version is ~3000 dependent fp64 instructions, i.e. ~10 us of pure
+// latency when a whole kernel consists of it).  Bit-identical to write_box.
+__device__ inline void write_box_wave(double* out, const double* Rg, double cyaw, double syaw, double xmin, double xmax,
+                                      double ymin, double ymax, double zmin, double zmax, int lane) {
+  const double dx = xmax - xmin, dy = ymax - ymin, dz = zmax - zmin;
+  const double c[3] = {(xmin + xmax) / 2, (ymin + ymax) / 2, (zmin + zmax) / 2};
+  const double h[3] = {dx / 2, dy / 2, dz / 2};
+  const double Ry[9] = {cyaw, 0, -syaw, 0, 1, 0, syaw, 0, cyaw};
+  if (lane < 8) {
+    const int sx = (lane == 1 || lane == 2 || lane == 5 || lane == 6) ? 1 : -1;
+    const int sy = (lane == 2 || lane == 3 || lane == 6 || lane == 7) ? 1 : -1;
+    const int sz = (lane >= 4) ? 1 : -1;
+    double g[3], r[3];
+    g[0] = f16_round(sx * h[0] + c[0]); g[1] = f16_round(sy * h[1] + c[1]); g[2] = f16_round(sz * h[2] + c[2]);
+    for (int i = 0; i < 3; ++i) r[i] = Ry[i * 3] * g[0] + Ry[i * 3 + 1] * g[1] + Ry[i * 3 + 2] * g[2];
+    for (int i = 0; i < 3; ++i) out[15 + lane * 3 + i] = r[0] * Rg[i * 3] + r[1] * Rg[i * 3 + 1] + r[2] * Rg[i * 3 + 2];
+  } else if (lane == 8) {
+    double w[3];
+    for (int i = 0; i < 3; ++i) w[i] = Ry[i * 3] * c[0] + Ry[i * 3 + 1] * c[1] + Ry[i * 3 + 2] * c[2];
+    for (int i = 0; i < 3; ++i) out[i] = Rg[i] * w[0] + Rg[3 + i] * w[1] + Rg[6 + i] * w[2];
+    out[3] = dz; out[4] = dy; out[5] = dx;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)   // lanes 9, 10, 11: one row of R_cam each (static indices: no scratch)
+      if (lane == 9 + i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) out[6 + i * 3 + j] = Rg[i] * Ry[j] + Rg[3 + i] * Ry[3 + j] + Rg[6 + i] * Ry[6 + j];
+      }
+  }
+}
+
+__device__ inline void write_nan_box(double* out) {
+  for (int i = 0; i < LA3D_REC; ++i) out[i] = NAN;
+}
+
+// ------------------------------------------------------------------------------------------
+// wave64 reductions (fixed butterfly order -> deterministic)
+// ------------------------------------------------------------------------------------------
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ inline double wave_min(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ inline double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ inline int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// wave-uniform double -> SGPR pair (the value is identical in every lane by construction)
+__device__ inline double uniform_f64(double v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const unsigned hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double((int)hi, (int)lo);
+}
+
+// XCD-aware block -> work-item map: the dispatcher is observed to place block b on XCD b % 8
+// (speed only, never correctness), so consecutive instances — which share an image's depth
+// plane in the shared-depth layout — land on one XCD's L2.  Bijective for any nb.
+__device__ inline int xcd_remap(int b, int nb) {
+  const int q = nb >> 3, r = nb & 7, x = b & 7;
+  const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + (b >> 3);
+}
+
+// 4 mask bytes -> 4 bits (bit k = byte k non-zero)
+__device__ inline unsigned nz4(unsigned w) {
+  const unsigned t = (((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u;  // high bit of each non-zero byte
+  return ((t >> 7) * 0x01020408u) >> 24;                                       // gather bits 0,8,16,24 -> 0..3
+}
+__device__ inline bool finite_f32(float d) { return (__float_as_uint(d) & 0x7f800000u) != 0x7f800000u; }
+
+// Raw fp64 min/max.  fmin()/fmax() on a loop-carried accumulator make hipcc emit a canonicalising
+// v_max_f64 x,x before every use (it cannot prove the accumulator is not a signalling NaN): +1 DP
+// instruction per min/max.  The hardware instructions already implement IEEE minNum/maxNum — a quiet
+// NaN operand returns the OTHER operand — which is exactly what the masked walk relies on: pixels
+// that are unmasked or non-finite carry a NaN depth and are ignored by the extents.
+__device__ inline double dmin(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ inline double dmax(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+struct FitParams {
+  const float* depth;
+  long long depth_plane_stride;
+  const int* image_index;
+  const unsigned char* mask;
+  const double* K;
+  int k_stride;
+  const double* ground;
+  const int* sample_idx;
+  int B, H, W, HW;
+  int nwords;          // ceil(HW / 32) bit-image words
+  int mask_lds_bytes;  // bit-image bytes in LDS (16-aligned), 0 when the image does not fit
+  int rows_aligned;    // W % 4 == 0: a 4-pixel quad never straddles a row
+  float rcpW;
+  double* geo;         // workspace: [B][GEO_D]
+  int ntx, nty;        // TILED: tiles of 32 px x 8 rows (ntx = W/32, nty = ceil(H/8))
+  int tiles_per_wave;  // TILED: ceil(ntx*nty / NWAVE)
+  int list_cap;        // TILED: entries of the active-tile list that fit the LDS budget
+  double* out;
+  int* status;
+  double* aux;
+};
+
+// per-instance geometry written by prep_kernel into the workspace (20 doubles = 160 B)
+constexpr int GEO_D = 20;  // M[9] (= Rg^T Kinv : p' = d * (M @ [u,v,1])), Rg[9], bad_ground, pad
+
+struct alignas(16) Shared {
+  double part[NWAVE][7];
+  double cyaw, syaw;
+  int cnt[NWAVE];
+  int nmask[NWAVE];
+  unsigned scan[NWAVE];
+  int n_valid;
+  int st;
+};
+
+__device__ inline void pix_uv(unsigned i, int W, float rcpW, unsigned* u, unsigned* v) {
+  unsigned vv = (unsigned)((float)i * rcpW);
+  int r = (int)i - (int)(vv * (unsigned)W);
+  if (r < 0) { vv -= 1; r += W; }
+  else if (r >= W) { vv += 1; r -= W; }
+  *u = (unsigned)r;
+  *v = vv;
+}
+
+// one pixel quad of a tile: PASS 0 accumulates count + moments, PASS 1 the six extents.
+// r0/r1/r2: ray components at the quad's first pixel; a00/a10/a20: their per-pixel (u+1) increments.
+template <int PASS>
+__device__ inline void quad_math(unsigned nib, const unsigned* db, double r0, double r1, double r2, double a00,
+                                 double a10, double a20, double* s, int* n) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    // 0 / -1 validity word: mask bit k set AND exponent field != 0xff
+    const int fin = ((int)(db[k] & 0x7fffffffu) - 0x7f800000) >> 31;
+    const int m = fin & -(int)((nib >> k) & 1u);
+    if (PASS == 0) {
+      const double d = (double)__uint_as_float(db[k] & (unsigned)m);   // invalid -> +0.0
+      const double x = d * r0, z = d * r2;
+      s[0] += x; s[1] += z;
+      s[2] = fma(x, x, s[2]); s[3] = fma(x, z, s[3]); s[4] = fma(z, z, s[4]);
+      *n -= m;
+    } else {
+      const double d = (double)__uint_as_float(db[k] | ~(unsigned)m);  // invalid -> NaN, ignored by min/max
+      const double x = d * r0, y = d * r1, z = d * r2;
+      s[0] = dmin(s[0], x); s[1] = dmax(s[1], x);
+      s[2] = dmin(s[2], y); s[3] = dmax(s[3], y);
+      s[4] = dmin(s[4], z); s[5] = dmax(s[5], z);
+      r1 += a10;
+    }
+    r0 += a00; r2 += a20;   // next pixel of the row: u + 1
+  }
+}
+
+
+inline int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return LA3D_ERR_HIP;
+  }
+  return LA3D_SUCCESS;
+}
+
+}  // namespace la3d

@@ -185,7 +185,15 @@ def test_g5_composed_path(la, golden):
 # ------------------------------------------------------------------------------------------
 # oracle comparisons on seeded inputs
 # ------------------------------------------------------------------------------------------
-def test_full_mask_mode_vs_oracle_640x480(la):
+@pytest.fixture(params=["instance", "split"])
+def engine(request, monkeypatch):
+    """la3d_fit_instances has two engines (one workgroup per instance / band scan + balanced tile walk);
+    the library picks by batch size, LA3D_ENGINE pins one.  Parity tests run through both."""
+    monkeypatch.setenv("LA3D_ENGINE", request.param)
+    return request.param
+
+
+def test_full_mask_mode_vs_oracle_640x480(la, engine):
     """BASELINE config-2 shaped inputs (private 480x640 depth planes, rectangular masks), 48 instances."""
     rs = np.random.RandomState(1234)
     B, H, W = 48, 480, 640
@@ -204,7 +212,7 @@ def test_full_mask_mode_vs_oracle_640x480(la):
     np.testing.assert_array_equal(a[:, 2], masks.reshape(B, -1).sum(1))
 
 
-def test_smooth_depth_compact_objects(la):
+def test_smooth_depth_compact_objects(la, engine):
     """Compact objects (smooth depth): small eigen-gaps and strong moment cancellation."""
     rs = np.random.RandomState(7)
     B, H, W = 32, 480, 640
@@ -218,7 +226,7 @@ def test_smooth_depth_compact_objects(la):
     assert_records(np_(boxes), np.array([r[0] for r in ref]), "smooth", gap=np_(aux)[:, 3])
 
 
-def test_shared_depth_with_image_index_and_per_image_K(la):
+def test_shared_depth_with_image_index_and_per_image_K(la, engine):
     rs = np.random.RandomState(3)
     P, B, H, W = 3, 10, 96, 128
     depth = rs.uniform(1, 6, (P, H, W)).astype(np.float32)
@@ -235,7 +243,7 @@ def test_shared_depth_with_image_index_and_per_image_K(la):
     assert_records(np_(boxes1), ref1, "single-plane")
 
 
-def test_irregular_masks_u8_values_and_nonfinite_depth(la):
+def test_irregular_masks_u8_values_and_nonfinite_depth(la, engine):
     rs = np.random.RandomState(5)
     B, H, W = 6, 64, 80
     depth = rs.uniform(1, 5, (B, H, W)).astype(np.float32)
@@ -251,7 +259,7 @@ def test_irregular_masks_u8_values_and_nonfinite_depth(la):
     np.testing.assert_array_equal(np_(aux)[:, 1], rn)  # NaN / inf pixels dropped exactly as the reference drops them
 
 
-def test_status_codes_batched(la):
+def test_status_codes_batched(la, engine):
     H, W = 32, 48
     depth = np.full((H, W), 2.0, np.float32)
     masks = np.zeros((6, H, W), bool)
@@ -274,8 +282,8 @@ def test_status_codes_batched(la):
     assert_records(b, ref, "status")
 
 
-@pytest.mark.parametrize("H,W", [(37, 53), (30, 50), (64, 66), (1000, 1100)])
-def test_odd_frame_sizes(la, H, W):
+@pytest.mark.parametrize("H,W", [(37, 53), (30, 50), (64, 66), (1000, 1100), (100, 96), (72, 2048)])
+def test_odd_frame_sizes(la, H, W, engine):
     """Unaligned planes (scalar path), rows not a multiple of 4, and a frame whose bit image does
     not fit LDS (H*W > 1M -> the kernel re-reads the u8 mask instead)."""
     rs = np.random.RandomState(H * W)
@@ -383,7 +391,7 @@ def test_convex_hull_method(la):
 # ------------------------------------------------------------------------------------------
 # full-size, size-independent properties (B = 1024 at 640x480: BASELINE config 2)
 # ------------------------------------------------------------------------------------------
-def test_full_size_properties(la):
+def test_full_size_properties(la, engine):
     import torch
 
     torch.manual_seed(0)
@@ -403,10 +411,13 @@ def test_full_size_properties(la):
     # (1) deterministic: a second run is bit-identical
     boxes2, _, aux2 = la.fit_instances(depth, masks, K640)
     assert torch.equal(b1, boxes2) and torch.equal(a1, aux2)
-    # (2) permuting the instances permutes the records bit-exactly (no cross-instance state)
+    # (2) permuting the instances permutes the records (no cross-instance state).  The split engine cuts
+    #     the batch's tile list into equal per-wave ranges, so the grouping of the fp64 partial sums — not
+    #     the set of summands — depends on the order: equal to rounding, not bitwise.
     perm = torch.randperm(B, device="cuda")
     boxes3, _, _ = la.fit_instances(depth[perm].contiguous(), masks[perm].contiguous(), K640)
-    assert torch.equal(boxes3, b1[perm])
+    assert torch.allclose(boxes3[:, :15], b1[perm][:, :15], rtol=1e-11, atol=1e-11)
+    assert torch.allclose(boxes3[:, 15:], b1[perm][:, 15:], rtol=0, atol=2e-2)  # fp16-quantised corners
     # (3) doubling every depth doubles centers and dims exactly (power-of-two scaling commutes with
     #     every rounding on the path before the fp16 cast) and leaves R_cam untouched
     boxes4, _, _ = la.fit_instances(depth * 2, masks, K640)
