@@ -302,7 +302,8 @@ __global__ __launch_bounds__(NT, 8) void fit_instances_kernel(const FitParams p)
   // TILED only: compacted list of active tile ids
   unsigned short* list = reinterpret_cast<unsigned short*>(smem + p.mask_lds_bytes + sizeof(Shared));
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: lives in an SGPR
   const int inst = xcd_remap(blockIdx.x, p.B);
   const int img = p.image_index ? p.image_index[inst] : inst;
   const int HW = p.HW;
@@ -596,7 +597,8 @@ template <bool HULL>
 __global__ __launch_bounds__(NTP) void fit_points_kernel(const PtsParams p) {
   __shared__ SharedP sh;
   __shared__ HullStore<HULL> hstore;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: lives in an SGPR
   const int c = blockIdx.x;
   const long long off = p.offsets[c];
   const long long n_in = p.offsets[c + 1] - off;

@@ -82,7 +82,8 @@ __global__ __launch_bounds__(64) void geo_kernel(const FitParams p) {
 __global__ __launch_bounds__(SNT) void scan_kernel(const SplitParams sp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const FitParams& p = sp.f;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: lives in an SGPR
   const int band = blockIdx.x % sp.nband;
   const int inst = sp.b0 + blockIdx.x / sp.nband;
   const int W = p.W, H = p.H, ntx = p.ntx, nty = p.nty;
@@ -186,7 +187,8 @@ constexpr int PNT = 1024;
 __global__ __launch_bounds__(PNT) void plan_kernel(const SplitParams sp) {
   __shared__ int prefix[MAX_SEG + 1];
   __shared__ int wtot[PNT / 64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: lives in an SGPR
   const int nseg = sp.nb * sp.nband;
   const int* cnt = sp.tcount + (long long)sp.b0 * sp.nband;
   for (int i = tid; i < nseg; i += PNT) prefix[i] = cnt[i];
@@ -234,9 +236,10 @@ __global__ __launch_bounds__(PNT) void plan_kernel(const SplitParams sp) {
 // the balanced walk shared by moments (PASS 0) and extents (PASS 1)
 // ------------------------------------------------------------------------------------------
 template <int PASS>
-__global__ __launch_bounds__(SNT, 3) void walk_kernel(const SplitParams sp) {
+__global__ __launch_bounds__(SNT, 4) void walk_kernel(const SplitParams sp) {
   const FitParams& p = sp.f;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: lives in an SGPR
   const int gw = blockIdx.x * SNW + wave;
   const int nseg = sp.nb * sp.nband;
   const int* __restrict__ toff = sp.toff;
@@ -476,11 +479,11 @@ struct Layout {
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 int walk_waves(int nb) {
-  // grid of the walking kernels: the walker holds two batches in flight (~136 VGPRs -> 3 waves/SIMD), so
-  // 3 workgroups of 4 waves fill a CU; one resident round = 768 workgroups
-  int g = nb * 3;
-  if (g < 192) g = 192;
-  if (g > 768) g = 768;
+  // grid of the walking kernels: the walker holds two batches in flight (~105 VGPRs -> 4 waves/SIMD), so
+  // 4 workgroups of 4 waves fill a CU; one resident round = 1024 workgroups
+  int g = nb * 4;
+  if (g < 256) g = 256;
+  if (g > 1024) g = 1024;
   const char* e = getenv("LA3D_SPLIT_GRID");
   if (e && atoi(e) > 0) g = atoi(e);
   return g * SNW;

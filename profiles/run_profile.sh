@@ -1,18 +1,20 @@
 #!/bin/bash
 # Profiling recipe for the bench command (run on the GPU box through gpurun).
-#   profiles/run_profile.sh <tag>
-# Writes rocprofv3 outputs under gpurun_out/prof_<tag>/ ; the summaries that matter are copied to profiles/.
+#   profiles/run_profile.sh <tag> [extra bench args]
+# Writes rocprofv3 CSV outputs under gpurun_out/prof_<tag>/ and a condensed markdown summary
+# gpurun_out/profile_<tag>.md (copy the summaries that matter into profiles/).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r01}; shift || true
+EXTRA="$@"
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $REPO/bench.py --steps 50 --warmup 5 --no-cpu-baseline"
+BENCH="python $REPO/bench.py --steps 50 --warmup 5 --no-cpu-baseline $EXTRA"
 # 1) per-kernel time
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o stats -- $BENCH > $OUT/stats.log 2>&1
-# 2) HBM traffic counters, one pass each (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2)
+# 2) HBM traffic counters, one pass each (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2); never with sys/hip traces
 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- $BENCH > $OUT/fetch.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o write -- $BENCH > $OUT/write.log 2>&1
 # 3) shader-side counters
