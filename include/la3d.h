@@ -95,6 +95,32 @@ int la3d_fit_instances(const float* depth, int64_t depth_plane_stride, const int
                        int B, int H, int W, double* out, int32_t* status, double* aux,
                        void* workspace, void* stream);
 
+/* ---- mask ingestion: the data format immediately upstream of the path -------------------
+ * The reference decodes COCO / COCONut annotations to (H,W) bool arrays on the CPU with pycocotools
+ * (mask_utils.decode, src/util.py:367,401-402; encoder src/download_coconut.py:167-175) and filters instances by
+ * area / height / border truncation (src/util.py:291-335, :375).  Run lengths are over the (H,W) mask in
+ * COLUMN-major order, alternating zeros / ones, zeros first. */
+
+/* la3d_fit_instances with the masks given as run lengths: rle_counts dev i32 [total], rle_offsets dev i64 [B+1].
+ * The runs are decoded straight into the kernel's LDS bit image: no 1 B/px plane is ever materialised or read
+ * (H*W <= 1048576).  All other arguments as la3d_fit_instances. */
+int la3d_fit_instances_rle(const float* depth, int64_t depth_plane_stride, const int32_t* image_index,
+                           const int32_t* rle_counts, const int64_t* rle_offsets, const double* K, int32_t k_stride,
+                           const double* ground, const int32_t* sample_idx, int B, int H, int W,
+                           double* out, int32_t* status, double* aux, void* workspace, void* stream);
+
+/* mask_utils.decode for a batch: run lengths -> u8 planes mask_out dev [B][H*W] (0/1), H*W <= 1048576. */
+int la3d_rle_decode(const int32_t* counts, const int64_t* offsets, int B, int H, int W, uint8_t* mask_out, void* stream);
+
+/* Per mask plane (dev u8 [B][H*W]) the quantities of the reference's instance filter: stats dev i32 [B][4] =
+ * area, rows holding a pixel (the RLE branch's height, :368-369), last-first+1 rows (get_maximum_height, :328-335),
+ * pixels inside the four `boundary`-px border strips with corners counted twice (analyze_mask, :303-322). */
+int la3d_mask_stats(const uint8_t* mask, int B, int H, int W, int boundary, int32_t* stats, void* stream);
+
+/* HOST helper: COCO compressed RLE string (pycocotools rleFrString) -> run lengths.  Returns the number of
+ * counts written, or -1 (malformed string / cap too small). */
+int la3d_rle_from_string_host(const char* s, int64_t len, int32_t* counts, int cap);
+
 /* Replaces estimate_bbox(in_pc, cat_name, ground_equ, method) for B point clouds at once —
  * reference src/util_3dbox.py:106-178 (caller :273-278, 500 mesh samples per object).
  * points   dev f64 [total][3];  offsets dev i64 [B+1] (cloud n = rows offsets[n]..offsets[n+1])

@@ -19,5 +19,7 @@ from .batched import (  # noqa: F401
     unpack_boxes,
 )
 
-__all__ = ["fit_instances", "fit_points", "mask_counts", "unproject", "draw_sample_idx", "unpack_boxes",
+from .masks import fit_instances_rle, keep_instances, mask_stats, pack_rle, rle_decode, rle_from_string  # noqa: E402,F401
+
+__all__ = ["fit_instances_rle", "rle_decode", "mask_stats", "keep_instances", "pack_rle", "rle_from_string","fit_instances", "fit_points", "mask_counts", "unproject", "draw_sample_idx", "unpack_boxes",
            "InstanceFitter", "La3dError", "REC", "AUX", "NSAMPLE"]

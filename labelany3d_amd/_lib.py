@@ -25,6 +25,12 @@ _SIGS = {
     "la3d_fit_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "la3d_f16_round_host": (C.c_double, [C.c_double]),
+    "la3d_fit_instances_rle": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                         C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]),
+    "la3d_rle_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "la3d_mask_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "la3d_rle_from_string_host": (C.c_int, [C.c_char_p, C.c_int64, C.POINTER(C.c_int32), C.c_int]),
 }
 
 EXPORTS = tuple(_SIGS)

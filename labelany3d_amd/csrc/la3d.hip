@@ -308,7 +308,7 @@ __global__ __launch_bounds__(NT, 8) void fit_instances_kernel(const FitParams p)
   const int img = p.image_index ? p.image_index[inst] : inst;
   const int HW = p.HW;
   const float* dpl = p.depth + (long long)img * p.depth_plane_stride;
-  const unsigned char* mpl = p.mask + (long long)inst * HW;
+  const unsigned char* mpl = p.mask ? p.mask + (long long)inst * HW : nullptr;
 
   const double* geo = p.geo + (long long)inst * GEO_D;  // uniform address -> scalar loads
   const double* Rgg = geo + 9;
@@ -320,7 +320,11 @@ __global__ __launch_bounds__(NT, 8) void fit_instances_kernel(const FitParams p)
 
   // ---- phase 0: u8 mask plane -> bit image in LDS --------------------------------------
   int nmask = 0;
-  if (LDSMASK) {
+  if (LDSMASK && p.rle_counts != nullptr) {
+    // masks arrive as COCO run lengths: decode straight into the LDS bit image — no u8 plane is ever read
+    const long long o0 = p.rle_offsets[inst];
+    nmask = rle_to_bits<NT>(p.rle_counts + o0, (int)(p.rle_offsets[inst + 1] - o0), bits, p.nwords, p.H, p.W, sh->scan, tid);
+  } else if (LDSMASK) {
     unsigned short* b16 = reinterpret_cast<unsigned short*>(bits);
     const int ngroups = (HW + 15) >> 4;
     if (VEC) {
@@ -792,6 +796,69 @@ __global__ __launch_bounds__(256) void mask_counts_kernel(const unsigned char* _
   if (threadIdx.x == 0) counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
+// mask_utils.decode for a batch (reference src/util.py:367,401-402): run lengths -> u8 planes.  The runs are
+// painted into an LDS bit image (rle_to_bits) and expanded with coalesced 16-byte stores.
+__global__ __launch_bounds__(256) void rle_decode_kernel(const int* __restrict__ counts, const long long* __restrict__ offsets,
+                                                         int H, int W, int nwords, unsigned char* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned* bits = reinterpret_cast<unsigned*>(smem);
+  unsigned* wtot = bits + nwords;
+  const int tid = threadIdx.x;
+  const long long o0 = offsets[blockIdx.x];
+  (void)rle_to_bits<256>(counts + o0, (int)(offsets[blockIdx.x + 1] - o0), bits, nwords, H, W, wtot, tid);
+  const int HW = H * W;
+  unsigned char* o = out + (long long)blockIdx.x * HW;
+  const unsigned short* b16 = reinterpret_cast<const unsigned short*>(bits);
+  if (HW % 16 == 0 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+    for (int g = tid; g < HW / 16; g += 256) {
+      const unsigned pat = b16[g];
+      uint4 v;
+      v.x = ((pat >> 0) & 1u) | (((pat >> 1) & 1u) << 8) | (((pat >> 2) & 1u) << 16) | (((pat >> 3) & 1u) << 24);
+      v.y = ((pat >> 4) & 1u) | (((pat >> 5) & 1u) << 8) | (((pat >> 6) & 1u) << 16) | (((pat >> 7) & 1u) << 24);
+      v.z = ((pat >> 8) & 1u) | (((pat >> 9) & 1u) << 8) | (((pat >> 10) & 1u) << 16) | (((pat >> 11) & 1u) << 24);
+      v.w = ((pat >> 12) & 1u) | (((pat >> 13) & 1u) << 8) | (((pat >> 14) & 1u) << 16) | (((pat >> 15) & 1u) << 24);
+      *reinterpret_cast<uint4*>(o + g * 16) = v;
+    }
+  } else {
+    for (int i = tid; i < HW; i += 256) o[i] = (bits[i >> 5] >> (i & 31)) & 1u;
+  }
+}
+
+// The quantities of the reference's instance filter (src/util.py:291-335, :367-376) per mask plane:
+// stats[0] = area, [1] = rows holding a pixel, [2] = last row - first row + 1, [3] = pixels inside the four
+// boundary strips of `boundary` px (corners counted twice, as analyze_mask does).
+__global__ __launch_bounds__(256) void mask_stats_kernel(const unsigned char* __restrict__ mask, int H, int W, int boundary,
+                                                         int* __restrict__ stats) {
+  __shared__ int red[4][4];
+  const unsigned char* m = mask + (long long)blockIdx.x * H * W;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int area = 0, rows = 0, first = H, last = -1, trunc = 0;
+  for (int r = wave; r < H; r += 4) {  // one wave per row
+    int cnt = 0, edge = 0;
+    for (int c = lane; c < W; c += 64) {
+      const int on = m[(long long)r * W + c] ? 1 : 0;
+      cnt += on;
+      if (on) edge += (c < boundary ? 1 : 0) + (c >= W - boundary ? 1 : 0);
+    }
+    cnt = wave_sum_i(cnt);
+    edge = wave_sum_i(edge);
+    area += cnt;
+    trunc += edge;
+    if (r < boundary || r >= H - boundary) trunc += (r < boundary && r >= H - boundary) ? 2 * cnt : cnt;
+    if (cnt) { rows += 1; first = min(first, r); last = max(last, r); }
+  }
+  if (lane == 0) { red[wave][0] = area; red[wave][1] = rows; red[wave][2] = first; red[wave][3] = last; }
+  __shared__ int tr[4];
+  if (lane == 0) tr[wave] = trunc;
+  __syncthreads();
+  if (tid == 0) {
+    int a = 0, rw = 0, f = H, l = -1, t = 0;
+    for (int w = 0; w < 4; ++w) { a += red[w][0]; rw += red[w][1]; f = min(f, red[w][2]); l = max(l, red[w][3]); t += tr[w]; }
+    int* o = stats + (long long)blockIdx.x * 4;
+    o[0] = a; o[1] = rw; o[2] = (l >= f) ? l - f + 1 : 0; o[3] = t;
+  }
+}
+
 // host-side 3x3 inverse (same elimination as inv3 above)
 void inv3_host(const double* A, double* X) {
   double a[3][6];
@@ -880,24 +947,26 @@ int la3d_mask_counts(const uint8_t* mask, int B, int H, int W, int32_t* counts, 
   return check_launch("mask_counts_kernel");
 }
 
-int la3d_fit_instances(const float* depth, int64_t depth_plane_stride, const int32_t* image_index,
-                       const uint8_t* mask, const double* K, int32_t k_stride, const double* ground,
-                       const int32_t* sample_idx, int B, int H, int W, double* out, int32_t* status, double* aux,
-                       void* workspace, void* stream) {
-  if (!depth || !mask || !K || !out || !status || B < 0 || H <= 0 || W <= 0 || depth_plane_stride < 0 ||
-      (k_stride != 0 && k_stride < 9) || (long long)H * W > (1LL << 28)) {
-    set_err("la3d_fit_instances: bad argument");
+static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const int32_t* image_index, const uint8_t* mask,
+                        const int32_t* rle_counts, const int64_t* rle_offsets, const double* K, int32_t k_stride,
+                        const double* ground, const int32_t* sample_idx, int B, int H, int W, double* out,
+                        int32_t* status, double* aux, void* workspace, void* stream, const char* who) {
+  const bool rle = rle_counts != nullptr;
+  if (!depth || (!mask && !rle) || (rle && !rle_offsets) || !K || !out || !status || B < 0 || H <= 0 || W <= 0 ||
+      depth_plane_stride < 0 || (k_stride != 0 && k_stride < 9) || (long long)H * W > (1LL << 28)) {
+    snprintf(g_err, sizeof(g_err), "%s: bad argument", who);
     return LA3D_ERR_ARG;
   }
   if (B == 0) return LA3D_SUCCESS;
   if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 7)) {
-    set_err("la3d_fit_instances: workspace of la3d_workspace_bytes() bytes (8-aligned) required");
+    snprintf(g_err, sizeof(g_err), "%s: workspace of la3d_workspace_bytes() bytes (8-aligned) required", who);
     return LA3D_ERR_ARG;
   }
   FitParams p;
   p.geo = static_cast<double*>(workspace);
   p.depth = depth; p.depth_plane_stride = depth_plane_stride; p.image_index = image_index;
   p.mask = mask; p.K = K; p.k_stride = k_stride; p.ground = ground; p.sample_idx = sample_idx;
+  p.rle_counts = rle_counts; p.rle_offsets = reinterpret_cast<const long long*>(rle_offsets);
   p.B = B; p.H = H; p.W = W; p.HW = H * W;
   p.nwords = (p.HW + 31) / 32;
   p.rows_aligned = (W % 4 == 0);
@@ -907,23 +976,27 @@ int la3d_fit_instances(const float* depth, int64_t depth_plane_stride, const int
   const int bit_bytes = ((((p.HW + 15) / 16 + 1) / 2) * 4 + 15) & ~15;  // u16 per 16 px, padded to u32, 16-aligned
   const bool ldsmask = bit_bytes <= MAX_MASK_LDS;
   p.mask_lds_bytes = ldsmask ? bit_bytes : 0;
-  // 16-byte vector path: every plane base 16-aligned
-  const bool vec = (p.HW % 16 == 0) && ((reinterpret_cast<uintptr_t>(mask) & 15) == 0) &&
+  if (rle && !ldsmask) {
+    snprintf(g_err, sizeof(g_err), "%s: run-length masks need the bit image in LDS (H*W <= 1048576)", who);
+    return LA3D_ERR_UNSUPPORTED;
+  }
+  // 16-byte vector path: every plane base 16-aligned (the u8 mask only when it is read at all)
+  const bool vec = (p.HW % 16 == 0) && (rle || (reinterpret_cast<uintptr_t>(mask) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(depth) & 15) == 0) && (depth_plane_stride % 4 == 0);
   const bool sample = sample_idx != nullptr;
   size_t lds = (size_t)p.mask_lds_bytes + sizeof(Shared);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (split_eligible(p, vec, ldsmask)) return split_fit(p, workspace, s);
+  if (!rle && split_eligible(p, vec, ldsmask)) return split_fit(p, workspace, s);
   hipLaunchKernelGGL(prep_kernel, dim3((B + 63) / 64), dim3(64), 0, s, p);
   if (int rc = check_launch("prep_kernel")) return rc;
   if (sample) {
     if (!ldsmask) {
-      set_err("la3d_fit_instances: reference-subsample mode needs the bit image in LDS (H*W <= 1048576)");
+      snprintf(g_err, sizeof(g_err), "%s: reference-subsample mode needs the bit image in LDS (H*W <= 1048576)", who);
       return LA3D_ERR_UNSUPPORTED;
     }
     lds += (size_t)p.nwords * 4 + 16;
     if (lds > 160 * 1024 - 256) {
-      set_err("la3d_fit_instances: reference-subsample mode: frame too large for LDS");
+      snprintf(g_err, sizeof(g_err), "%s: reference-subsample mode: frame too large for LDS", who);
       return LA3D_ERR_UNSUPPORTED;
     }
     return vec ? launch_fit<true, true, true>(p, lds, s) : launch_fit<false, true, true>(p, lds, s);
@@ -950,6 +1023,80 @@ int la3d_fit_instances(const float* depth, int64_t depth_plane_stride, const int
   }
   if (ldsmask) return vec ? launch_fit<true, true, false>(p, lds, s) : launch_fit<false, true, false>(p, lds, s);
   return vec ? launch_fit<true, false, false>(p, lds, s) : launch_fit<false, false, false>(p, lds, s);
+}
+
+int la3d_fit_instances(const float* depth, int64_t depth_plane_stride, const int32_t* image_index,
+                       const uint8_t* mask, const double* K, int32_t k_stride, const double* ground,
+                       const int32_t* sample_idx, int B, int H, int W, double* out, int32_t* status, double* aux,
+                       void* workspace, void* stream) {
+  return fit_dispatch(depth, depth_plane_stride, image_index, mask, nullptr, nullptr, K, k_stride, ground, sample_idx, B, H,
+                      W, out, status, aux, workspace, stream, "la3d_fit_instances");
+}
+
+int la3d_fit_instances_rle(const float* depth, int64_t depth_plane_stride, const int32_t* image_index,
+                           const int32_t* rle_counts, const int64_t* rle_offsets, const double* K, int32_t k_stride,
+                           const double* ground, const int32_t* sample_idx, int B, int H, int W, double* out,
+                           int32_t* status, double* aux, void* workspace, void* stream) {
+  if (!rle_counts && B > 0) {
+    set_err("la3d_fit_instances_rle: bad argument");
+    return LA3D_ERR_ARG;
+  }
+  return fit_dispatch(depth, depth_plane_stride, image_index, nullptr, rle_counts, rle_offsets, K, k_stride, ground,
+                      sample_idx, B, H, W, out, status, aux, workspace, stream, "la3d_fit_instances_rle");
+}
+
+int la3d_rle_from_string_host(const char* s, int64_t len, int32_t* counts, int cap) {
+  // pycocotools rleFrString (maskApi.c): 5-bit groups, char - 48, bit 5 = continuation, bit 4 of the last
+  // group = sign; counts beyond the third are stored as a difference to the count two places earlier
+  if (!s || len < 0 || (!counts && cap > 0)) return -1;
+  int m = 0;
+  int64_t pz = 0;
+  while (pz < len && s[pz]) {
+    long x = 0;
+    int k = 0, more = 1;
+    while (more) {
+      if (pz >= len) return -1;
+      const int c = s[pz] - 48;
+      x |= (long)(c & 0x1f) << (5 * k);
+      more = c & 0x20;
+      ++pz; ++k;
+      if (!more && (c & 0x10)) x |= -1L << (5 * k);
+    }
+    if (m > 2) x += counts[m - 2];
+    if (m >= cap) return -1;
+    counts[m++] = (int32_t)x;
+  }
+  return m;
+}
+
+int la3d_rle_decode(const int32_t* counts, const int64_t* offsets, int B, int H, int W, uint8_t* mask_out, void* stream) {
+  if ((!counts && B > 0) || !offsets || !mask_out || B < 0 || H <= 0 || W <= 0 || (long long)H * W > (1LL << 20)) {
+    set_err("la3d_rle_decode: bad argument (H*W <= 1048576)");
+    return LA3D_ERR_ARG;
+  }
+  if (B == 0) return LA3D_SUCCESS;
+  const int nwords = (H * W + 31) / 32;
+  const size_t lds = (size_t)nwords * 4 + 64;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(rle_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      (void)hipGetLastError();
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(rle_decode_kernel, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), counts,
+                     reinterpret_cast<const long long*>(offsets), H, W, nwords, mask_out);
+  return check_launch("rle_decode_kernel");
+}
+
+int la3d_mask_stats(const uint8_t* mask, int B, int H, int W, int boundary, int32_t* stats, void* stream) {
+  if (!mask || !stats || B < 0 || H <= 0 || W <= 0 || boundary < 0) {
+    set_err("la3d_mask_stats: bad argument");
+    return LA3D_ERR_ARG;
+  }
+  if (B == 0) return LA3D_SUCCESS;
+  hipLaunchKernelGGL(mask_stats_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), mask, H, W, boundary, stats);
+  return check_launch("mask_stats_kernel");
 }
 
 int la3d_fit_points(const double* points, const int64_t* offsets, const double* ground, const int32_t* sample_idx,

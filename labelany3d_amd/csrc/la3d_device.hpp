@@ -285,6 +285,8 @@ struct FitParams {
   int rows_aligned;    // W % 4 == 0: a 4-pixel quad never straddles a row
   float rcpW;
   double* geo;         // workspace: [B][GEO_D]
+  const int* rle_counts;        // masks given as COCO run lengths (column-major, zeros first) instead of u8 planes
+  const long long* rle_offsets; // [B+1] into rle_counts
   int ntx, nty;        // TILED: tiles of 32 px x 8 rows (ntx = W/32, nty = ceil(H/8))
   int tiles_per_wave;  // TILED: ceil(ntx*nty / NWAVE)
   int list_cap;        // TILED: entries of the active-tile list that fit the LDS budget
@@ -343,6 +345,61 @@ __device__ inline void quad_math(unsigned nib, const unsigned* db, double r0, do
   }
 }
 
+
+// COCO run lengths -> row-major 1-bit-per-pixel image in LDS (the decode step of pycocotools' rleDecode,
+// called by the reference at src/util.py:367,401-402).  Runs are over the (H, W) mask in COLUMN-major order,
+// alternating zeros / ones, zeros first.  NTH threads take NTH runs per step: a workgroup scan of the run
+// lengths gives every run its start; then each wave paints the ones-runs of its own 64 lanes one after the
+// other (start / length broadcast by shuffle; lanes = consecutive pixels of the run = consecutive rows =
+// distinct words of the row-major image).  wtot: LDS, NTH/64 words.  Returns (per thread) the number of
+// mask pixels it accounted for; bits must hold ceil(H*W/32) words and is zeroed here.
+template <int NTH>
+__device__ inline int rle_to_bits(const int* __restrict__ counts, int nr, unsigned* bits, int nwords, int H, int W,
+                                  unsigned* wtot, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = NTH / 64;
+  const int HW = H * W;
+  const float rcpH = 1.0f / (float)H;
+  for (int i = tid; i < nwords; i += NTH) bits[i] = 0;
+  unsigned carry = 0;
+  int nm = 0;
+  for (int c0 = 0; c0 < nr; c0 += NTH) {
+    const int j = c0 + tid;
+    unsigned len = 0;
+    if (j < nr) { const int v = counts[j]; len = v > 0 ? (unsigned)v : 0u; }
+    unsigned incl = len;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    __syncthreads();                       // previous step's readers of wtot are done; bits zeroing is ordered
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    unsigned base = carry, total = 0;
+    for (int w = 0; w < NW; ++w) { if (w < wave) base += wtot[w]; total += wtot[w]; }
+    const unsigned start = base + incl - len;
+    unsigned L = 0;
+    if ((j & 1) && len > 0 && start < (unsigned)HW) L = min(len, (unsigned)HW - start);
+    nm += (int)L;
+    carry += total;
+    unsigned long long todo = __ballot(L != 0);
+    while (todo) {                         // wave-uniform loop over this wave's ones-runs
+      const int src = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const unsigned S = __shfl(start, src), Lr = __shfl(L, src);
+      for (unsigned q = lane; q < Lr; q += 64) {
+        unsigned col, row;
+        pix_uv(S + q, H, rcpH, &row, &col);   // position = col * H + row
+        const unsigned idx = row * (unsigned)W + col;
+        atomicOr(&bits[idx >> 5], 1u << (idx & 31));
+      }
+    }
+    if (carry >= (unsigned)HW) break;      // the frame is full: later runs fall outside it (uniform)
+  }
+  __syncthreads();
+  return nm;
+}
 
 inline int check_launch(const char* what) {
   const hipError_t e = hipGetLastError();

@@ -397,3 +397,99 @@ def cam_orbit_camera(elevation, azimuth, radius=1, is_degree=True, target=None, 
     T[:3, :3] = cam_look_at(campos, target, opengl)
     T[:3, 3] = campos
     return T
+
+
+# --------------------------------------------------------------------------------------
+# §8f-1  mask ingestion: COCO run-length masks and the reference's instance filters
+# --------------------------------------------------------------------------------------
+# Third-party piece: pycocotools (COCO API, `mask_utils.decode / frPyObjects`, called at reference
+# src/util.py:367,401-402; absent from /root/reference and from this image).  Its published format:
+# `counts` are run lengths over the (h, w) mask in COLUMN-MAJOR order, alternating zeros / ones and
+# starting with zeros; the compressed string form stores each count in 5-bit groups (char - 48, bit 5 =
+# continuation, bit 4 of the last group = sign) with counts beyond the third stored as a difference to
+# the count two places earlier (maskApi.c rleToString / rleFrString).  The reference's own encoder,
+# binary_mask_to_rle (src/download_coconut.py:167-175), produces the uncompressed list form and is the
+# pinning call site: tests/golden/g8_masks.npz holds its outputs.
+def rle_encode(mask):
+    """src/download_coconut.py:167-175 — uncompressed RLE {'counts', 'size'} of a binary mask."""
+    m = np.asarray(mask).astype(bool)
+    flat = m.ravel(order="F")
+    if flat.size == 0:
+        return {"counts": [], "size": list(m.shape)}
+    change = np.flatnonzero(flat[1:] != flat[:-1]) + 1
+    bounds = np.concatenate([[0], change, [flat.size]])
+    counts = np.diff(bounds).tolist()
+    if flat[0]:
+        counts = [0] + counts
+    return {"counts": counts, "size": list(m.shape)}
+
+
+def rle_decode(counts, h, w):
+    """pycocotools rleDecode: column-major runs -> (h, w) bool."""
+    counts = np.asarray(counts, dtype=np.int64)
+    vals = (np.arange(len(counts)) & 1).astype(bool)
+    flat = np.repeat(vals, counts)[: h * w]
+    if flat.size < h * w:
+        flat = np.concatenate([flat, np.zeros(h * w - flat.size, bool)])
+    return flat.reshape((w, h)).T.copy()
+
+
+def rle_to_string(counts):
+    """pycocotools rleToString (maskApi.c) — compressed ASCII form of the counts."""
+    out = bytearray()
+    for i, c in enumerate(counts):
+        x = int(c)
+        if i > 2:
+            x -= int(counts[i - 2])
+        more = True
+        while more:
+            ch = x & 0x1F
+            x >>= 5
+            more = (x != -1) if (ch & 0x10) else (x != 0)
+            if more:
+                ch |= 0x20
+            out.append(ch + 48)
+    return bytes(out)
+
+
+def rle_from_string(s):
+    """pycocotools rleFrString (maskApi.c)."""
+    if isinstance(s, str):
+        s = s.encode("ascii")
+    counts, p = [], 0
+    while p < len(s):
+        x, k, more = 0, 0, True
+        while more:
+            c = s[p] - 48
+            x |= (c & 0x1F) << (5 * k)
+            more = bool(c & 0x20)
+            p += 1
+            k += 1
+            if not more and (c & 0x10):
+                x |= -1 << (5 * k)
+        if len(counts) > 2:
+            x += counts[-2]
+        counts.append(x)
+    return counts
+
+
+def mask_stats(mask, boundary_threshold=10):
+    """The quantities the reference's instance filter looks at (src/util.py:291-335, :367-376):
+    area = mask.sum(); rows = number of rows holding a pixel (the RLE branch's `height`, :368-369);
+    span = last row - first row + 1 (get_maximum_height, the polygon branch's height, :328-335);
+    trunc = pixels inside the four boundary strips of `boundary_threshold` px, corners counted twice
+    (analyze_mask :303-322)."""
+    m = np.asarray(mask).astype(bool)
+    rows_any = m.any(axis=1)
+    idx = np.flatnonzero(rows_any)
+    span = int(idx[-1] - idx[0] + 1) if idx.size else 0
+    b = boundary_threshold
+    trunc = int(m[:b].sum() + m[-b:].sum() + m[:, :b].sum() + m[:, -b:].sum())
+    return int(m.sum()), int(rows_any.sum()), span, trunc
+
+
+def keep_instance(stats, image_height, from_rle, scale_threshold=100):
+    """src/util.py:375 — height/H > 0.0625 and not truncated (trunc < 10) and area >= 100."""
+    area, rows, span, trunc = stats
+    height = rows if from_rle else span
+    return (height / image_height > 0.0625) and not (trunc >= 10) and (area >= scale_threshold)

@@ -140,3 +140,25 @@ def test_draw_sample_idx_consumes_global_stream_like_reference():
     np.testing.assert_array_equal(idx[2], b)
     np.testing.assert_array_equal(idx[4], c)
     assert (idx[1] == 0).all() and (idx[3] == 0).all()
+
+
+def test_rle_string_host_helper_matches_oracle(golden):
+    """la3d_rle_from_string_host (pycocotools rleFrString restated in C) against the oracle's codec on the
+    reference encoder's outputs."""
+    from labelany3d_amd import pack_rle, rle_from_string
+    from oracle import la3d_oracle as O
+
+    g = golden("g8_masks.npz")
+    offs = np.concatenate([[0], np.cumsum(g["lens"])])
+    rles = []
+    for i in range(len(g["lens"])):
+        counts = g["counts"][offs[i]:offs[i + 1]].tolist()
+        s = O.rle_to_string(counts)
+        np.testing.assert_array_equal(rle_from_string(s), counts)
+        rles.append({"size": [48, 64], "counts": s if i % 2 else counts})   # mixed list / string forms
+    c, o, H, W = pack_rle(rles)
+    assert (H, W) == (48, 64)
+    np.testing.assert_array_equal(o, offs)
+    np.testing.assert_array_equal(c, g["counts"])
+    with pytest.raises(ValueError):
+        rle_from_string(b"P")              # 0x50 - 48 has the continuation bit set, then the string ends

@@ -1,0 +1,115 @@
+"""GPU tests of the mask-ingestion row: run-length decode, instance filters, and the box fit
+fed with run lengths — against the oracle and the reference's own encoder / filter outputs (g8_masks.npz)."""
+import numpy as np
+import pytest
+
+from oracle import la3d_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def la():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import labelany3d_amd
+
+    return labelany3d_amd
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def _g8_rles(g):
+    offs = np.concatenate([[0], np.cumsum(g["lens"])])
+    return [{"size": [48, 64], "counts": g["counts"][offs[i]:offs[i + 1]].tolist()} for i in range(len(g["lens"]))]
+
+
+def test_rle_decode_and_filters_vs_reference(la, golden):
+    g = golden("g8_masks.npz")
+    rles = _g8_rles(g)
+    masks = la.rle_decode(rles)
+    assert masks.dtype.is_floating_point is False and tuple(masks.shape) == g["masks"].shape
+    np.testing.assert_array_equal(np_(masks), g["masks"].astype(bool))       # inverts the reference's encoder
+    st = np_(la.mask_stats(masks))
+    ref = g["ref_stats"]
+    np.testing.assert_array_equal(st[:, :3], ref[:, :3])                       # area, rows, get_maximum_height
+    np.testing.assert_array_equal(st[:, 3] >= 10, ref[:, 3].astype(bool))      # analyze_mask: is_truncated
+    np.testing.assert_array_equal(st[:, 0] >= 100, ref[:, 4].astype(bool))     # analyze_mask: is_scaleable
+    for from_rle in (True, False):
+        keep = np_(la.keep_instances(la.mask_stats(masks), 48, from_rle))
+        want = [O.keep_instance(O.mask_stats(m), 48, from_rle) for m in g["masks"]]
+        np.testing.assert_array_equal(keep, want)
+    # same stats straight from uint8 planes with arbitrary non-zero values
+    st2 = np_(la.mask_stats((g["masks"] * 255).astype(np.uint8)))
+    np.testing.assert_array_equal(st2, st)
+
+
+@pytest.mark.parametrize("H,W", [(480, 640), (37, 53), (64, 96)])
+def test_rle_decode_random_masks(la, H, W):
+    rs = np.random.RandomState(H + W)
+    masks = np.zeros((9, H, W), bool)
+    for i in range(5):
+        h, w = rs.randint(1, H + 1), rs.randint(1, W + 1)
+        r0, c0 = rs.randint(0, H - h + 1), rs.randint(0, W - w + 1)
+        masks[i, r0:r0 + h, c0:c0 + w] = True
+    masks[5] = rs.rand(H, W) < 0.5          # ~H*W/2 runs: many scan steps
+    masks[6] = True                          # one run covering the frame
+    masks[7] = False
+    masks[8, :, W // 2] = True
+    rles = [O.rle_encode(m) for m in masks]
+    rles[3]["counts"] = O.rle_to_string(rles[3]["counts"])      # compressed-string form
+    out = la.rle_decode(rles)
+    np.testing.assert_array_equal(np_(out), masks)
+    want = np.array([O.mask_stats(m) for m in masks])
+    np.testing.assert_array_equal(np_(la.mask_stats(out)), want)
+
+
+def test_fit_from_rle_equals_fit_from_planes(la):
+    """The composed path fed with run lengths gives the same boxes as fed with the decoded u8 planes."""
+    rs = np.random.RandomState(77)
+    B, H, W = 24, 480, 640
+    K = np.array([[500.0, 0, 320], [0, 500.0, 240], [0, 0, 1]])
+    depth = rs.uniform(0.5, 10, (B, H, W)).astype(np.float32)
+    masks = np.zeros((B, H, W), bool)
+    for i in range(B - 3):
+        h, w = rs.randint(8, 301), rs.randint(8, 331)
+        r0, c0 = rs.randint(0, H - h + 1), rs.randint(0, W - w + 1)
+        masks[i, r0:r0 + h, c0:c0 + w] = True
+    vv, uu = np.mgrid[0:H, 0:W]
+    masks[B - 3] = ((uu - 300) ** 2 / 9000.0 + (vv - 200) ** 2 / 4000.0) < 1.0
+    masks[B - 2] = rs.rand(H, W) < 0.02
+    # masks[B-1] stays empty
+    ground = np.array([[0.02, -0.98, 0.1, 1.5]] * B) + 0.03 * rs.randn(B, 4)
+    rles = [O.rle_encode(m) for m in masks]
+    b_r, s_r, a_r = la.fit_instances_rle(depth, rles, K, ground=ground)
+    ref = [O.fit_instance(depth[i], masks[i], K, ground[i]) for i in range(B)]
+    assert np_(s_r).tolist() == [r[1] for r in ref]
+    got = np_(b_r)
+    for i, (rec, st, aux) in enumerate(ref):
+        if st:
+            assert np.isnan(got[i]).all()
+            continue
+        np.testing.assert_allclose(got[i, :15], rec[:15], rtol=0, atol=1e-9 * max(1, np.abs(rec[:6]).max()))
+        np.testing.assert_allclose(got[i, 15:], rec[15:], rtol=0, atol=max(np.abs(rec[15:]).max(), 1) * 2.0 ** -10)
+    np.testing.assert_array_equal(np_(a_r)[:, 2], masks.reshape(B, -1).sum(1))
+    # bit-identical to the u8-plane entry point of the same engine
+    import os
+    os.environ["LA3D_ENGINE"] = "instance"
+    try:
+        b_p, s_p, a_p = la.fit_instances(depth, masks, K, ground=ground)
+    finally:
+        del os.environ["LA3D_ENGINE"]
+    assert np.array_equal(np_(b_p), got, equal_nan=True) and np.array_equal(np_(s_p), np_(s_r))
+    # reference-subsample mode through the RLE entry point
+    counts = masks.reshape(B, -1).sum(1)
+    np.random.seed(3)
+    idx = la.draw_sample_idx(counts)
+    b_s, s_s, _ = la.fit_instances_rle(depth, rles, K, ground=ground, sample_idx=idx)
+    ref_s, st_s, _, _ = O.fit_instances(depth, masks, K[None].repeat(B, 0), ground=ground, sample_idx=idx)
+    assert np_(s_s).tolist() == st_s.tolist()
+    ok = st_s == 0
+    np.testing.assert_allclose(np_(b_s)[ok][:, :15], ref_s[ok][:, :15], rtol=0, atol=1e-8)
