@@ -388,11 +388,21 @@ __device__ inline int rle_to_bits(const int* __restrict__ counts, int nr, unsign
       const int src = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
       const unsigned S = __shfl(start, src), Lr = __shfl(L, src);
-      for (unsigned q = lane; q < Lr; q += 64) {
-        unsigned col, row;
-        pix_uv(S + q, H, rcpH, &row, &col);   // position = col * H + row
-        const unsigned idx = row * (unsigned)W + col;
-        atomicOr(&bits[idx >> 5], 1u << (idx & 31));
+      unsigned col0, row0;
+      pix_uv(S, H, rcpH, &row0, &col0);     // run start: position = col0 * H + row0 (same in every lane)
+      if (row0 + Lr <= (unsigned)H) {       // the run stays inside one column (the common case): row0+q, col0
+        const unsigned base = row0 * (unsigned)W + col0;
+        for (unsigned q = lane; q < Lr; q += 64) {
+          const unsigned idx = base + q * (unsigned)W;
+          atomicOr(&bits[idx >> 5], 1u << (idx & 31));
+        }
+      } else {                              // wraps into following columns
+        for (unsigned q = lane; q < Lr; q += 64) {
+          unsigned col, row;
+          pix_uv(S + q, H, rcpH, &row, &col);
+          const unsigned idx = row * (unsigned)W + col;
+          atomicOr(&bits[idx >> 5], 1u << (idx & 31));
+        }
       }
     }
     if (carry >= (unsigned)HW) break;      // the frame is full: later runs fall outside it (uniform)
