@@ -121,6 +121,19 @@ int la3d_mask_stats(const uint8_t* mask, int B, int H, int W, int boundary, int3
  * counts written, or -1 (malformed string / cap too small). */
 int la3d_rle_from_string_host(const char* s, int64_t len, int32_t* counts, int cap);
 
+/* ---- box consumers: the step immediately downstream of the path ----------------------------
+ * Reference src/tools/combine_results.py: the 8 corners of each record are projected with the image's K
+ * (project_to_2d, :105-108), bbox2D_proj = [min_x, min_y, max_x, max_y] and bbox2D_trunc = its clamp to
+ * [0,width] x [0,height] (:238-252).  records dev f64 [B][39] (as written by the fit calls), K dev f64 (9 per
+ * image, k_stride 0 = shared), image_index dev i32 [B] | NULL; out dev f64 [B][8] = proj(4), trunc(4); a box with a
+ * NaN projection gives 8 NaNs. */
+int la3d_project_boxes(const double* records, const double* K, int32_t k_stride, const int32_t* image_index, int B,
+                       double width, double height, double* out, void* stream);
+
+/* iou2D (:111-124) of every pair of xyxy boxes: a dev f64 [na][4], b dev f64 [nb][4] -> out dev f64 [na][nb]
+ * (negated = the Hungarian cost matrix of :131-135). */
+int la3d_iou_matrix(const double* boxes_a, int na, const double* boxes_b, int nb, double* out, void* stream);
+
 /* Replaces estimate_bbox(in_pc, cat_name, ground_equ, method) for B point clouds at once —
  * reference src/util_3dbox.py:106-178 (caller :273-278, 500 mesh samples per object).
  * points   dev f64 [total][3];  offsets dev i64 [B+1] (cloud n = rows offsets[n]..offsets[n+1])

@@ -1,0 +1,50 @@
+"""Box consumers on the device: what the reference does with the fitted boxes right after the
+path (src/tools/combine_results.py) — project the 8 corners with K, take the 2-D box and its clamp to the frame,
+and build the IoU matrix the Hungarian matching consumes.  The assignment itself stays scipy
+(`linear_sum_assignment`, as in the reference :138): it is a tiny sequential problem per image."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from ._lib import check, lib
+from .batched import _as_dev, _dev, _ptr, _stream
+
+
+def project_boxes(boxes, K, image_size, image_index=None, stream=None) -> torch.Tensor:
+    """boxes (B,39) records -> (B,8) = bbox2D_proj [min_x,min_y,max_x,max_y] + bbox2D_trunc (clamped to
+    [0,W]x[0,H]); image_size = (W, H) as in the reference (:233-252).  K (3,3) or (P,3,3) with image_index."""
+    dev = boxes.device if isinstance(boxes, torch.Tensor) and boxes.is_cuda else _dev()
+    b = _as_dev(boxes, torch.float64, dev)
+    k = _as_dev(K, torch.float64, dev)
+    if k.dim() == 2:
+        k = k[None]
+    B = b.shape[0]
+    ii = None if image_index is None else _as_dev(image_index, torch.int32, dev)
+    if ii is None and k.shape[0] not in (1, B):
+        raise ValueError("K must be (3,3), (B,3,3), or (P,3,3) with image_index")
+    out = torch.empty((B, 8), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.la3d_project_boxes(_ptr(b), _ptr(k), 9 if k.shape[0] > 1 else 0, _ptr(ii), B, float(image_size[0]),
+                                     float(image_size[1]), _ptr(out), _stream(stream)), "la3d_project_boxes")
+    return out
+
+
+def iou2d_matrix(boxes0, boxes1, stream=None) -> torch.Tensor:
+    """(n0,4) x (n1,4) xyxy boxes -> (n0,n1) IoU (reference iou2D, :111-124)."""
+    dev = boxes0.device if isinstance(boxes0, torch.Tensor) and boxes0.is_cuda else _dev()
+    a, b = _as_dev(boxes0, torch.float64, dev).reshape(-1, 4), _as_dev(boxes1, torch.float64, dev).reshape(-1, 4)
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.la3d_iou_matrix(_ptr(a), a.shape[0], _ptr(b), b.shape[0], _ptr(out), _stream(stream)), "la3d_iou_matrix")
+    return out
+
+
+def hungarian_matching(boxes0, boxes1):
+    """Reference hungarian_matching (:127-144): IoU matrix on the GPU, assignment with SciPy as in the reference.
+    Returns [(index0, index1, iou), ...]."""
+    from scipy.optimize import linear_sum_assignment
+
+    iou = iou2d_matrix(boxes0, boxes1).cpu().numpy()
+    rows, cols = linear_sum_assignment(-iou)
+    return [(int(i), int(j), float(iou[i, j])) for i, j in zip(rows, cols)]

@@ -859,6 +859,44 @@ __global__ __launch_bounds__(256) void mask_stats_kernel(const unsigned char* __
   }
 }
 
+// Box consumers (reference src/tools/combine_results.py:105-108, :238-252): project the 8 corners of every
+// record with its image's K, 2-D AABB and its clamp to the frame.  One thread per box.
+__global__ __launch_bounds__(128) void project_boxes_kernel(const double* __restrict__ rec, const double* __restrict__ K,
+                                                            int k_stride, const int* __restrict__ image_index, int B,
+                                                            double Wd, double Hd, double* __restrict__ out) {
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= B) return;
+  const double* k = K + (long long)(image_index ? image_index[i] : i) * k_stride;
+  const double* c = rec + (long long)i * LA3D_REC + 15;
+  double lo[2] = {INFINITY, INFINITY}, hi[2] = {-INFINITY, -INFINITY};
+  bool bad = false;
+  for (int v = 0; v < 8; ++v) {
+    const double x = c[v * 3], y = c[v * 3 + 1], z = c[v * 3 + 2];
+    const double hx = k[0] * x + k[1] * y + k[2] * z, hy = k[3] * x + k[4] * y + k[5] * z, hz = k[6] * x + k[7] * y + k[8] * z;
+    const double px = hx / hz, py = hy / hz;            // (K @ P)[:2] / (K @ P)[2]
+    if (px != px || py != py) bad = true;              // Python's min()/max() over NaN are order dependent: report NaN
+    lo[0] = fmin(lo[0], px); hi[0] = fmax(hi[0], px);
+    lo[1] = fmin(lo[1], py); hi[1] = fmax(hi[1], py);
+  }
+  double* o = out + (long long)i * 8;
+  if (bad) { for (int j = 0; j < 8; ++j) o[j] = NAN; return; }
+  o[0] = lo[0]; o[1] = lo[1]; o[2] = hi[0]; o[3] = hi[1];
+  o[4] = fmax(0.0, lo[0]); o[5] = fmax(0.0, lo[1]); o[6] = fmin(Wd, hi[0]); o[7] = fmin(Hd, hi[1]);
+}
+
+// IoU of every pair of xyxy boxes (iou2D, reference src/tools/combine_results.py:111-124): the negated matrix is
+// the Hungarian cost matrix of :131-135.
+__global__ __launch_bounds__(256) void iou_matrix_kernel(const double* __restrict__ a, int na, const double* __restrict__ b,
+                                                         int nb, double* __restrict__ out) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)na * nb) return;
+  const double* p = a + (t / nb) * 4;
+  const double* q = b + (t % nb) * 4;
+  const double x1 = fmax(p[0], q[0]), y1 = fmax(p[1], q[1]), x2 = fmin(p[2], q[2]), y2 = fmin(p[3], q[3]);
+  const double inter = fmax(0.0, x2 - x1) * fmax(0.0, y2 - y1);
+  out[t] = inter / ((p[2] - p[0]) * (p[3] - p[1]) + (q[2] - q[0]) * (q[3] - q[1]) - inter + 1e-6);
+}
+
 // host-side 3x3 inverse (same elimination as inv3 above)
 void inv3_host(const double* A, double* X) {
   double a[3][6];
@@ -1097,6 +1135,30 @@ int la3d_mask_stats(const uint8_t* mask, int B, int H, int W, int boundary, int3
   if (B == 0) return LA3D_SUCCESS;
   hipLaunchKernelGGL(mask_stats_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), mask, H, W, boundary, stats);
   return check_launch("mask_stats_kernel");
+}
+
+int la3d_project_boxes(const double* records, const double* K, int32_t k_stride, const int32_t* image_index, int B,
+                       double width, double height, double* out, void* stream) {
+  if ((!records && B > 0) || !K || !out || B < 0 || (k_stride != 0 && k_stride < 9)) {
+    set_err("la3d_project_boxes: bad argument");
+    return LA3D_ERR_ARG;
+  }
+  if (B == 0) return LA3D_SUCCESS;
+  hipLaunchKernelGGL(project_boxes_kernel, dim3((B + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream), records, K,
+                     k_stride, image_index, B, width, height, out);
+  return check_launch("project_boxes_kernel");
+}
+
+int la3d_iou_matrix(const double* boxes_a, int na, const double* boxes_b, int nb, double* out, void* stream) {
+  if (na < 0 || nb < 0 || ((!boxes_a || !boxes_b || !out) && na > 0 && nb > 0)) {
+    set_err("la3d_iou_matrix: bad argument");
+    return LA3D_ERR_ARG;
+  }
+  if (na == 0 || nb == 0) return LA3D_SUCCESS;
+  const long long n = (long long)na * nb;
+  hipLaunchKernelGGL(iou_matrix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     boxes_a, na, boxes_b, nb, out);
+  return check_launch("iou_matrix_kernel");
 }
 
 int la3d_fit_points(const double* points, const int64_t* offsets, const double* ground, const int32_t* sample_idx,

@@ -493,3 +493,38 @@ def keep_instance(stats, image_height, from_rle, scale_threshold=100):
     area, rows, span, trunc = stats
     height = rows if from_rle else span
     return (height / image_height > 0.0625) and not (trunc >= 10) and (area >= scale_threshold)
+
+
+# --------------------------------------------------------------------------------------
+# §8f-2  box consumers: corner projection, 2-D boxes, IoU cost matrix  (src/tools/combine_results.py)
+# --------------------------------------------------------------------------------------
+def project_boxes(records, K, image_size):
+    """src/tools/combine_results.py:105-108, :238-252 — project the 8 corners of each 39-double record with K
+    (p2d = (K @ P)[:2] / (K @ P)[2]); bbox2D_proj = [min_x, min_y, max_x, max_y]; bbox2D_trunc clamps it to
+    [0, W] x [0, H].  records (B,39), K (3,3) or (B,3,3), image_size (W, H) -> (B,8)."""
+    rec = np.asarray(records, dtype=np.float64)
+    K = np.asarray(K, dtype=np.float64)
+    Wd, Hd = image_size
+    out = np.empty((len(rec), 8))
+    for i, r in enumerate(rec):
+        Ki = K if K.ndim == 2 else K[i]
+        corners = r[15:39].reshape(8, 3)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            pts = [np.dot(Ki, p)[:2] / np.dot(Ki, p)[2] for p in corners]
+        min_x, min_y = min(p[0] for p in pts), min(p[1] for p in pts)
+        max_x, max_y = max(p[0] for p in pts), max(p[1] for p in pts)
+        out[i] = [min_x, min_y, max_x, max_y, max(0, min_x), max(0, min_y), min(Wd, max_x), min(Hd, max_y)]
+    return out
+
+
+def iou2d_matrix(boxes0, boxes1):
+    """src/tools/combine_results.py:111-124 (iou2D) for every pair: the negated entries are the Hungarian cost
+    matrix of :131-135."""
+    b0, b1 = np.asarray(boxes0, float), np.asarray(boxes1, float)
+    out = np.zeros((len(b0), len(b1)))
+    for i, a in enumerate(b0):
+        for j, b in enumerate(b1):
+            x1, y1, x2, y2 = max(a[0], b[0]), max(a[1], b[1]), min(a[2], b[2]), min(a[3], b[3])
+            inter = max(0, x2 - x1) * max(0, y2 - y1)
+            out[i, j] = inter / ((a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter + 1e-6)
+    return out

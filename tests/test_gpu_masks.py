@@ -113,3 +113,25 @@ def test_fit_from_rle_equals_fit_from_planes(la):
     assert np_(s_s).tolist() == st_s.tolist()
     ok = st_s == 0
     np.testing.assert_allclose(np_(b_s)[ok][:, :15], ref_s[ok][:, :15], rtol=0, atol=1e-8)
+
+
+def test_box_consumers_vs_reference(la, golden):
+    """la3d_project_boxes / la3d_iou_matrix against the reference's project_to_2d, iou2D and hungarian_matching."""
+    g = golden("g9_consumers.npz")
+    out = np_(la.project_boxes(g["records"], g["K"], tuple(g["image_size"])))
+    np.testing.assert_allclose(out, g["boxes2d"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(np_(la.iou2d_matrix(g["iou_a"], g["iou_b"])), g["iou"], rtol=1e-12, atol=1e-14)
+    got = la.hungarian_matching(g["iou_a"], g["iou_b"])
+    want = g["matches"]
+    assert [(i, j) for i, j, _ in got] == [(int(i), int(j)) for i, j, _ in want]
+    np.testing.assert_allclose([v for _, _, v in got], want[:, 2], rtol=1e-12)
+    # per-image K through image_index, and a failed box (NaN record) gives NaNs
+    rec = g["records"].copy()
+    rec[3] = np.nan
+    Ks = np.stack([g["K"], g["K"] * [[1.1], [0.9], [1.0]]])
+    idx = (np.arange(len(rec)) % 2).astype(np.int32)
+    out = np_(la.project_boxes(rec, Ks, (640, 480), image_index=idx))
+    ref = O.project_boxes(rec, Ks[idx], (640, 480))
+    assert np.isnan(out[3]).all()
+    ok = np.arange(len(rec)) != 3
+    np.testing.assert_allclose(out[ok], ref[ok], rtol=1e-12, atol=1e-12)

@@ -44,3 +44,10 @@ def test_mask_stats_match_reference_filters(golden):
             height = rows if from_rle else span
             want = (height / H > 0.0625) and not bool(ref[3]) and bool(ref[4])   # src/util.py:375
             assert O.keep_instance((area, rows, span, trunc), H, from_rle) == want
+
+
+def test_box_consumers_match_reference(golden):
+    """project_to_2d / bbox2D_proj / bbox2D_trunc / iou2D of the reference (src/tools/combine_results.py)."""
+    g = golden("g9_consumers.npz")
+    np.testing.assert_allclose(O.project_boxes(g["records"], g["K"], tuple(g["image_size"])), g["boxes2d"], rtol=1e-14)
+    np.testing.assert_allclose(O.iou2d_matrix(g["iou_a"], g["iou_b"]), g["iou"], rtol=1e-14, atol=1e-15)
