@@ -56,13 +56,19 @@ def gather_boxes(boxes: torch.Tensor, status: torch.Tensor, dst: int = 0, group=
         [boxes, boxes.new_zeros((nmax - boxes.shape[0], boxes.shape[1]))])
     ps = status if status.shape[0] == nmax else torch.cat([status, status.new_zeros(nmax - status.shape[0])])
     pb, ps = pb.contiguous(), ps.contiguous()
-    if rank == dst:
+    try:
+        if rank == dst:
+            gb = [torch.empty_like(pb) for _ in range(world)]
+            gs = [torch.empty_like(ps) for _ in range(world)]
+        else:
+            gb = gs = None
+        dist.gather(pb, gb, dst=dst, group=group)
+        dist.gather(ps, gs, dst=dst, group=group)
+    except (RuntimeError, NotImplementedError):  # a backend without gather: every rank collects, dst keeps
         gb = [torch.empty_like(pb) for _ in range(world)]
         gs = [torch.empty_like(ps) for _ in range(world)]
-    else:
-        gb = gs = None
-    dist.gather(pb, gb, dst=dst, group=group)
-    dist.gather(ps, gs, dst=dst, group=group)
+        dist.all_gather(gb, pb, group=group)
+        dist.all_gather(gs, ps, group=group)
     if rank != dst:
         return None
     return (torch.cat([g[:c] for g, c in zip(gb, counts)]), torch.cat([g[:c] for g, c in zip(gs, counts)]), counts)
