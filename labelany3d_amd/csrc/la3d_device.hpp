@@ -2,6 +2,9 @@
 // instance; la3d_split.hip: band scan + tile-range-balanced passes).  Reference semantics cited per
 // function (paths relative to /root/reference).
 #pragma once
+#ifndef LA3D_NT
+#define LA3D_NT 512
+#endif
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -13,7 +16,7 @@
 namespace la3d {
 
 
-constexpr int NT = 512;          // threads per workgroup (fit_instances)
+constexpr int NT = LA3D_NT;      // threads per workgroup (fit_instances)
 constexpr int NWAVE = NT / 64;   // wave64
 constexpr int NTP = 256;         // threads per workgroup (fit_points)
 constexpr int NWAVEP = NTP / 64;

@@ -318,6 +318,56 @@ def test_reference_subsample_mode_640x480(la):
     np.testing.assert_array_equal(np_(aux)[:, 1], rn)
 
 
+def test_config3_standin_shared_depth_reference_subsample(la):
+    """BASELINE config 3 stand-in: many images, instance count ~Poisson(7) per image, mask area
+    log-uniform 400..100k px, depth plane and K SHARED per image, reference-subsample mode with the indices
+    the reference's global RNG would draw in instance order.  Per-box check against the oracle."""
+    rs = np.random.RandomState(2017)
+    P, H, W = 40, 480, 640
+    vv, uu = np.mgrid[0:H, 0:W]
+    depth = np.empty((P, H, W), np.float32)
+    Ks = np.empty((P, 3, 3))
+    for pimg in range(P):
+        depth[pimg] = (rs.uniform(2, 6) + rs.uniform(-0.004, 0.004) * uu + rs.uniform(0, 0.01) * vv +
+                       0.03 * rs.randn(H, W)).astype(np.float32)
+        f = rs.uniform(450, 700)
+        Ks[pimg] = [[f, 0, 320 + rs.uniform(-8, 8)], [0, f * rs.uniform(0.98, 1.02), 240 + rs.uniform(-8, 8)], [0, 0, 1]]
+    img, masks = [], []
+    for pimg in range(P):
+        for _ in range(max(1, rs.poisson(7))):
+            area = np.exp(rs.uniform(np.log(400), np.log(100000)))
+            asp = np.exp(rs.uniform(-0.7, 0.7))
+            h = int(np.clip(np.sqrt(area * asp), 8, H)); w = int(np.clip(area / h, 8, W))
+            r0, c0 = rs.randint(0, H - h + 1), rs.randint(0, W - w + 1)
+            m = np.zeros((H, W), bool)
+            m[r0:r0 + h, c0:c0 + w] = ((uu[r0:r0 + h, c0:c0 + w] - c0 - w / 2) ** 2 / (w / 2) ** 2 +
+                                        (vv[r0:r0 + h, c0:c0 + w] - r0 - h / 2) ** 2 / (h / 2) ** 2) < 1.0   # elliptical blob
+            masks.append(m)
+            img.append(pimg)
+    masks = np.array(masks)
+    img = np.array(img, np.int32)
+    B = len(img)
+    ground = np.array([[0.0, -1.0, 0.0, 1.5]] * B) + 0.05 * rs.randn(B, 4)
+    counts = np_(la.mask_counts(masks))
+    np.random.seed(1)
+    idx = la.draw_sample_idx(counts)                      # consumes np.random like the reference, box by box
+    boxes, status, aux = la.fit_instances(depth, masks, Ks, ground=ground, sample_idx=idx, image_index=img)
+    ref, rst, ryaw, rn = O.fit_instances(depth, masks, Ks, ground=ground, sample_idx=idx, depth_index=img)
+    assert (np_(status) == rst).all() and (rst == 0).all()
+    a = np_(aux)
+    assert_records(np_(boxes), ref, "config3", gap=a[:, 3])
+    ok = a[:, 3] > 1e-6
+    np.testing.assert_allclose(a[ok, 0], ryaw[ok], atol=1e-9)
+    # the BASELINE target itself (1e-4 relative on center / dims / yaw) with a wide margin
+    rel = np.abs(np_(boxes)[:, :6] - ref[:, :6]) / np.maximum(np.abs(ref[:, :6]), 1e-3)
+    assert rel.max() < 1e-8
+    # full-mask mode on the same scene, both engines agree with the oracle too
+    boxes_f, status_f, _ = la.fit_instances(depth, masks, Ks, ground=ground, image_index=img)
+    ref_f, rst_f, _, _ = O.fit_instances(depth, masks, Ks, ground=ground, depth_index=img)
+    assert (np_(status_f) == rst_f).all()
+    assert_records(np_(boxes_f), ref_f, "config3-full", rtol=1e-8)
+
+
 def test_fit_points_batched_vs_oracle(la):
     rs = np.random.RandomState(21)
     clouds, grounds = [], []
