@@ -192,11 +192,11 @@ __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__
 // ------------------------------------------------------------------------------------------
 // workgroup stages shared by the fit kernels (every thread of the workgroup must call them)
 // ------------------------------------------------------------------------------------------
-// moments of all waves -> thread 0 (fixed order: bit-reproducible) -> status, yaw axis, aux.
-// On return sh->st / sh->cyaw / sh->syaw are valid for every thread.
-__device__ inline void stage_moments_to_axis(Shared* sh, const FitParams& p, int inst, const double* geo,
-                                             const double* acc, int cnt, int nmask, int tid, int wave, int lane,
-                                             int nw = NWAVE) {
+// moments of all waves -> thread 0 (fixed order: bit-reproducible) -> status, yaw axis.
+// On return sh->st / sh->cyaw / sh->syaw are valid for every thread.  The aux record (with its atan2) is
+// written afterwards by thread 0 only, off the other waves' critical path.
+__device__ inline void stage_moments_to_axis(Shared* sh, const FitParams& p, int inst, const double* acc, int cnt,
+                                             int nmask, int tid, int wave, int lane) {
   {
     const double r0 = wave_sum(acc[0]), r1 = wave_sum(acc[1]), r2 = wave_sum(acc[2]), r3 = wave_sum(acc[3]),
                  r4 = wave_sum(acc[4]);
@@ -209,37 +209,42 @@ __device__ inline void stage_moments_to_axis(Shared* sh, const FitParams& p, int
     }
   }
   __syncthreads();
+  double gap = NAN;
+  int nm = 0;
   if (tid == 0) {
     double s[5] = {0, 0, 0, 0, 0};
-    int n = 0, nm = 0;
+    int n = 0;
 #pragma unroll 1
-    for (int w = 0; w < nw; ++w) {  // fixed order (not unrolled: keeps thread 0's live set small)
+    for (int w = 0; w < NWAVE; ++w) {  // fixed order (not unrolled: keeps thread 0's live set small)
       for (int k = 0; k < 5; ++k) s[k] += sh->part[w][k];
       n += sh->cnt[w];
       nm += sh->nmask[w];
     }
     int st = LA3D_BOX_OK;
-    if (geo[18] != 0.0) st = LA3D_BOX_BAD_GROUND;
+    if (sh->bad_ground) st = LA3D_BOX_BAD_GROUND;
     else if (n == 0) st = LA3D_BOX_EMPTY;
     else if (n == 1) st = LA3D_BOX_TOO_FEW;
-    double cy = NAN, sy = NAN, gap = NAN;
+    double cy = NAN, sy = NAN;
     if (st == LA3D_BOX_OK) axis_from_sums((double)n, s[0], s[1], s[2], s[3], s[4], &cy, &sy, &gap);
     sh->cyaw = cy; sh->syaw = sy;
     sh->st = st;
     sh->n_valid = n;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int st = sh->st;
     if (p.aux) {
       double* a = p.aux + (long long)inst * LA3D_AUX;
-      a[0] = atan2(sy, cy); a[1] = (double)n; a[2] = (double)nm; a[3] = gap;
+      a[0] = atan2(sh->syaw, sh->cyaw); a[1] = (double)sh->n_valid; a[2] = (double)nm; a[3] = gap;
     }
     p.status[inst] = st;
     if (st != LA3D_BOX_OK) write_nan_box(p.out + (long long)inst * LA3D_REC);
   }
-  __syncthreads();
 }
 
-// extents (x,y,z : lo,hi) of all waves -> thread 0 -> the 39-double record
-__device__ inline void stage_extents_to_box(Shared* sh, const FitParams& p, int inst, const double* Rgg,
-                                            const double* ext, int tid, int wave, int lane, int nw = NWAVE) {
+// extents (x,y,z : lo,hi) of all waves -> wave 0 -> the 39-double record, written lane-parallel
+__device__ inline void stage_extents_to_box(Shared* sh, const FitParams& p, int inst, const double* ext, int tid,
+                                            int wave, int lane) {
   {
     const double r0 = wave_min(ext[0]), r1 = wave_max(ext[1]), r2 = wave_min(ext[2]), r3 = wave_max(ext[3]),
                  r4 = wave_min(ext[4]), r5 = wave_max(ext[5]);
@@ -249,15 +254,17 @@ __device__ inline void stage_extents_to_box(Shared* sh, const FitParams& p, int 
     }
   }
   __syncthreads();
-  if (tid == 0) {
-    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-#pragma unroll 1
-    for (int w = 0; w < nw; ++w)
-      for (int k = 0; k < 3; ++k) {
-        lo[k] = fmin(lo[k], sh->part[w][2 * k]);
-        hi[k] = fmax(hi[k], sh->part[w][2 * k + 1]);
-      }
-    write_box(p.out + (long long)inst * LA3D_REC, Rgg, sh->cyaw, sh->syaw, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]);
+  if (wave == 0) {
+    double lo[3], hi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = wave_min(lane < NWAVE ? sh->part[lane][2 * k] : INFINITY);
+      hi[k] = wave_max(lane < NWAVE ? sh->part[lane][2 * k + 1] : -INFINITY);
+    }
+    double Rg[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rg[i] = sh->Rg[i];
+    write_box_wave(p.out + (long long)inst * LA3D_REC, Rg, sh->cyaw, sh->syaw, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], lane);
   }
 }
 
@@ -269,25 +276,6 @@ __device__ inline void yaw_rows(const Shared* sh, const double* Mg, double* N0, 
     N0[jj] = uniform_f64(cy * Mg[jj] + sy * Mg[6 + jj]);
     N2[jj] = uniform_f64(-sy * Mg[jj] + cy * Mg[6 + jj]);
   }
-}
-
-// ------------------------------------------------------------------------------------------
-// per-instance geometry: Kinv, Rg, M = Rg^T Kinv  (one thread per instance; keeps the 3x3
-// elimination and Rodrigues algebra out of the streaming kernel's register budget)
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void prep_kernel(const FitParams p) {
-  const int inst = blockIdx.x * 64 + threadIdx.x;
-  if (inst >= p.B) return;
-  const int img = p.image_index ? p.image_index[inst] : inst;
-  double Kinv[9], Rg[9];
-  inv3(p.K + (long long)img * p.k_stride, Kinv);
-  const int bad = ground_rotation(p.ground ? p.ground + (long long)inst * 4 : nullptr, Rg);
-  double* g = p.geo + (long long)inst * GEO_D;
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) g[i * 3 + j] = Rg[i] * Kinv[j] + Rg[3 + i] * Kinv[3 + j] + Rg[6 + i] * Kinv[6 + j];
-  for (int i = 0; i < 9; ++i) g[9 + i] = Rg[i];
-  g[18] = bad ? 1.0 : 0.0;
-  g[19] = 0.0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -310,13 +298,19 @@ __global__ __launch_bounds__(NT, 8) void fit_instances_kernel(const FitParams p)
   const float* dpl = p.depth + (long long)img * p.depth_plane_stride;
   const unsigned char* mpl = p.mask ? p.mask + (long long)inst * HW : nullptr;
 
-  const double* geo = p.geo + (long long)inst * GEO_D;  // uniform address -> scalar loads
-  const double* Rgg = geo + 9;
-  // read before the first barrier: the compiler only keeps uniform loads on the scalar path (SGPRs)
-  // while nothing in the kernel can have clobbered them
-  double Mg[9];
+  if (tid == NT - 1) {
+    // per-instance geometry (reference src/util.py:56, src/util_3dbox.py:128-134), one lane, overlapped with the
+    // mask stream of everyone else: Kinv, Rg, M = Rg^T Kinv
+    double Kinv[9], Rg[9];
+    inv3_cofactor(p.K + (long long)img * p.k_stride, Kinv);
+    sh->bad_ground = ground_rotation(p.ground ? p.ground + (long long)inst * 4 : nullptr, Rg);
 #pragma unroll
-  for (int i = 0; i < 9; ++i) Mg[i] = geo[i];
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) sh->M[i * 3 + j] = Rg[i] * Kinv[j] + Rg[3 + i] * Kinv[3 + j] + Rg[6 + i] * Kinv[6 + j];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) sh->Rg[i] = Rg[i];
+  }
 
   // ---- phase 0: u8 mask plane -> bit image in LDS --------------------------------------
   int nmask = 0;
@@ -329,9 +323,19 @@ __global__ __launch_bounds__(NT, 8) void fit_instances_kernel(const FitParams p)
     const int ngroups = (HW + 15) >> 4;
     if (VEC) {
       const u32x4* m4 = reinterpret_cast<const u32x4*>(mpl);
-#pragma unroll 4
+#ifndef LA3D_P0_UNROLL
+#define LA3D_P0_UNROLL 4
+#endif
+#ifndef LA3D_P0_NT
+#define LA3D_P0_NT 1
+#endif
+#pragma unroll LA3D_P0_UNROLL
       for (int g = tid; g < ngroups; g += NT) {
+#if LA3D_P0_NT
         const u32x4 w = __builtin_nontemporal_load(m4 + g);
+#else
+        const u32x4 w = m4[g];
+#endif
         const unsigned pat = nz4(w.x) | (nz4(w.y) << 4) | (nz4(w.z) << 8) | (nz4(w.w) << 12);
         b16[g] = (unsigned short)pat;
         nmask += __popc(pat);
@@ -350,6 +354,9 @@ __global__ __launch_bounds__(NT, 8) void fit_instances_kernel(const FitParams p)
     if ((ngroups & 1) && tid == 0) b16[ngroups] = 0;  // upper half of the last 32-bit word
   }
   __syncthreads();
+  double Mg[9];   // wave-uniform: moved to SGPRs
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Mg[i] = uniform_f64(sh->M[i]);
 
   // ---- active-tile list (deterministic two-pass compaction: count, prefix, write) ----------------
   int nactive = 0;
@@ -461,7 +468,7 @@ __global__ __launch_bounds__(NT, 8) void fit_instances_kernel(const FitParams p)
   if (tid == 0) { cnt = 2; acc[0] = 1; acc[1] = 2; acc[2] = 3; acc[3] = 1; acc[4] = 5; }
 #endif
 
-  stage_moments_to_axis(sh, p, inst, geo, acc, cnt, nmask, tid, wave, lane);
+  stage_moments_to_axis(sh, p, inst, acc, cnt, nmask, tid, wave, lane);
   if (sh->st != LA3D_BOX_OK) return;
 
   // ---- pass B: extents along the principal axes -----------------------------------------
@@ -485,7 +492,7 @@ __global__ __launch_bounds__(NT, 8) void fit_instances_kernel(const FitParams p)
     ext[0] = 0; ext[1] = 1; ext[2] = 0; ext[3] = 1; ext[4] = 0; ext[5] = 1;
 #endif
   }
-  stage_extents_to_box(sh, p, inst, Rgg, ext, tid, wave, lane);
+  stage_extents_to_box(sh, p, inst, ext, tid, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -949,7 +956,7 @@ double la3d_f16_round_host(double x) { return f16_round(x); }
 
 size_t la3d_workspace_bytes(int B, int H, int W) {
   if (B <= 0) return 0;
-  const size_t inst = (size_t)B * GEO_D * sizeof(double);  // instance engine: per-instance geometry (prep_kernel)
+  const size_t inst = (size_t)B * GEO_D * sizeof(double);  // kept as the minimum (older callers size by it)
   const size_t split = split_workspace_bytes(B, H, W);     // split engine: + bit image, tile lists, partial slots
   return split > inst ? split : inst;
 }
@@ -1025,8 +1032,6 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   size_t lds = (size_t)p.mask_lds_bytes + sizeof(Shared);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (!rle && split_eligible(p, vec, ldsmask)) return split_fit(p, workspace, s);
-  hipLaunchKernelGGL(prep_kernel, dim3((B + 63) / 64), dim3(64), 0, s, p);
-  if (int rc = check_launch("prep_kernel")) return rc;
   if (sample) {
     if (!ldsmask) {
       snprintf(g_err, sizeof(g_err), "%s: reference-subsample mode needs the bit image in LDS (H*W <= 1048576)", who);

@@ -82,6 +82,18 @@ __device__ inline void inv3(const double* A, double* X) {
   }
 }
 
+// Same inverse by cofactors: straight-line code without pivot bookkeeping (no dynamically indexed arrays, so
+// it can live inside the streaming kernel without costing it scratch memory).  Camera intrinsics are
+// well conditioned; it agrees with the elimination above to a few ulp.
+__device__ inline void inv3_cofactor(const double* A, double* X) {
+  const double a = A[0], b = A[1], c = A[2], d = A[3], e = A[4], f = A[5], g = A[6], h = A[7], i = A[8];
+  const double c00 = e * i - f * h, c01 = f * g - d * i, c02 = d * h - e * g;
+  const double inv = 1.0 / (a * c00 + b * c01 + c * c02);
+  X[0] = c00 * inv; X[1] = (c * h - b * i) * inv; X[2] = (b * f - c * e) * inv;
+  X[3] = c01 * inv; X[4] = (a * i - c * g) * inv; X[5] = (c * d - a * f) * inv;
+  X[6] = c02 * inv; X[7] = (b * g - a * h) * inv; X[8] = (a * e - b * d) * inv;
+}
+
 // Rg of reference src/util_3dbox.py:128-134 (+ :20-25, :37-55).  ground == nullptr or a NaN
 // first component selects the identity ("ground_equ is None").  Returns 1 when the matrix
 // is not finite (parallel / antiparallel / zero ground vector -> 0/0).
@@ -303,12 +315,16 @@ constexpr int GEO_D = 20;  // M[9] (= Rg^T Kinv : p' = d * (M @ [u,v,1])), Rg[9]
 
 struct alignas(16) Shared {
   double part[NWAVE][7];
+  double M[9];     // Rg^T * Kinv, computed in-kernel by one lane while the others stream the mask
+  double Rg[9];
   double cyaw, syaw;
   int cnt[NWAVE];
   int nmask[NWAVE];
   unsigned scan[NWAVE];
   int n_valid;
   int st;
+  int bad_ground;
+  int pad;
 };
 
 __device__ inline void pix_uv(unsigned i, int W, float rcpW, unsigned* u, unsigned* v) {

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Throughput of the auxiliary kernels (not the headline metric; bench.py is).  Run on an MI355X:
+    python profiles/bench_aux.py > gpurun_out/bench_aux.json
+Each entry: HIP-event time per call on the launch stream, algorithmic bytes per call, GB/s."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import labelany3d_amd as la  # noqa: E402
+from labelany3d_amd.util import depth_to_points  # noqa: E402,F401
+
+H, W = 480, 640
+K = np.array([[500.0, 0, 320], [0, 500.0, 240], [0, 0, 1]])
+
+
+def timed(fn, n=50, warm=5):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e-3
+
+
+def main():
+    torch.cuda.set_device(0)
+    out = {}
+    rs = np.random.RandomState(0)
+    # depth_to_points, one 640x480 frame, f64 output (reference dtype): 4 B in + 24 B out per pixel
+    d = torch.rand((H, W), device="cuda") * 9.5 + 0.5
+    t = timed(lambda: la.unproject(d, K))
+    out["unproject_640x480_f64"] = dict(s=t, bytes=H * W * 28, GBps=H * W * 28 / t / 1e9, frames_per_s=1 / t)
+    big = torch.rand((2160, 3840), device="cuda") * 9.5 + 0.5
+    t = timed(lambda: la.unproject(big, K), n=20)
+    out["unproject_3840x2160_f64"] = dict(s=t, bytes=big.numel() * 28, GBps=big.numel() * 28 / t / 1e9)
+    # estimate_bbox on 500-point clouds (the reference's actual call), 4096 clouds per launch
+    B = 4096
+    pts = torch.as_tensor(rs.randn(B * 500, 3) * [1.0, 0.3, 0.5] + [0, 0, 5.0], device="cuda")
+    off = torch.arange(0, B * 500 + 1, 500, device="cuda", dtype=torch.int64)
+    for method in ("pca", "convex_hull"):
+        t = timed(lambda: la.fit_points((pts, off), None, None, method), n=20)
+        out[f"fit_points_500pt_{method}"] = dict(s=t, boxes_per_s=B / t, bytes=B * 500 * 24 * 2, GBps=B * 500 * 48 / t / 1e9)
+    # masks: rle decode, stats
+    Bm = 1024
+    hh, ww = rs.randint(8, 301, Bm), rs.randint(8, 331, Bm)
+    r0 = (rs.rand(Bm) * (H - hh + 1)).astype(int)
+    c0 = (rs.rand(Bm) * (W - ww + 1)).astype(int)
+    counts, offs = [], [0]
+    for a, b, h, w in zip(r0, c0, hh, ww):
+        counts += [int(b * H + a)] + [int(h), int(H - h)] * (int(w) - 1) + [int(h), int((W - b - w) * H + (H - a - h))]
+        offs.append(len(counts))
+    packed = (np.asarray(counts, np.int32), np.asarray(offs, np.int64), H, W)
+    masks = la.rle_decode(packed)
+    t = timed(lambda: la.rle_decode(packed), n=20)
+    out["rle_decode_1024x640x480"] = dict(s=t, bytes=Bm * H * W, GBps=Bm * H * W / t / 1e9, masks_per_s=Bm / t,
+                                          note="includes the host->device copy of the run lengths")
+    t = timed(lambda: la.mask_stats(masks), n=20)
+    out["mask_stats_1024x640x480"] = dict(s=t, bytes=Bm * H * W, GBps=Bm * H * W / t / 1e9)
+    t = timed(lambda: la.mask_counts(masks), n=20)
+    out["mask_counts_1024x640x480"] = dict(s=t, bytes=Bm * H * W, GBps=Bm * H * W / t / 1e9)
+    # consumers
+    depth = torch.rand((Bm, H, W), device="cuda") * 9.5 + 0.5
+    boxes, _, _ = la.fit_instances(depth, masks, K)
+    t = timed(lambda: la.project_boxes(boxes, K, (W, H)))
+    out["project_boxes_1024"] = dict(s=t, boxes_per_s=Bm / t)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
