@@ -130,7 +130,10 @@ __device__ inline void sweep(const FitParams& p, const float* __restrict__ dpl, 
 // Branch-free pixel math: validity (mask bit AND finite depth) is a 0/-1 word; PASS 0 (moments) ANDs it
 // into the depth bits (invalid -> +0.0 contributes nothing to the sums); PASS 1 (extents of all three
 // axes) ORs its complement (invalid -> NaN, ignored by v_min/v_max_f64).
-constexpr int TG = 4;
+#ifndef LA3D_TG
+#define LA3D_TG 4
+#endif
+constexpr int TG = LA3D_TG;
 
 template <int PASS>
 __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__ dpl, const unsigned* bits,
@@ -282,7 +285,7 @@ __device__ inline void yaw_rows(const Shared* sh, const double* Mg, double* N0, 
 // fused kernel: one workgroup per instance
 // ------------------------------------------------------------------------------------------
 template <bool VEC, bool LDSMASK, bool SAMPLE, bool TILED>
-__global__ __launch_bounds__(NT, 8) void fit_instances_kernel(const FitParams p) {
+__global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned* bits = reinterpret_cast<unsigned*>(smem);
   Shared* sh = reinterpret_cast<Shared*>(smem + p.mask_lds_bytes);
