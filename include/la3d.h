@@ -134,6 +134,16 @@ int la3d_project_boxes(const double* records, const double* K, int32_t k_stride,
  * (negated = the Hungarian cost matrix of :131-135). */
 int la3d_iou_matrix(const double* boxes_a, int na, const double* boxes_b, int nb, double* out, void* stream);
 
+/* ---- masked depth statistics ------------------------------------------------------------------
+ * Reference src/util.py:476-486 (align_to_depth_match): overlap = mask & render_mask;
+ * scale = np.median(depth_map[overlap] / depth_render[overlap])  (float32 arithmetic, float32 result).
+ * num   dev f32 planes (plane of instance n = image_index[n] or n; stride in floats, 0 = one shared plane)
+ * den   dev f32 [B][H*W];  mask_a dev u8 [B][H*W];  mask_b dev u8 [B][H*W] | NULL (non-zero = True)
+ * median dev f32 [B] (NaN when the overlap is empty or a ratio is NaN, as np.median);  count dev i32 [B]. */
+int la3d_masked_ratio_median(const float* num, int64_t num_plane_stride, const int32_t* image_index, const float* den,
+                             const uint8_t* mask_a, const uint8_t* mask_b, int B, int H, int W, float* median,
+                             int32_t* count, void* stream);
+
 /* Replaces estimate_bbox(in_pc, cat_name, ground_equ, method) for B point clouds at once —
  * reference src/util_3dbox.py:106-178 (caller :273-278, 500 mesh samples per object).
  * points   dev f64 [total][3];  offsets dev i64 [B+1] (cloud n = rows offsets[n]..offsets[n+1])

@@ -907,6 +907,101 @@ __global__ __launch_bounds__(256) void iou_matrix_kernel(const double* __restric
   out[t] = inter / ((p[2] - p[0]) * (p[3] - p[1]) + (q[2] - q[0]) * (q[3] - q[1]) - inter + 1e-6);
 }
 
+// Masked depth-ratio median — reference src/util.py:476-486 (align_to_depth_match): overlap = mask_a & mask_b,
+// scale = np.median(num[overlap] / den[overlap]) in float32.  One workgroup per instance: the overlap goes to a
+// bit image in LDS, then the k-th smallest ratio is found exactly by a 4 x 8-bit most-significant-first radix
+// select on an order-preserving key (two selections when the count is even; np.median averages the two middle
+// values in float32).  Any NaN ratio makes the result NaN, as np.median does; an empty overlap gives count 0, NaN.
+__device__ inline unsigned f32_key(float v) {
+  const unsigned b = __float_as_uint(v);
+  return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ inline float f32_unkey(unsigned k) {
+  return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
+}
+
+__global__ __launch_bounds__(256) void ratio_median_kernel(const float* __restrict__ num, long long num_stride,
+                                                           const int* __restrict__ image_index, const float* __restrict__ den,
+                                                           const unsigned char* __restrict__ mask_a,
+                                                           const unsigned char* __restrict__ mask_b, int HW, int nwords,
+                                                           float* __restrict__ median, int* __restrict__ count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned* bits = reinterpret_cast<unsigned*>(smem);
+  unsigned* hist = bits + nwords;          // 256 bins
+  unsigned* misc = hist + 256;             // [0] n, [1] nan count, [2] selected prefix, [3] remaining rank
+  const int tid = threadIdx.x, inst = blockIdx.x;
+  const float* np_ = num + (long long)(image_index ? image_index[inst] : inst) * num_stride;
+  const float* dp = den + (long long)inst * HW;
+  const unsigned char* ma = mask_a + (long long)inst * HW;
+  const unsigned char* mb = mask_b ? mask_b + (long long)inst * HW : nullptr;
+  if (tid < 4) misc[tid] = 0;
+  __syncthreads();
+  // overlap bit image + counts
+  unsigned n_local = 0, nan_local = 0;
+  for (int w = tid; w < nwords; w += 256) {
+    unsigned word = 0;
+    const int i0 = w * 32;
+    for (int k = 0; k < 32; ++k) {
+      const int i = i0 + k;
+      if (i < HW && ma[i] && (!mb || mb[i])) {
+        word |= 1u << k;
+        const float r = np_[i] / dp[i];
+        nan_local += (r != r) ? 1u : 0u;
+      }
+    }
+    bits[w] = word;
+    n_local += __popc(word);
+  }
+  atomicAdd(&misc[0], n_local);
+  atomicAdd(&misc[1], nan_local);
+  __syncthreads();
+  const unsigned n = misc[0];
+  if (n == 0 || misc[1] != 0) {
+    if (tid == 0) { median[inst] = NAN; count[inst] = (int)n; }
+    return;
+  }
+  float result[2] = {0.f, 0.f};
+  const int nsel = (n & 1u) ? 1 : 2;
+  for (int sel = 0; sel < nsel; ++sel) {
+    unsigned rank = (n & 1u) ? n / 2 : n / 2 - 1 + sel;   // 0-based rank among the sorted ratios
+    unsigned prefix = 0, pmask = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      hist[tid] = 0;
+      __syncthreads();
+      for (int w = tid; w < nwords; w += 256) {
+        unsigned word = bits[w];
+        while (word) {
+          const int k = __ffs((int)word) - 1;
+          word &= word - 1;
+          const int i = w * 32 + k;
+          const unsigned key = f32_key(np_[i] / dp[i]);
+          if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 0xffu], 1u);
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {   // the bin holding the wanted rank
+        unsigned acc = 0, b = 0;
+        for (; b < 256; ++b) {
+          if (acc + hist[b] > rank) break;
+          acc += hist[b];
+        }
+        misc[2] = prefix | (b << shift);
+        misc[3] = rank - acc;
+      }
+      __syncthreads();
+      prefix = misc[2];
+      rank = misc[3];
+      pmask |= 0xffu << shift;
+      __syncthreads();
+    }
+    result[sel] = f32_unkey(prefix);
+  }
+  if (tid == 0) {
+    median[inst] = (nsel == 1) ? result[0] : (result[0] + result[1]) / 2.0f;   // float32 mean of the two middle values
+    count[inst] = (int)n;
+  }
+}
+
 // host-side 3x3 inverse (same elimination as inv3 above)
 void inv3_host(const double* A, double* X) {
   double a[3][6];
@@ -1143,6 +1238,29 @@ int la3d_mask_stats(const uint8_t* mask, int B, int H, int W, int boundary, int3
   if (B == 0) return LA3D_SUCCESS;
   hipLaunchKernelGGL(mask_stats_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), mask, H, W, boundary, stats);
   return check_launch("mask_stats_kernel");
+}
+
+int la3d_masked_ratio_median(const float* num, int64_t num_plane_stride, const int32_t* image_index, const float* den,
+                             const uint8_t* mask_a, const uint8_t* mask_b, int B, int H, int W, float* median,
+                             int32_t* count, void* stream) {
+  if (!num || !den || !mask_a || !median || !count || B < 0 || H <= 0 || W <= 0 || num_plane_stride < 0 ||
+      (long long)H * W > (1LL << 20)) {
+    set_err("la3d_masked_ratio_median: bad argument (H*W <= 1048576)");
+    return LA3D_ERR_ARG;
+  }
+  if (B == 0) return LA3D_SUCCESS;
+  const int HW = H * W, nwords = (HW + 31) / 32;
+  const size_t lds = (size_t)nwords * 4 + 256 * 4 + 64;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(ratio_median_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      (void)hipGetLastError();
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(ratio_median_kernel, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), num,
+                     (long long)num_plane_stride, image_index, den, mask_a, mask_b, HW, nwords, median, count);
+  return check_launch("ratio_median_kernel");
 }
 
 int la3d_project_boxes(const double* records, const double* K, int32_t k_stride, const int32_t* image_index, int B,

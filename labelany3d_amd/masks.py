@@ -115,3 +115,28 @@ def fit_instances_rle(depth, rles, K, ground=None, sample_idx=None, image_index=
                                         _ptr(f.status[0]), _ptr(f.aux[0]), _ptr(f.workspace[0]), _stream(stream))
         check(rc, "la3d_fit_instances_rle")
     return f.boxes[0], f.status[0], f.aux[0]
+
+
+def masked_ratio_median(depth_map, depth_render, mask, render_mask=None, image_index=None, stream=None):
+    """Per instance ``np.median(depth_map[overlap] / depth_render[overlap])`` with ``overlap = mask & render_mask``
+    — the scale estimate of the reference's align_to_depth_match (src/util.py:476-486), exact (radix select on
+    the float32 ratios).  depth_map (P,H,W) or (H,W); depth_render, mask, render_mask (B,H,W).
+    Returns (median float32 (B,), count int32 (B,)) on the GPU; an empty overlap gives count 0 and NaN (the
+    reference returns the identity transform there, :476-478)."""
+    dev = mask.device if isinstance(mask, torch.Tensor) and mask.is_cuda else _dev()
+    m = _as_dev(mask, torch.uint8, dev)
+    B, H, W = m.shape
+    rm = None if render_mask is None else _as_dev(render_mask, torch.uint8, dev)
+    d = _as_dev(depth_map, torch.float32, dev)
+    if d.dim() == 2:
+        d = d[None]
+    r = _as_dev(depth_render, torch.float32, dev)
+    ii = None if image_index is None else _as_dev(image_index, torch.int32, dev)
+    if ii is None and d.shape[0] not in (1, B):
+        raise ValueError("without image_index, depth_map must have 1 or B planes")
+    med = torch.empty(B, dtype=torch.float32, device=dev)
+    cnt = torch.empty(B, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.la3d_masked_ratio_median(_ptr(d), H * W if d.shape[0] > 1 else 0, _ptr(ii), _ptr(r), _ptr(m), _ptr(rm), B, H, W,
+                                           _ptr(med), _ptr(cnt), _stream(stream)), "la3d_masked_ratio_median")
+    return med, cnt

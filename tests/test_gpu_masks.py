@@ -137,3 +137,43 @@ def test_box_consumers_vs_reference(la, golden):
     assert np.isnan(out[3]).all()
     ok = np.arange(len(rec)) != 3
     np.testing.assert_allclose(out[ok], ref[ok], rtol=1e-12, atol=1e-12)
+
+
+def test_masked_ratio_median_vs_numpy(la):
+    """the float32 arithmetic of reference src/util.py:480-486, restated with the same NumPy calls."""
+    rs = np.random.RandomState(12)
+    B, H, W = 9, 96, 128
+    depth_map = rs.uniform(0.5, 10, (H, W)).astype(np.float32)
+    render = (depth_map[None] * rs.uniform(0.3, 3.0, (B, 1, 1)) * (1 + 0.05 * rs.randn(B, H, W))).astype(np.float32)
+    mask = rs.rand(B, H, W) < 0.3
+    rmask = rs.rand(B, H, W) < 0.7
+    mask[1] = False                                   # empty overlap -> the reference returns the identity transform
+    mask[2] = False; mask[2, 5, 7] = True; rmask[2, 5, 7] = True           # one pixel
+    mask[3] = False; mask[3, 10, 10:12] = True; rmask[3] = True            # two pixels: mean of both, in float32
+    render[4, mask[4] & rmask[4]] *= -1               # negative ratios
+    render[5, 20, 20] = 0.0; mask[5, 20, 20] = True; rmask[5, 20, 20] = True   # +inf ratio sorts last
+    render[6, 30, 30] = np.nan; mask[6, 30, 30] = True; rmask[6, 30, 30] = True  # NaN -> NaN
+    render[7][:] = render[7][0, 0]                    # heavy ties
+    med, cnt = la.masked_ratio_median(depth_map, render, mask, rmask)
+    med, cnt = np_(med), np_(cnt)
+    for i in range(B):
+        overlap = mask[i] & rmask[i]
+        assert cnt[i] == overlap.sum()
+        if not overlap.any():
+            assert np.isnan(med[i])
+            continue
+        with np.errstate(all="ignore"):
+            ratios = depth_map[overlap] / render[i][overlap]      # src/util.py:480-485
+            want = np.median(ratios)                              # :486
+        assert want.dtype == np.float32
+        if np.isnan(want):
+            assert np.isnan(med[i]), i
+        else:
+            assert med[i] == want, (i, med[i], want)              # exact: selection, not approximation
+    # per-instance depth planes through image_index, no second mask
+    dm = rs.uniform(1, 5, (3, H, W)).astype(np.float32)
+    idx = rs.randint(0, 3, B).astype(np.int32)
+    med2, _ = la.masked_ratio_median(dm, np.abs(render) + 0.1, mask, None, image_index=idx)
+    for i in range(B):
+        if mask[i].any():
+            assert np_(med2)[i] == np.median(dm[idx[i]][mask[i]] / (np.abs(render[i]) + 0.1)[mask[i]]) or np.isnan(np_(med2)[i])
