@@ -144,6 +144,15 @@ int la3d_masked_ratio_median(const float* num, int64_t num_plane_stride, const i
                              const uint8_t* mask_a, const uint8_t* mask_b, int B, int H, int W, float* median,
                              int32_t* count, void* stream);
 
+/* ---- sparse unprojection at match points -------------------------------------------------------
+ * Reference src/matching/matcher.py:70-91: depth dev f32 [H][W] looked up at (int(v), int(u)) of each match
+ * uv dev f64 [N][2]; matches whose depth is -1 (or that fall outside the frame) get valid = 0 and NaNs;
+ * p = ((u'-cx) d/fx, (v'-cy) d/fy, d) with u' = flip-u, v' = flip-v when use_flip (the reference uses 512);
+ * with R9 / T3 (HOST, both or neither): world = R (p - T)  (:88-89).  out dev f64 [N][3], valid dev i32 [N]. */
+int la3d_unproject_matches(const float* depth, int H, int W, const double* uv, int N, double fx, double fy, double cx,
+                           double cy, int use_flip, double flip, const double* R9, const double* T3, double* out,
+                           int32_t* valid, void* stream);
+
 /* Replaces estimate_bbox(in_pc, cat_name, ground_equ, method) for B point clouds at once —
  * reference src/util_3dbox.py:106-178 (caller :273-278, 500 mesh samples per object).
  * points   dev f64 [total][3];  offsets dev i64 [B+1] (cloud n = rows offsets[n]..offsets[n+1])

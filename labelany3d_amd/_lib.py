@@ -32,6 +32,9 @@ _SIGS = {
     "la3d_mask_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "la3d_masked_ratio_median": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                            C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "la3d_unproject_matches": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double,
+                                         C.c_double, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                         C.c_void_p, C.c_void_p, C.c_void_p]),
     "la3d_project_boxes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int, C.c_double, C.c_double,
                                      C.c_void_p, C.c_void_p]),
     "la3d_iou_matrix": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

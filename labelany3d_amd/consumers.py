@@ -40,6 +40,30 @@ def iou2d_matrix(boxes0, boxes1, stream=None) -> torch.Tensor:
     return out
 
 
+def unproject_matches(depth, uv, fx=560.44, fy=560.44, cx=256.0, cy=256.0, flip=512.0, R=None, T=None, stream=None):
+    """Sparse pinhole unprojection at 2-D match points (reference src/matching/matcher.py:70-91; the defaults are
+    its hard-coded intrinsics and 512-flip): returns (points (N,3) float64, valid (N,) bool) on the GPU; matches
+    whose depth is -1 are flagged invalid (the reference drops them, :72-75).  With R (3,3) and T (3,):
+    world = R (p - T).  ``flip=None`` disables the 512-u / 512-v flip."""
+    import ctypes as C
+
+    dev = depth.device if isinstance(depth, torch.Tensor) and depth.is_cuda else _dev()
+    d = _as_dev(depth, torch.float32, dev)
+    m = _as_dev(uv, torch.float64, dev).reshape(-1, 2)
+    N = m.shape[0]
+    out = torch.empty((N, 3), dtype=torch.float64, device=dev)
+    valid = torch.empty(N, dtype=torch.int32, device=dev)
+    R9 = T3 = None
+    if R is not None or T is not None:
+        R9 = (C.c_double * 9)(*np.asarray(np.eye(3) if R is None else R, dtype=np.float64).ravel())
+        T3 = (C.c_double * 3)(*np.asarray(np.zeros(3) if T is None else T, dtype=np.float64).ravel())
+    with torch.cuda.device(dev):
+        check(lib.la3d_unproject_matches(_ptr(d), d.shape[0], d.shape[1], _ptr(m), N, fx, fy, cx, cy, int(flip is not None),
+                                         float(flip or 0.0), R9, T3, _ptr(out), _ptr(valid), _stream(stream)),
+              "la3d_unproject_matches")
+    return out, valid.bool()
+
+
 def hungarian_matching(boxes0, boxes1):
     """Reference hungarian_matching (:127-144): IoU matrix on the GPU, assignment with SciPy as in the reference.
     Returns [(index0, index1, iou), ...]."""

@@ -1002,6 +1002,41 @@ __global__ __launch_bounds__(256) void ratio_median_kernel(const float* __restri
   }
 }
 
+// Sparse unprojection at match points — reference src/matching/matcher.py:70-91: depth looked up at
+// (int(v), int(u)), points with depth == -1 dropped, u' = flip - u, v' = flip - v (flip = 512 there),
+// p = ((u'-cx) d / fx, (v'-cy) d / fy, d), world = R (p - T).  One thread per match.
+struct MatchParams {
+  double fx, fy, cx, cy, flip;
+  double R[9], T[3];
+  int has_rt, use_flip;
+  int H, W, N;
+};
+__global__ __launch_bounds__(128) void unproject_matches_kernel(const float* __restrict__ depth, const double* __restrict__ uv,
+                                                                const MatchParams p, double* __restrict__ out,
+                                                                int* __restrict__ valid) {
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= p.N) return;
+  const double mu = uv[2 * i], mv = uv[2 * i + 1];
+  const long long cu = (long long)mu, cv = (long long)mv;    // astype(int): truncation toward zero
+  double* o = out + (long long)i * 3;
+  bool ok = cu >= 0 && cu < p.W && cv >= 0 && cv < p.H;
+  float df = -1.f;
+  if (ok) df = depth[cv * p.W + cu];
+  ok = ok && (df != -1.f);
+  valid[i] = ok ? 1 : 0;
+  if (!ok) { o[0] = o[1] = o[2] = NAN; return; }
+  const double d = (double)df;
+  const double u = p.use_flip ? p.flip - mu : mu, v = p.use_flip ? p.flip - mv : mv;
+  double q[3] = {(u - p.cx) * d / p.fx, (v - p.cy) * d / p.fy, d};
+  if (p.has_rt) {
+    const double a = q[0] - p.T[0], b = q[1] - p.T[1], c = q[2] - p.T[2];
+    q[0] = p.R[0] * a + p.R[1] * b + p.R[2] * c;
+    q[1] = p.R[3] * a + p.R[4] * b + p.R[5] * c;
+    q[2] = p.R[6] * a + p.R[7] * b + p.R[8] * c;
+  }
+  o[0] = q[0]; o[1] = q[1]; o[2] = q[2];
+}
+
 // host-side 3x3 inverse (same elimination as inv3 above)
 void inv3_host(const double* A, double* X) {
   double a[3][6];
@@ -1261,6 +1296,24 @@ int la3d_masked_ratio_median(const float* num, int64_t num_plane_stride, const i
   hipLaunchKernelGGL(ratio_median_kernel, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), num,
                      (long long)num_plane_stride, image_index, den, mask_a, mask_b, HW, nwords, median, count);
   return check_launch("ratio_median_kernel");
+}
+
+int la3d_unproject_matches(const float* depth, int H, int W, const double* uv, int N, double fx, double fy, double cx,
+                           double cy, int use_flip, double flip, const double* R9, const double* T3, double* out,
+                           int32_t* valid, void* stream) {
+  if (!depth || (!uv && N > 0) || !out || !valid || N < 0 || H <= 0 || W <= 0 || (R9 == nullptr) != (T3 == nullptr)) {
+    set_err("la3d_unproject_matches: bad argument");
+    return LA3D_ERR_ARG;
+  }
+  if (N == 0) return LA3D_SUCCESS;
+  MatchParams p;
+  p.fx = fx; p.fy = fy; p.cx = cx; p.cy = cy; p.flip = flip; p.use_flip = use_flip; p.H = H; p.W = W; p.N = N;
+  p.has_rt = R9 != nullptr;
+  for (int i = 0; i < 9; ++i) p.R[i] = R9 ? R9[i] : 0.0;
+  for (int i = 0; i < 3; ++i) p.T[i] = T3 ? T3[i] : 0.0;
+  hipLaunchKernelGGL(unproject_matches_kernel, dim3((N + 127) / 128), dim3(128), 0, static_cast<hipStream_t>(stream), depth, uv,
+                     p, out, valid);
+  return check_launch("unproject_matches_kernel");
 }
 
 int la3d_project_boxes(const double* records, const double* K, int32_t k_stride, const int32_t* image_index, int B,

@@ -177,3 +177,26 @@ def test_masked_ratio_median_vs_numpy(la):
     for i in range(B):
         if mask[i].any():
             assert np_(med2)[i] == np.median(dm[idx[i]][mask[i]] / (np.abs(render[i]) + 0.1)[mask[i]]) or np.isnan(np_(med2)[i])
+
+
+def test_unproject_matches_vs_numpy(la):
+    """reference src/matching/matcher.py:70-91 restated with the same NumPy expressions."""
+    rs = np.random.RandomState(8)
+    depth = rs.uniform(1, 4, (512, 512)).astype(np.float32)
+    depth[rs.rand(512, 512) < 0.2] = -1                       # the renderer's "no surface" value
+    m1 = rs.uniform(0, 511.9, (300, 2))
+    R = np.linalg.qr(rs.randn(3, 3))[0]
+    T = rs.randn(3)
+    pts, valid = la.unproject_matches(depth, m1, R=R, T=T)
+    d_of = depth[m1[:, 1].astype(int), m1[:, 0].astype(int)]           # :71
+    ok = d_of != -1                                                      # :72
+    assert np.array_equal(np_(valid), ok)
+    fx, fy, cx, cy = 560.44, 560.44, 256, 256                            # :78
+    u = 512 - m1[ok][:, 0]; v = 512 - m1[ok][:, 1]                       # :79-80
+    x = (u - cx) * d_of[ok] / fx; y = (v - cy) * d_of[ok] / fy; z = d_of[ok]   # :82-84
+    p3 = np.stack((x, y, z), axis=-1)
+    world = np.matmul(R, (p3.T - T.reshape(3, 1))).T                      # :88-90
+    np.testing.assert_allclose(np_(pts)[ok], world, rtol=1e-13, atol=1e-13)
+    assert np.isnan(np_(pts)[~ok]).all()
+    pts2, _ = la.unproject_matches(depth, m1, flip=None)                  # plain pinhole, camera frame
+    np.testing.assert_allclose(np_(pts2)[ok][:, 2], d_of[ok])
