@@ -6,17 +6,19 @@
 //   depth_to_points   /root/reference/src/util.py:52-75
 //   estimate_bbox     /root/reference/src/util_3dbox.py:106-178   (+ helpers :20-103, PCA yaw :181-186)
 //
-// Memory-bound integer/byte + fp64 reduction work: no MFMA.  Layout and kernel design are
-// described in DESIGN.md; the short version for the fused kernel `fit_instances_kernel`:
-//   one 512-thread workgroup (8 wave64) per instance;
-//   phase 0  streams the u8 mask plane once with 16-byte non-temporal loads and packs it to a
-//            1-bit-per-pixel image in LDS (38.4 KB for 640x480);
-//   pass A   walks the bit image, 4 pixels per lane; only quads with a set bit load their
-//            float4 of depth (coalesced 1 KB per wave), unproject in fp64 and accumulate
-//            n, Sx, Sz, Sxx, Sxz, Szz, ymin, ymax per lane -> wave shuffle reduce -> LDS -> thread 0;
-//   yaw      closed-form 2x2 principal axis with scikit-learn's sign rule (thread 0);
-//   pass B   same walk (depth now L2/Infinity-Cache resident), min/max of the yaw-rotated x,z;
-//   epilog   thread 0 writes center / dims / R_cam / fp16-quantised vertices.
+// Memory-bound integer/byte + fp64 reduction work: no MFMA.  Layout, kernel design and measurements are in
+// DESIGN.md.  This file holds the INSTANCE ENGINE of la3d_fit_instances (one workgroup per instance; used for
+// B > 384, for run-length masks, for reference-subsample mode and for frames the split engine does not take —
+// la3d_split.hip is the other engine) and every other kernel of the C-ABI.  `fit_instances_kernel` in short:
+//   one 512-thread workgroup (8 wave64) per instance, 64 VGPRs / 40 KB LDS -> 4 workgroups per CU;
+//   phase 0  streams the u8 mask plane once with 16-byte non-temporal loads (or decodes COCO run lengths) into a
+//            1-bit-per-pixel image in LDS (38.4 KB for 640x480); meanwhile one lane computes K^-1, Rg, M;
+//   list     deterministic compaction of the 32 px x 8 row tiles that contain a set bit;
+//   pass A   4 listed tiles per wave-step, their float4 depth loads issued back to back; branch-free fp64
+//            accumulation of n, Sx, Sz, Sxx, Sxz, Szz -> wave butterfly -> LDS -> thread 0 (fixed order);
+//   yaw      closed-form 2x2 principal axis with scikit-learn's sign rule, no trigonometry (thread 0);
+//   pass B   same walk, six extents in the yaw frame with NaN-ignoring raw v_min/v_max_f64;
+//   epilog   wave 0 writes center / dims / R_cam / fp16-quantised vertices, one lane per output group.
 #include "la3d_device.hpp"
 
 namespace la3d {
@@ -282,7 +284,7 @@ __device__ inline void yaw_rows(const Shared* sh, const double* Mg, double* N0, 
 }
 
 // ------------------------------------------------------------------------------------------
-// fused kernel: one workgroup per instance
+// instance engine: one workgroup per instance
 // ------------------------------------------------------------------------------------------
 template <bool VEC, bool LDSMASK, bool SAMPLE, bool TILED>
 __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitParams p) {

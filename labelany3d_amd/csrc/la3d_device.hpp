@@ -310,7 +310,8 @@ struct FitParams {
   double* aux;
 };
 
-// per-instance geometry written by prep_kernel into the workspace (20 doubles = 160 B)
+// per-instance geometry in the workspace (20 doubles = 160 B), written by the split engine's geo_kernel
+// (the instance engine keeps it in LDS)
 constexpr int GEO_D = 20;  // M[9] (= Rg^T Kinv : p' = d * (M @ [u,v,1])), Rg[9], bad_ground, pad
 
 struct alignas(16) Shared {
