@@ -297,7 +297,7 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: lives in an SGPR
-  const int inst = xcd_remap(blockIdx.x, p.B);
+  const int inst = p.perm ? p.perm[blockIdx.x] : xcd_remap(blockIdx.x, p.B);
   const int img = p.image_index ? p.image_index[inst] : inst;
   const int HW = p.HW;
   const float* dpl = p.depth + (long long)img * p.depth_plane_stride;
@@ -1061,8 +1061,99 @@ void inv3_host(const double* A, double* X) {
 
 constexpr int MAX_MASK_LDS = 128 * 1024;  // bit image budget; larger frames re-read the u8 mask instead
 
+// ------------------------------------------------------------------------------------------
+// launch order.  Measured on MI355X (profiles/microbench/wg_census.hip, profiles/exp_chain.py): workgroup b of a
+// fresh grid starts on CU b % 256 (XCD b % 8), so with G workgroups resident per CU the instances of blocks
+// {c, c+256, ..., c+(G-1)*256} share CU c for their whole life, and the fit passes are VALU-bound per CU: the
+// launch lasts as long as the most loaded CU.  With random sizes that CU carries ~2x the mean.  Two small kernels
+// estimate each instance's mask area and hand out blocks so that every CU gets a snake-balanced set (rank r of
+// the descending order -> group r/256, alternating direction); ranks beyond the resident set follow in descending
+// order (longest-first list scheduling for the dynamically placed remainder).  Same multiset of sizes on B=1024:
+// 152 us unordered, 113 us snake-ordered (host-arranged), 196 us worst case.
+// ------------------------------------------------------------------------------------------
+constexpr int EST_STEP = 67;        // area estimate: every 67th 16-byte group of the plane (67 is coprime to W/16 = 40,
+                                    // 80, 120: the lattice visits every column group); small frames take a smaller
+                                    // prime so that about 256 groups are still sampled
+constexpr int ORDER_MAX_B = 16384;  // the ranking is O(B^2 / lanes); beyond this dynamic placement averages well enough
+constexpr int KEY_IDX_BITS = 14;    // sort key = (area quantised to 18 bits) << 14 | (16383 - instance): unique, and a
+                                    // plain unsigned compare orders by area descending, then index ascending
+
+__global__ __launch_bounds__(256) void size_estimate_kernel(const unsigned char* __restrict__ mask,
+                                                            const int* __restrict__ rle_counts,
+                                                            const long long* __restrict__ rle_offsets, int B, int HW,
+                                                            int step, int shift, unsigned* __restrict__ keys) {
+  const int lane = threadIdx.x & 63;
+  const int inst = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (inst >= B) return;
+  int c = 0;
+  if (rle_counts) {  // exact: the sum of the ones-runs (odd positions)
+    const long long lo = rle_offsets[inst], hi = rle_offsets[inst + 1];
+    for (long long k = lo + 1 + 2 * lane; k < hi; k += 128) {
+      const int v = rle_counts[k];
+      c += v > 0 ? v : 0;
+    }
+  } else {
+    const u32x4* src = reinterpret_cast<const u32x4*>(mask + (long long)inst * HW);
+    const int ngroups = HW >> 4;
+    for (int g = lane * step; g < ngroups; g += 64 * step) {
+      const u32x4 v = src[g];
+      c += __popc(nz4(v.x)) + __popc(nz4(v.y)) + __popc(nz4(v.z)) + __popc(nz4(v.w));
+    }
+  }
+  c = wave_sum_i(c);
+  if (lane == 0) {
+    unsigned q = (unsigned)c >> shift;
+    if (q > 0x3ffffu) q = 0x3ffffu;
+    keys[inst] = (q << KEY_IDX_BITS) | (unsigned)((1 << KEY_IDX_BITS) - 1 - inst);
+  }
+}
+
+// rank = number of larger keys.  64 instances per workgroup (one per lane); each of the four waves counts over a
+// quarter of the batch, 64 keys at a time: one coalesced load, then 64 register broadcasts (v_readlane) - no
+// dependent memory access inside the counting loop.
+__global__ __launch_bounds__(256) void launch_order_kernel(const unsigned* __restrict__ keys, int B, int resident,
+                                                           int* __restrict__ perm) {
+  __shared__ int part[4][64];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = blockIdx.x * 64 + lane;
+  const unsigned mine = i < B ? keys[i] : 0xffffffffu;
+  const int chunk = (((B + 3) >> 2) + 63) & ~63;
+  const int j0 = w * chunk, j1 = (j0 + chunk < B) ? j0 + chunk : B;
+  int cnt = 0;
+  for (int j = j0; j < j1; j += 64) {
+    const unsigned v = (j + lane < j1) ? keys[j + lane] : 0u;  // key 0 never counts (no key is smaller than 0)
+#pragma unroll
+    for (int t = 0; t < 64; ++t) cnt += ((unsigned)__builtin_amdgcn_readlane((int)v, t) > mine) ? 1 : 0;
+  }
+  part[w][lane] = cnt;
+  __syncthreads();
+  if (w == 0 && i < B) {
+    const int rank = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+    int blk = rank;
+    const int R = B < resident ? B : resident;
+    if (rank < R) {
+      const int g = rank >> 8, pos = rank & 255;
+      const int ng = (R - (g << 8)) < 256 ? (R - (g << 8)) : 256;
+      blk = (g << 8) + ((g & 1) ? ng - 1 - pos : pos);
+    }
+    perm[blk] = i;
+  }
+}
+
+inline bool balance_enabled() {
+  const char* e = getenv("LA3D_BALANCE");  // measurement / test switch: 0 = plain XCD-strided order
+  return !(e && e[0] == '0');
+}
+
+inline int balance_max_rounds() {
+  const char* e = getenv("LA3D_BALANCE_ROUNDS");  // measurement switch: batches up to this many resident sets are ordered
+  const int v = e ? atoi(e) : 0;
+  return v > 0 ? v : 3;  // measured: +21 % at one resident set, +9 % at two, +3 % at three, none at four, negative beyond
+}
+
 template <bool VEC, bool LDSMASK, bool SAMPLE, bool TILED = false>
-int launch_fit(const FitParams& p, size_t lds, hipStream_t s) {
+int launch_fit(const FitParams& p_in, size_t lds, hipStream_t s, void* workspace = nullptr) {
   auto kern = fit_instances_kernel<VEC, LDSMASK, SAMPLE, TILED>;
   static bool attr_done = false;  // one flag per instantiation
   if (!attr_done) {
@@ -1071,6 +1162,31 @@ int launch_fit(const FitParams& p, size_t lds, hipStream_t s) {
       (void)hipGetLastError();
     }
     attr_done = true;
+  }
+  FitParams p = p_in;
+  p.perm = nullptr;
+  // size-balanced launch order: needs the 16-byte mask groups (VEC), more than one workgroup per CU, and a batch
+  // the O(B^2) ranking is cheap for
+  if (workspace && VEC && !SAMPLE && p.B > 256 && p.B <= ORDER_MAX_B && balance_enabled()) {
+    const int max_rounds = balance_max_rounds();
+    int wg_per_cu = 2048 / NT;  // wave slots: 32 per CU
+    const int by_lds = (int)((160 * 1024) / (lds ? lds : 1));
+    if (by_lds < wg_per_cu) wg_per_cu = by_lds;
+    if (wg_per_cu >= 1 && p.B <= max_rounds * wg_per_cu * 256) {
+      unsigned* est = static_cast<unsigned*>(workspace);  // [B] area estimates, then [B] block -> instance
+      int* perm = reinterpret_cast<int*>(est + p.B);
+      // quantise the area to 18 bits: run lengths give the exact area (<= HW), the byte lattice about HW / 67
+      int step = 1;
+      for (int cand : {EST_STEP, 31, 13, 7, 3})
+        if ((p.HW >> 4) / cand >= 256) { step = cand; break; }
+      long long amax = p.rle_counts ? (long long)p.HW : (long long)p.HW / step + 16;
+      int shift = 0;
+      while ((amax >> shift) > 0x3ffff) ++shift;
+      hipLaunchKernelGGL(size_estimate_kernel, dim3((p.B + 3) / 4), dim3(256), 0, s, p.mask, p.rle_counts, p.rle_offsets, p.B,
+                         p.HW, step, shift, est);
+      hipLaunchKernelGGL(launch_order_kernel, dim3((p.B + 63) / 64), dim3(256), 0, s, est, p.B, wg_per_cu * 256, perm);
+      p.perm = perm;
+    }
   }
   hipLaunchKernelGGL(kern, dim3(p.B), dim3(NT), lds, s, p);
   return check_launch("fit_instances_kernel");
@@ -1153,6 +1269,7 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   p.rcpW = 1.0f / (float)W;
   p.out = out; p.status = status; p.aux = aux;
   p.ntx = p.nty = p.tiles_per_wave = p.list_cap = 0;
+  p.perm = nullptr;
   const int bit_bytes = ((((p.HW + 15) / 16 + 1) / 2) * 4 + 15) & ~15;  // u16 per 16 px, padded to u32, 16-aligned
   const bool ldsmask = bit_bytes <= MAX_MASK_LDS;
   p.mask_lds_bytes = ldsmask ? bit_bytes : 0;
@@ -1196,10 +1313,10 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
     if (cap > ntiles) cap = ntiles;
     if (cap >= 64) {
       p.list_cap = (int)cap;
-      return launch_fit<true, true, false, true>(p, fixed + (size_t)cap * 2, s);
+      return launch_fit<true, true, false, true>(p, fixed + (size_t)cap * 2, s, workspace);
     }
   }
-  if (ldsmask) return vec ? launch_fit<true, true, false>(p, lds, s) : launch_fit<false, true, false>(p, lds, s);
+  if (ldsmask) return vec ? launch_fit<true, true, false>(p, lds, s, workspace) : launch_fit<false, true, false>(p, lds, s);
   return vec ? launch_fit<true, false, false>(p, lds, s) : launch_fit<false, false, false>(p, lds, s);
 }
 

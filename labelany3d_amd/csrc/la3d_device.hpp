@@ -305,6 +305,7 @@ struct FitParams {
   int ntx, nty;        // TILED: tiles of 32 px x 8 rows (ntx = W/32, nty = ceil(H/8))
   int tiles_per_wave;  // TILED: ceil(ntx*nty / NWAVE)
   int list_cap;        // TILED: entries of the active-tile list that fit the LDS budget
+  const int* perm;     // launch order: workgroup b fits instance perm[b] (nullptr: xcd_remap(b))
   double* out;
   int* status;
   double* aux;

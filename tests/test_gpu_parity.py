@@ -492,3 +492,57 @@ def test_full_size_properties(la, engine):
     for i in range(0, B, 128):
         rec, st, a = O.fit_instance(np_(depth[i]), np_(masks[i]), K640)
         assert_records(np_(b1[i])[None], rec[None], f"big{i}")
+
+
+# ------------------------------------------------------------------------------------------
+# size-balanced launch order (instance engine, 256 < B <= 3 resident sets): which workgroup fits which
+# instance must not change a single bit of any record
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B", [300, 400, 777, 1024, 1300])
+def test_launch_order_is_invisible(la, B, monkeypatch):
+    import torch
+
+    from labelany3d_amd import InstanceFitter
+    from labelany3d_amd.masks import fit_instances_rle
+    from oracle import la3d_oracle as O2
+
+    monkeypatch.setenv("LA3D_ENGINE", "instance")
+    rs = np.random.RandomState(B)
+    H, W = 96, 128
+    depth = torch.as_tensor(rs.uniform(0.5, 10, (B, H, W)).astype(np.float32), device="cuda")
+    m = np.zeros((B, H, W), np.uint8)
+    for i in range(B):
+        h, w = rs.randint(1, H + 1), rs.randint(1, W + 1)
+        r0, c0 = rs.randint(0, H - h + 1), rs.randint(0, W - w + 1)
+        m[i, r0:r0 + h, c0:c0 + w] = rs.randint(1, 256)
+    m[5] = 0  # an empty mask keeps its status wherever it is launched
+    masks = torch.as_tensor(m, device="cuda")
+    K = np.array([[100.0, 0, 64], [0, 100.0, 48], [0, 0, 1]])
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("LA3D_BALANCE", flag)
+        f = InstanceFitter(B, H, W, torch.device("cuda", 0))
+        f.workspace.zero_()
+        b, s, a = f.run(depth, masks, torch.as_tensor(K, device="cuda"))
+        torch.cuda.synchronize()
+        out[flag] = (b.clone(), s.clone(), a.clone())
+        if flag == "1":  # the order the library chose is a permutation, largest estimated area first
+            ws = f.workspace[0][: 8 * B].view(torch.int32).cpu().numpy()
+            keys, perm = ws[:B].astype(np.int64), ws[B:]
+            assert sorted(perm.tolist()) == list(range(B))
+            area = (m.reshape(B, -1) != 0).sum(1)
+            assert np.corrcoef(keys >> 14, area)[0, 1] > 0.9
+            assert area[perm[0]] >= np.percentile(area, 99) * 0.8
+    for x, y in zip(out["0"], out["1"]):
+        assert torch.equal(x, y, ) or torch.equal(torch.nan_to_num(x, nan=-7.0), torch.nan_to_num(y, nan=-7.0))
+    assert int(out["1"][1][5]) == 1 and int((out["1"][1] != 0).sum()) == 1
+    # run-length input takes the same ordering path with exact areas
+    rles = [O2.rle_encode(m[i] != 0) for i in range(B)]
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("LA3D_BALANCE", flag)
+        b, s, a = fit_instances_rle(depth, rles, K)
+        res[flag] = (b.clone(), s.clone())
+    assert torch.equal(torch.nan_to_num(res["0"][0], nan=-7.0), torch.nan_to_num(res["1"][0], nan=-7.0))
+    assert torch.equal(res["0"][1], res["1"][1])
+    assert torch.allclose(torch.nan_to_num(res["1"][0], nan=-7.0), torch.nan_to_num(out["1"][0], nan=-7.0), rtol=1e-12, atol=1e-12)
