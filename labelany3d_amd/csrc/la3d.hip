@@ -1071,9 +1071,9 @@ constexpr int MAX_MASK_LDS = 128 * 1024;  // bit image budget; larger frames re-
 // order (longest-first list scheduling for the dynamically placed remainder).  Same multiset of sizes on B=1024:
 // 152 us unordered, 113 us snake-ordered (host-arranged), 196 us worst case.
 // ------------------------------------------------------------------------------------------
-constexpr int EST_STEP = 67;        // area estimate: every 67th 16-byte group of the plane (67 is coprime to W/16 = 40,
-                                    // 80, 120: the lattice visits every column group); small frames take a smaller
-                                    // prime so that about 256 groups are still sampled
+constexpr int EST_STEP = 37;        // area estimate: every 37th 128-byte line of the plane (37 is coprime to W/128 = 5, 10,
+                                    // 15: the lattice visits every column block); small frames take a smaller prime so
+                                    // that at least 64 lines are sampled
 constexpr int ORDER_MAX_B = 16384;  // the ranking is O(B^2 / lanes); beyond this dynamic placement averages well enough
 constexpr int KEY_IDX_BITS = 14;    // sort key = (area quantised to 18 bits) << 14 | (16383 - instance): unique, and a
                                     // plain unsigned compare orders by area descending, then index ascending
@@ -1093,11 +1093,19 @@ __global__ __launch_bounds__(256) void size_estimate_kernel(const unsigned char*
       c += v > 0 ? v : 0;
     }
   } else {
+    // whole 128-byte lines (HBM delivers nothing smaller): every step-th line of the plane, eight lanes per line,
+    // eight lines per lane in flight (VGA: 65 of 2400 lines, one batch)
     const u32x4* src = reinterpret_cast<const u32x4*>(mask + (long long)inst * HW);
-    const int ngroups = HW >> 4;
-    for (int g = lane * step; g < ngroups; g += 64 * step) {
-      const u32x4 v = src[g];
-      c += __popc(nz4(v.x)) + __popc(nz4(v.y)) + __popc(nz4(v.z)) + __popc(nz4(v.w));
+    const int nlines = HW >> 7, sub = lane & 7;
+    for (int l0 = (lane >> 3) * step; l0 < nlines; l0 += 64 * step) {
+      u32x4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int l = l0 + k * 8 * step;
+        v[k] = (l < nlines) ? src[l * 8 + sub] : u32x4{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) c += __popc(nz4(v[k].x)) + __popc(nz4(v[k].y)) + __popc(nz4(v[k].z)) + __popc(nz4(v[k].w));
     }
   }
   c = wave_sum_i(c);
@@ -1108,28 +1116,38 @@ __global__ __launch_bounds__(256) void size_estimate_kernel(const unsigned char*
   }
 }
 
-// rank = number of larger keys.  64 instances per workgroup (one per lane); each of the four waves counts over a
-// quarter of the batch, 64 keys at a time: one coalesced load, then 64 register broadcasts (v_readlane) - no
-// dependent memory access inside the counting loop.
-__global__ __launch_bounds__(256) void launch_order_kernel(const unsigned* __restrict__ keys, int B, int resident,
-                                                           int* __restrict__ perm) {
-  __shared__ int part[4][64];
+// rank = number of larger keys.  64 instances per workgroup (one per lane); each of the 16 waves counts over a
+// sixteenth of the batch, 64 keys at a time: coalesced loads issued up front, then register broadcasts
+// (v_readlane) - no dependent memory access inside the counting loop.
+constexpr int ORDER_WAVES = 16;
+__global__ __launch_bounds__(ORDER_WAVES * 64) void launch_order_kernel(const unsigned* __restrict__ keys, int B, int resident,
+                                                                        int* __restrict__ perm) {
+  __shared__ int part[ORDER_WAVES][64];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = blockIdx.x * 64 + lane;
   const unsigned mine = i < B ? keys[i] : 0xffffffffu;
-  const int chunk = (((B + 3) >> 2) + 63) & ~63;
+  const int chunk = (((B + ORDER_WAVES - 1) / ORDER_WAVES) + 63) & ~63;
   const int j0 = w * chunk, j1 = (j0 + chunk < B) ? j0 + chunk : B;
   int cnt = 0;
-  for (int j = j0; j < j1; j += 64) {
-    const unsigned v = (j + lane < j1) ? keys[j + lane] : 0u;  // key 0 never counts (no key is smaller than 0)
+  for (int j = j0; j < j1; j += 256) {
+    unsigned v[4];
 #pragma unroll
-    for (int t = 0; t < 64; ++t) cnt += ((unsigned)__builtin_amdgcn_readlane((int)v, t) > mine) ? 1 : 0;
+    for (int k = 0; k < 4; ++k) v[k] = (j + k * 64 + lane < j1) ? keys[j + k * 64 + lane] : 0u;  // key 0 never counts
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (j + k * 64 < j1) {  // wave-uniform
+#pragma unroll
+        for (int t = 0; t < 64; ++t) cnt += ((unsigned)__builtin_amdgcn_readlane((int)v[k], t) > mine) ? 1 : 0;
+      }
+    }
   }
   part[w][lane] = cnt;
   __syncthreads();
   if (w == 0 && i < B) {
-    const int rank = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+    int rank = 0;
+#pragma unroll
+    for (int k = 0; k < ORDER_WAVES; ++k) rank += part[k][lane];
     int blk = rank;
     const int R = B < resident ? B : resident;
     if (rank < R) {
@@ -1177,14 +1195,15 @@ int launch_fit(const FitParams& p_in, size_t lds, hipStream_t s, void* workspace
       int* perm = reinterpret_cast<int*>(est + p.B);
       // quantise the area to 18 bits: run lengths give the exact area (<= HW), the byte lattice about HW / 67
       int step = 1;
-      for (int cand : {EST_STEP, 31, 13, 7, 3})
-        if ((p.HW >> 4) / cand >= 256) { step = cand; break; }
-      long long amax = p.rle_counts ? (long long)p.HW : (long long)p.HW / step + 16;
+      for (int cand : {EST_STEP, 31, 17, 7, 3})
+        if ((p.HW >> 7) / cand >= 64) { step = cand; break; }
+      long long amax = p.rle_counts ? (long long)p.HW : (long long)p.HW / step + 128;
       int shift = 0;
       while ((amax >> shift) > 0x3ffff) ++shift;
       hipLaunchKernelGGL(size_estimate_kernel, dim3((p.B + 3) / 4), dim3(256), 0, s, p.mask, p.rle_counts, p.rle_offsets, p.B,
                          p.HW, step, shift, est);
-      hipLaunchKernelGGL(launch_order_kernel, dim3((p.B + 63) / 64), dim3(256), 0, s, est, p.B, wg_per_cu * 256, perm);
+      hipLaunchKernelGGL(launch_order_kernel, dim3((p.B + 63) / 64), dim3(ORDER_WAVES * 64), 0, s, est, p.B, wg_per_cu * 256,
+                         perm);
       p.perm = perm;
     }
   }

@@ -11,7 +11,7 @@ from collections import defaultdict
 
 def short(name):
     for k in ("fit_instances_kernel", "fit_points_kernel", "prep_kernel", "unproject_kernel", "mask_counts_kernel",
-              "scan_kernel", "plan_kernel", "walk_kernel", "axis_kernel", "final_kernel", "geo_kernel"):
+              "size_estimate_kernel", "launch_order_kernel", "scan_kernel", "plan_kernel", "walk_kernel", "axis_kernel", "final_kernel", "geo_kernel"):
         if k in name:
             i = name.find(k)
             return name[i:].split("(")[0][:70]
