@@ -317,6 +317,16 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
     for (int i = 0; i < 9; ++i) sh->Rg[i] = Rg[i];
   }
 
+#ifdef LA3D_TIMELINE
+  // measurement build only (profiles/timeline.py): wall-clock stamps (100 MHz) per workgroup at the phase boundaries,
+  // into the workspace behind the launch-order arrays
+  double* tl = p.geo + 1024 + (long long)inst * 8;
+#define LA3D_STAMP(k) do { if (tid == 0) tl[k] = (double)wall_clock64(); } while (0)
+  if (tid == 0) tl[7] = (double)blockIdx.x;
+#else
+#define LA3D_STAMP(k) do { } while (0)
+#endif
+  LA3D_STAMP(0);
   // ---- phase 0: u8 mask plane -> bit image in LDS --------------------------------------
   int nmask = 0;
   if (LDSMASK && p.rle_counts != nullptr) {
@@ -359,6 +369,7 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
     if ((ngroups & 1) && tid == 0) b16[ngroups] = 0;  // upper half of the last 32-bit word
   }
   __syncthreads();
+  LA3D_STAMP(1);
   double Mg[9];   // wave-uniform: moved to SGPRs
 #pragma unroll
   for (int i = 0; i < 9; ++i) Mg[i] = uniform_f64(sh->M[i]);
@@ -400,6 +411,7 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
     __syncthreads();
   }
 
+  LA3D_STAMP(2);
   // ---- pass A: moments ------------------------------------------------------------------
   double acc[5] = {0, 0, 0, 0, 0};
   int cnt = 0;
@@ -473,7 +485,9 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
   if (tid == 0) { cnt = 2; acc[0] = 1; acc[1] = 2; acc[2] = 3; acc[3] = 1; acc[4] = 5; }
 #endif
 
+  LA3D_STAMP(3);
   stage_moments_to_axis(sh, p, inst, acc, cnt, nmask, tid, wave, lane);
+  LA3D_STAMP(4);
   if (sh->st != LA3D_BOX_OK) return;
 
   // ---- pass B: extents along the principal axes -----------------------------------------
@@ -497,7 +511,9 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
     ext[0] = 0; ext[1] = 1; ext[2] = 0; ext[3] = 1; ext[4] = 0; ext[5] = 1;
 #endif
   }
+  LA3D_STAMP(5);
   stage_extents_to_box(sh, p, inst, ext, tid, wave, lane);
+  LA3D_STAMP(6);
 }
 
 // ------------------------------------------------------------------------------------------

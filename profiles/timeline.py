@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Per-workgroup phase timeline of the instance engine (measurement build: -DLA3D_TIMELINE, see profiles/timeline.sh).
+Every workgroup stamps wall_clock64() (100 MHz) at its phase boundaries; this prints when the phases start and end
+relative to the first workgroup's start.    python profiles/timeline.py [B ...]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+os.environ["LA3D_ENGINE"] = "instance"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from labelany3d_amd import InstanceFitter  # noqa: E402
+
+H, W = 480, 640
+dev = torch.device("cuda", 0)
+K = torch.tensor([[500.0, 0, 320], [0, 500.0, 240], [0, 0, 1]], dtype=torch.float64, device=dev)
+names = ["start", "stream done", "list done", "pass A (wave 0)", "axis done", "pass B (wave 0)", "end"]
+
+
+def one(B, sizes="bench"):
+    rs = np.random.RandomState(1234)
+    depth = torch.rand((B, H, W), device=dev) * 9.5 + 0.5
+    masks = torch.zeros((B, H, W), dtype=torch.uint8, device=dev)
+    for i in range(B):
+        h, w = (rs.randint(8, 301), rs.randint(8, 331)) if sizes == "bench" else (154, 169)
+        r0, c0 = rs.randint(0, H - h + 1), rs.randint(0, W - w + 1)
+        masks[i, r0:r0 + h, c0:c0 + w] = 1
+    f = InstanceFitter(B, H, W, dev)
+    for _ in range(5):
+        f.run(depth, masks, K)
+    torch.cuda.synchronize()
+    tl = f.workspace[0][8192: 8192 + B * 64].view(torch.float64).cpu().numpy().reshape(B, 8)
+    t = (tl[:, :7] - tl[:, 0].min()) / 100.0  # us
+    print(f"\n== B={B} sizes={sizes}: launch-relative times in us (min / mean / max over workgroups)")
+    for k, n in enumerate(names):
+        print(f"  {n:18s} {t[:, k].min():7.1f} {t[:, k].mean():7.1f} {t[:, k].max():7.1f}")
+    d = np.diff(t, axis=1)
+    print("  durations: " + "  ".join(f"{n}={d[:, k].mean():.1f} (max {d[:, k].max():.1f})"
+                                      for k, n in enumerate(["stream", "list", "passA", "axis", "passB", "box"])))
+
+
+for B in [int(a) for a in sys.argv[1:]] or [16, 1024]:
+    one(B)
+    one(B, "mean")
+
+if os.environ.get("TL_DETAIL"):
+    B = 1024
+    rs = np.random.RandomState(1234)
+    depth = torch.rand((B, H, W), device=dev) * 9.5 + 0.5
+    masks = torch.zeros((B, H, W), dtype=torch.uint8, device=dev)
+    for i in range(B):
+        h, w = rs.randint(8, 301), rs.randint(8, 331)
+        r0, c0 = rs.randint(0, H - h + 1), rs.randint(0, W - w + 1)
+        masks[i, r0:r0 + h, c0:c0 + w] = 1
+    f = InstanceFitter(B, H, W, dev)
+    for _ in range(5):
+        f.run(depth, masks, K)
+    torch.cuda.synchronize()
+    tl = f.workspace[0][8192: 8192 + B * 64].view(torch.float64).cpu().numpy().reshape(B, 8)
+    t = (tl[:, :7] - tl[:, 0].min()) / 100.0
+    blk = tl[:, 7].astype(int)
+    order = np.argsort(blk)
+    t = t[order]
+    print("\nstart time percentiles (us):", np.percentile(t[:, 0], [10, 25, 50, 75, 90, 95, 99, 100]).round(1))
+    print("end   time percentiles (us):", np.percentile(t[:, 6], [10, 25, 50, 75, 90, 95, 99, 100]).round(1))
+    for g in range(4):
+        sl = slice(g * 256, (g + 1) * 256)
+        print(f"blocks {g*256:4d}..{g*256+255:4d}: start mean {t[sl, 0].mean():5.1f} max {t[sl, 0].max():5.1f} | stream done mean {t[sl, 1].mean():5.1f} | end mean {t[sl, 6].mean():5.1f} max {t[sl, 6].max():5.1f}")
+    for x in range(8):
+        sl = np.arange(B)[np.arange(B) % 8 == x]
+        print(f"XCD {x}: start mean {t[sl, 0].mean():5.1f} max {t[sl, 0].max():5.1f} | end mean {t[sl, 6].mean():5.1f} max {t[sl, 6].max():5.1f}")
+    late = np.argsort(-t[:, 6])[:8]
+    print("latest finishers (block, start, stream, list, passA, axis, passB, end):")
+    for b in late:
+        print("  ", b, t[b].round(1))
