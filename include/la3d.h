@@ -117,6 +117,12 @@ int la3d_rle_decode(const int32_t* counts, const int64_t* offsets, int B, int H,
  * pixels inside the four `boundary`-px border strips with corners counted twice (analyze_mask, :303-322). */
 int la3d_mask_stats(const uint8_t* mask, int B, int H, int W, int boundary, int32_t* stats, void* stream);
 
+/* The same four quantities straight from COCO run lengths (layout as la3d_fit_instances_rle), by interval arithmetic on
+ * the runs: no mask plane is decoded.  Replaces mask_utils.decode + np.any/np.sum + analyze_mask for RLE annotations
+ * (src/util.py:364-376).  H <= 32768, H*W <= 2^30. */
+int la3d_mask_stats_rle(const int32_t* counts, const int64_t* offsets, int B, int H, int W, int boundary, int32_t* stats,
+                        void* stream);
+
 /* HOST helper: COCO compressed RLE string (pycocotools rleFrString) -> run lengths.  Returns the number of
  * counts written, or -1 (malformed string / cap too small). */
 int la3d_rle_from_string_host(const char* s, int64_t len, int32_t* counts, int cap);

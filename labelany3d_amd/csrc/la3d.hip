@@ -887,6 +887,169 @@ __global__ __launch_bounds__(256) void mask_stats_kernel(const unsigned char* __
   }
 }
 
+// ---- the same four quantities, wide loads and run-length input -------------------------------------------------
+// Shared tail: rowv[r] != 0 <=> row r holds a pixel.  Returns rows / first / last over the workgroup (256 threads);
+// red: LDS, 3 x 4 ints.
+__device__ inline void rows_summary(const int* rowv, int H, int* red, int tid, int* rows_out, int* span_out) {
+  const int lane = tid & 63, wave = tid >> 6;
+  int rows = 0, first = H, last = -1;
+  for (int r = tid; r < H; r += 256)
+    if (rowv[r] != 0) { rows += 1; first = min(first, r); last = max(last, r); }
+  rows = wave_sum_i(rows);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { first = min(first, __shfl_xor(first, o)); last = max(last, __shfl_xor(last, o)); }
+  if (lane == 0) { red[wave] = rows; red[4 + wave] = first; red[8 + wave] = last; }
+  __syncthreads();
+  int rw = 0, f = H, l = -1;
+  for (int w = 0; w < 4; ++w) { rw += red[w]; f = min(f, red[4 + w]); l = max(l, red[8 + w]); }
+  *rows_out = rw;
+  *span_out = (l >= f) ? l - f + 1 : 0;
+}
+
+// u8 planes with W % 16 == 0 and 16-byte aligned planes: 16 pixels per load, four loads in flight per lane, per-row
+// pixel counts accumulated in LDS (one atomic per non-empty group).  Dynamic LDS: H ints.
+__global__ __launch_bounds__(256) void mask_stats_vec_kernel(const unsigned char* __restrict__ mask, int H, int W, int boundary,
+                                                             int* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int* rowcnt = reinterpret_cast<int*>(smem);
+  __shared__ int red[12];
+  __shared__ int tot[4][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int r = tid; r < H; r += 256) rowcnt[r] = 0;
+  __syncthreads();
+  const u32x4* m4 = reinterpret_cast<const u32x4*>(mask + (long long)blockIdx.x * H * W);
+  const int gpr = W >> 4, ngroups = H * gpr;
+  const int step_row = 256 / gpr, step_col = 256 % gpr;
+  const int bc = min(boundary, W);
+  int row = tid / gpr, col = tid - row * gpr;
+  int area = 0, edge = 0;
+#pragma unroll 4
+  for (int g = tid; g < ngroups; g += 256) {
+    const u32x4 w = __builtin_nontemporal_load(m4 + g);
+    const unsigned pat = nz4(w.x) | (nz4(w.y) << 4) | (nz4(w.z) << 8) | (nz4(w.w) << 12);
+    if (pat) {
+      const int c0 = col << 4, n = __popc(pat);
+      area += n;
+      atomicAdd(&rowcnt[row], n);
+      const int nlo = min(max(bc - c0, 0), 16), fhi = min(max(W - bc - c0, 0), 16);
+      edge += __popc(pat & ((1u << nlo) - 1u)) + __popc(pat & (0xffffu & ~((1u << fhi) - 1u)));
+    }
+    col += step_col; row += step_row;
+    if (col >= gpr) { col -= gpr; ++row; }
+  }
+  __syncthreads();
+  // top / bottom strips from the row counts (a row inside both strips counts twice, as m[:b].sum() + m[-b:].sum() does)
+  const int br = min(boundary, H);
+  for (int r = tid; r < H; r += 256) {
+    const int k = (r < br ? 1 : 0) + (r >= H - br ? 1 : 0);
+    if (k) edge += k * rowcnt[r];
+  }
+  area = wave_sum_i(area);
+  edge = wave_sum_i(edge);
+  if (lane == 0) { tot[wave][0] = area; tot[wave][1] = edge; }
+  int rows, span;
+  rows_summary(rowcnt, H, red, tid, &rows, &span);  // has the barrier that publishes tot
+  if (tid == 0) {
+    int* o = stats + (long long)blockIdx.x * 4;
+    o[0] = tot[0][0] + tot[1][0] + tot[2][0] + tot[3][0];
+    o[1] = rows; o[2] = span;
+    o[3] = tot[0][1] + tot[1][1] + tot[2][1] + tot[3][1];
+  }
+}
+
+// COCO run lengths (column-major, zeros first): no plane is decoded.  A ones-run is the interval [s, e) of the
+// column-major pixel index i = col * H + row, so every quantity is interval arithmetic: area = sum of lengths; the
+// left / right strips are the index ranges [0, b*H) and [(W-b)*H, W*H); the top / bottom strips are the residues
+// i mod H in [0, b) and [H-b, H), counted in closed form; row presence goes through a difference array over rows
+// (two LDS atomics per run) and one prefix scan.  Dynamic LDS: H + 1 ints.
+__device__ inline long long strip_rows_below(long long x, int H, int br) {  // pixels i < x with i mod H in the two row strips
+  const long long q = x / H;
+  const int r = (int)(x - q * H);
+  return q * 2 * br + min(r, br) + max(0, r - (H - br));
+}
+
+__global__ __launch_bounds__(256) void mask_stats_rle_kernel(const int* __restrict__ counts, const long long* __restrict__ offsets,
+                                                             int H, int W, int boundary, int* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int* diff = reinterpret_cast<int*>(smem);  // [H + 1]
+  __shared__ int red[12];
+  __shared__ unsigned wtot[4];
+  __shared__ long long tot[4][2];
+  __shared__ int full;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long o0 = offsets[blockIdx.x];
+  const int nr = (int)(offsets[blockIdx.x + 1] - o0);
+  const int* cnt = counts + o0;
+  const long long HW = (long long)H * W;
+  for (int r = tid; r <= H; r += 256) diff[r] = 0;
+  if (tid == 0) full = 0;
+  const int bc = min(boundary, W), br = min(boundary, H);
+  const long long left_end = (long long)bc * H, right_beg = (long long)(W - bc) * H;
+  long long area = 0, edge = 0;
+  unsigned long long carry = 0;
+  for (int c0 = 0; c0 < nr; c0 += 256) {
+    const int j = c0 + tid;
+    unsigned len = 0;
+    if (j < nr) { const int v = cnt[j]; len = v > 0 ? (unsigned)v : 0u; }
+    unsigned incl = len;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    __syncthreads();  // previous step's readers of wtot are done; the zeroing of diff is ordered
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    unsigned long long base = carry, total = 0;
+    for (int w = 0; w < 4; ++w) { if (w < wave) base += wtot[w]; total += wtot[w]; }
+    const long long s = (long long)(base + incl - len);
+    carry += total;
+    if ((j & 1) && len > 0 && s < HW) {
+      const long long e = min(s + (long long)len, HW);
+      area += e - s;
+      edge += max(0LL, min(e, left_end) - s) + max(0LL, e - max(s, right_beg));
+      edge += strip_rows_below(e, H, br) - strip_rows_below(s, H, br);
+      if (e - s >= H) {
+        full = 1;  // every row holds a pixel
+      } else {
+        const int r0 = (int)(s % H), r1 = (int)((e - 1) % H);
+        if (r0 <= r1) { atomicAdd(&diff[r0], 1); atomicAdd(&diff[r1 + 1], -1); }
+        else { atomicAdd(&diff[r0], 1); atomicAdd(&diff[H], -1); atomicAdd(&diff[0], 1); atomicAdd(&diff[r1 + 1], -1); }
+      }
+    }
+    if (carry >= (unsigned long long)HW) break;  // uniform: later runs fall outside the frame
+  }
+  __syncthreads();
+  // prefix scan of the difference array in place (chunk per thread, chunk sums scanned through LDS)
+  const int per = (H + 255) / 256, rb = min(tid * per, H), re = min(rb + per, H);
+  int csum = 0;
+  for (int r = rb; r < re; ++r) csum += diff[r];
+  int incl = csum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wtot[wave] = (unsigned)incl;
+  __syncthreads();
+  int run = incl - csum;
+  for (int w = 0; w < wave; ++w) run += (int)wtot[w];
+  const int all_rows = full;
+  for (int r = rb; r < re; ++r) { run += diff[r]; diff[r] = (run > 0 || all_rows) ? 1 : 0; }
+  // publish the sums, then rows / span (rows_summary's barrier orders the diff writes and tot)
+  for (int o = 32; o > 0; o >>= 1) { area += __shfl_xor(area, o); edge += __shfl_xor(edge, o); }
+  if (lane == 0) { tot[wave][0] = area; tot[wave][1] = edge; }
+  __syncthreads();
+  int rows, span;
+  rows_summary(diff, H, red, tid, &rows, &span);
+  if (tid == 0) {
+    int* o = stats + (long long)blockIdx.x * 4;
+    o[0] = (int)(tot[0][0] + tot[1][0] + tot[2][0] + tot[3][0]);
+    o[1] = rows; o[2] = span;
+    o[3] = (int)(tot[0][1] + tot[1][1] + tot[2][1] + tot[3][1]);
+  }
+}
+
 // Box consumers (reference src/tools/combine_results.py:105-108, :238-252): project the 8 corners of every
 // record with its image's K, 2-D AABB and its clamp to the frame.  One thread per box.
 __global__ __launch_bounds__(128) void project_boxes_kernel(const double* __restrict__ rec, const double* __restrict__ K,
@@ -1419,14 +1582,42 @@ int la3d_rle_decode(const int32_t* counts, const int64_t* offsets, int B, int H,
   return check_launch("rle_decode_kernel");
 }
 
+static void stats_lds_attr() {  // rows beyond 16 K need more than the default 64 KiB of dynamic LDS
+  static bool done = false;
+  if (done) return;
+  for (const void* k : {reinterpret_cast<const void*>(mask_stats_rle_kernel), reinterpret_cast<const void*>(mask_stats_vec_kernel)})
+    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) (void)hipGetLastError();
+  done = true;
+}
+
 int la3d_mask_stats(const uint8_t* mask, int B, int H, int W, int boundary, int32_t* stats, void* stream) {
   if (!mask || !stats || B < 0 || H <= 0 || W <= 0 || boundary < 0) {
     set_err("la3d_mask_stats: bad argument");
     return LA3D_ERR_ARG;
   }
   if (B == 0) return LA3D_SUCCESS;
+  if (W % 16 == 0 && (reinterpret_cast<uintptr_t>(mask) & 15) == 0 && H <= 32768) {
+    stats_lds_attr();
+    hipLaunchKernelGGL(mask_stats_vec_kernel, dim3(B), dim3(256), (size_t)H * 4, static_cast<hipStream_t>(stream), mask, H, W,
+                       boundary, stats);
+    return check_launch("mask_stats_vec_kernel");
+  }
   hipLaunchKernelGGL(mask_stats_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), mask, H, W, boundary, stats);
   return check_launch("mask_stats_kernel");
+}
+
+int la3d_mask_stats_rle(const int32_t* counts, const int64_t* offsets, int B, int H, int W, int boundary, int32_t* stats,
+                        void* stream) {
+  if ((!counts && B > 0) || !offsets || !stats || B < 0 || H <= 0 || W <= 0 || boundary < 0 || H > 32768 ||
+      (long long)H * W > (1LL << 30)) {
+    set_err("la3d_mask_stats_rle: bad argument (H <= 32768, H*W <= 2^30)");
+    return LA3D_ERR_ARG;
+  }
+  if (B == 0) return LA3D_SUCCESS;
+  stats_lds_attr();
+  hipLaunchKernelGGL(mask_stats_rle_kernel, dim3(B), dim3(256), (size_t)(H + 1) * 4, static_cast<hipStream_t>(stream), counts,
+                     reinterpret_cast<const long long*>(offsets), H, W, boundary, stats);
+  return check_launch("mask_stats_rle_kernel");
 }
 
 int la3d_masked_ratio_median(const float* num, int64_t num_plane_stride, const int32_t* image_index, const float* den,

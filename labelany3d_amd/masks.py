@@ -75,6 +75,21 @@ def mask_stats(masks, boundary_threshold: int = 10, stream=None) -> torch.Tensor
     return out
 
 
+def mask_stats_rle(rles, boundary_threshold: int = 10, stream=None, device=None) -> torch.Tensor:
+    """``mask_stats`` straight from COCO run lengths (a list of RLE objects or the tuple from ``pack_rle``): the four
+    filter quantities by interval arithmetic on the runs, no mask plane is decoded.  With ``keep_instances(...,
+    from_rle=True)`` this is the reference's RLE branch of read_bounding_boxes_segmentations (src/util.py:364-376)."""
+    counts, offsets, H, W = pack_rle(rles)
+    dev = _dev(device)
+    c, o = _as_dev(counts, torch.int32, dev), _as_dev(offsets, torch.int64, dev)
+    B = o.numel() - 1
+    out = torch.empty((B, 4), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.la3d_mask_stats_rle(_ptr(c), _ptr(o), B, H, W, int(boundary_threshold), _ptr(out), _stream(stream)),
+              "la3d_mask_stats_rle")
+    return out
+
+
 def keep_instances(stats: torch.Tensor, image_height: int, from_rle: bool = True, scale_threshold: int = 100) -> torch.Tensor:
     """The reference's keep rule (src/util.py:375): height/H > 0.0625 and truncation < 10 and area >= 100, with
     height = rows holding a pixel for RLE annotations (:368-369) and last-first+1 for polygons (:328-335)."""

@@ -200,3 +200,63 @@ def test_unproject_matches_vs_numpy(la):
     assert np.isnan(np_(pts)[~ok]).all()
     pts2, _ = la.unproject_matches(depth, m1, flip=None)                  # plain pinhole, camera frame
     np.testing.assert_allclose(np_(pts2)[ok][:, 2], d_of[ok])
+
+
+# ------------------------------------------------------------------------------------------
+# the instance filter without a mask plane: stats from the run lengths, and the wide-load plane kernel
+# ------------------------------------------------------------------------------------------
+def _random_masks(rs, B, H, W):
+    m = np.zeros((B, H, W), bool)
+    for i in range(B):
+        kind = i % 6
+        if kind == 0:    # rectangle anywhere (often touching a border)
+            h, w = rs.randint(1, H + 1), rs.randint(1, W + 1)
+            r0, c0 = rs.randint(0, H - h + 1), rs.randint(0, W - w + 1)
+            m[i, r0:r0 + h, c0:c0 + w] = True
+        elif kind == 1:  # salt noise
+            m[i] = rs.rand(H, W) < 0.02
+        elif kind == 2:  # ellipse
+            yy, xx = np.mgrid[0:H, 0:W]
+            m[i] = ((yy - rs.uniform(0, H)) / rs.uniform(2, H / 2)) ** 2 + ((xx - rs.uniform(0, W)) / rs.uniform(2, W / 2)) ** 2 < 1
+        elif kind == 3:  # full columns / full frame: runs longer than H
+            m[i, :, rs.randint(0, W // 2):rs.randint(W // 2, W + 1)] = True
+        elif kind == 4:  # two blobs with a gap of empty rows between them
+            m[i, 1:3, 2:9] = True
+            m[i, H - 5:H - 2, W - 7:W - 1] = True
+        # kind 5: empty
+    return m
+
+
+@pytest.mark.parametrize("H,W,boundary", [(48, 64, 10), (480, 640, 10), (37, 53, 10), (30, 48, 20), (16, 16, 10), (8, 128, 3)])
+def test_mask_stats_rle_and_planes_vs_oracle(la, H, W, boundary):
+    import torch
+
+    rs = np.random.RandomState(H * 1000 + W)
+    B = 24
+    m = _random_masks(rs, B, H, W)
+    want = np.array([O.mask_stats(x, boundary) for x in m])
+    # (a) straight from the runs
+    rles = [O.rle_encode(x) for x in m]
+    got = np_(la.mask_stats_rle(rles, boundary))
+    np.testing.assert_array_equal(got, want)
+    # (b) from u8 planes: 16-byte path when W % 16 == 0, byte path otherwise; any non-zero byte counts
+    planes = torch.as_tensor(m.astype(np.uint8) * rs.randint(1, 256, (B, 1, 1)).astype(np.uint8), device="cuda")
+    np.testing.assert_array_equal(np_(la.mask_stats(planes, boundary)), want)
+    # (c) the keep rule on both
+    for from_rle in (True, False):
+        k1 = np_(la.keep_instances(la.mask_stats_rle(rles, boundary), H, from_rle))
+        assert k1.tolist() == [O.keep_instance(tuple(s), H, from_rle) for s in want]
+
+
+def test_mask_stats_rle_golden_and_compressed_strings(la, golden):
+    g = golden("g8_masks.npz")
+    rles = _g8_rles(g)
+    want = np.array([O.mask_stats(m) for m in g["masks"]])
+    np.testing.assert_array_equal(np_(la.mask_stats_rle(rles)), want)
+    # compressed counts strings (what COCONut annotations carry) go through the host codec first
+    strs = [{"size": r["size"], "counts": O.rle_to_string(r["counts"])} for r in rles]
+    np.testing.assert_array_equal(np_(la.mask_stats_rle(strs)), want)
+    # malformed input: runs beyond the frame are clipped exactly like the decoder clips them
+    over = [{"size": [48, 64], "counts": [10, 48 * 64 + 500]}]
+    dec = np_(la.rle_decode(over))[0]
+    np.testing.assert_array_equal(np_(la.mask_stats_rle(over))[0], np.array(O.mask_stats(dec)))
