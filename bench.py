@@ -277,10 +277,13 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": kern_ms,
                 "traffic": traffic,
+                "traffic_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if (traffic and not args.config3 and not args.rle and B == 1024) else None,
                 "traffic_source": traffic_src,
-                "note": "achieved = 1,536,312 algorithmic B/box x 1024 boxes / HIP-event time per step on the launch "
-                        "stream (max over ranks). The kernel skips depth lines whose mask bits are all zero, so real "
-                        "HBM traffic is below the algorithmic count (see traffic / DESIGN.md).",
+                "note": "achieved = 1,536,312 algorithmic B/box x boxes per launch / HIP-event time per step on the launch "
+                        "stream (max over ranks); a step = the fit kernel plus, for 256 < B <= 3072, its two ~5 us "
+                        "launch-order helper kernels. The kernel skips depth lines whose mask bits are all zero, so real "
+                        "HBM traffic (traffic, PMC-measured at B = 1024) is below the algorithmic count and frac can "
+                        "exceed 1; traffic_GBps = traffic / the same time (see DESIGN.md section 5).",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
