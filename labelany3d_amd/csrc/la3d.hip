@@ -286,7 +286,7 @@ __device__ inline void yaw_rows(const Shared* sh, const double* Mg, double* N0, 
 // ------------------------------------------------------------------------------------------
 // instance engine: one workgroup per instance
 // ------------------------------------------------------------------------------------------
-template <bool VEC, bool LDSMASK, bool SAMPLE, bool TILED>
+template <bool VEC, bool LDSMASK, bool SAMPLE, bool TILED, bool RLE>
 __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned* bits = reinterpret_cast<unsigned*>(smem);
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
   LA3D_STAMP(0);
   // ---- phase 0: u8 mask plane -> bit image in LDS --------------------------------------
   int nmask = 0;
-  if (LDSMASK && p.rle_counts != nullptr) {
+  if (LDSMASK && RLE) {
     // masks arrive as COCO run lengths: decode straight into the LDS bit image — no u8 plane is ever read
     const long long o0 = p.rle_offsets[inst];
     nmask = rle_to_bits<NT>(p.rle_counts + o0, (int)(p.rle_offsets[inst + 1] - o0), bits, p.nwords, p.H, p.W, sh->scan, tid);
@@ -1349,9 +1349,9 @@ inline int balance_max_rounds() {
   return v > 0 ? v : 3;  // measured: +21 % at one resident set, +9 % at two, +3 % at three, none at four, negative beyond
 }
 
-template <bool VEC, bool LDSMASK, bool SAMPLE, bool TILED = false>
-int launch_fit(const FitParams& p_in, size_t lds, hipStream_t s, void* workspace = nullptr) {
-  auto kern = fit_instances_kernel<VEC, LDSMASK, SAMPLE, TILED>;
+template <bool VEC, bool LDSMASK, bool SAMPLE, bool TILED, bool RLE>
+int launch_fit_inst(const FitParams& p_in, size_t lds, hipStream_t s, void* workspace) {
+  auto kern = fit_instances_kernel<VEC, LDSMASK, SAMPLE, TILED, RLE>;
   static bool attr_done = false;  // one flag per instantiation
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1388,6 +1388,13 @@ int launch_fit(const FitParams& p_in, size_t lds, hipStream_t s, void* workspace
   }
   hipLaunchKernelGGL(kern, dim3(p.B), dim3(NT), lds, s, p);
   return check_launch("fit_instances_kernel");
+}
+
+// run-length input is its own instantiation (it needs the LDS bit image), so the u8 kernels carry no decode code
+template <bool VEC, bool LDSMASK, bool SAMPLE, bool TILED = false>
+int launch_fit(const FitParams& p, size_t lds, hipStream_t s, void* workspace = nullptr) {
+  if (LDSMASK && p.rle_counts != nullptr) return launch_fit_inst<VEC, LDSMASK, SAMPLE, TILED, LDSMASK>(p, lds, s, workspace);
+  return launch_fit_inst<VEC, LDSMASK, SAMPLE, TILED, false>(p, lds, s, workspace);
 }
 
 }  // namespace

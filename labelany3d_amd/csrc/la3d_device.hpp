@@ -405,13 +405,57 @@ __device__ inline int rle_to_bits(const int* __restrict__ counts, int nr, unsign
     nm += (int)L;
     carry += total;
     unsigned long long todo = __ballot(L != 0);
-    while (todo) {                         // wave-uniform loop over this wave's ones-runs
+    if ((W & 31) == 0) {
+      // Word-aligned rows: runs that stay inside one column are painted 32 columns at a time.  All runs of this wave whose
+      // column falls into the same 32-px word column form a group; lanes take rows, every run of the group is broadcast
+      // (v_readlane) and contributes its column bit to the rows it covers: one ds_or per 64 rows and word column instead
+      // of one per pixel.
+      const int ntx = W >> 5;
+      unsigned col0, row0;
+      pix_uv(start, H, rcpH, &row0, &col0);
+      const bool single = L != 0 && row0 + L <= (unsigned)H;
+      unsigned long long left = __ballot(single);
+      todo &= ~left;
+      while (left) {                       // wave-uniform loop over word columns
+        const int src = __ffsll((long long)left) - 1;
+        const int cw = (int)((unsigned)__builtin_amdgcn_readlane((int)col0, src) >> 5);
+        const unsigned long long grp = __ballot(single && (int)(col0 >> 5) == cw);
+        left &= ~grp;
+        int rmin = H, rmax = 0;
+        for (unsigned long long m = grp; m; m &= m - 1) {
+          const int k = __ffsll((long long)m) - 1;
+          const int a = __builtin_amdgcn_readlane((int)row0, k), b = a + __builtin_amdgcn_readlane((int)L, k);
+          rmin = min(rmin, a); rmax = max(rmax, b);
+        }
+        for (int wb = rmin; wb < rmax; wb += 512) {   // windows of 8 x 64 rows
+          const int nch = min(8, (rmax - wb + 63) >> 6);
+          unsigned wd[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+          for (unsigned long long m = grp; m; m &= m - 1) {
+            const int k = __ffsll((long long)m) - 1;
+            const int a = __builtin_amdgcn_readlane((int)row0, k), b = a + __builtin_amdgcn_readlane((int)L, k);
+            const unsigned bit = 1u << ((unsigned)__builtin_amdgcn_readlane((int)col0, k) & 31u);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+              if (c < nch) {                 // wave-uniform
+                const int row = wb + c * 64 + lane;
+                wd[c] |= (row >= a && row < b) ? bit : 0u;
+              }
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            if (c < nch && wd[c]) atomicOr(&bits[(wb + c * 64 + lane) * ntx + cw], wd[c]);
+          }
+        }
+      }
+    }
+    while (todo) {                         // wave-uniform loop over the remaining ones-runs (they wrap columns, or W % 32 != 0)
       const int src = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
       const unsigned S = __shfl(start, src), Lr = __shfl(L, src);
       unsigned col0, row0;
       pix_uv(S, H, rcpH, &row0, &col0);     // run start: position = col0 * H + row0 (same in every lane)
-      if (row0 + Lr <= (unsigned)H) {       // the run stays inside one column (the common case): row0+q, col0
+      if (row0 + Lr <= (unsigned)H) {       // the run stays inside one column: row0+q, col0
         const unsigned base = row0 * (unsigned)W + col0;
         for (unsigned q = lane; q < Lr; q += 64) {
           const unsigned idx = base + q * (unsigned)W;

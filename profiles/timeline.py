@@ -22,11 +22,31 @@ def one(B, sizes="bench"):
     rs = np.random.RandomState(1234)
     depth = torch.rand((B, H, W), device=dev) * 9.5 + 0.5
     masks = torch.zeros((B, H, W), dtype=torch.uint8, device=dev)
+    counts, offs = [], [0]
     for i in range(B):
         h, w = (rs.randint(8, 301), rs.randint(8, 331)) if sizes == "bench" else (154, 169)
         r0, c0 = rs.randint(0, H - h + 1), rs.randint(0, W - w + 1)
         masks[i, r0:r0 + h, c0:c0 + w] = 1
+        counts += [int(c0 * H + r0)] + [int(h), int(H - h)] * (int(w) - 1) + [int(h), int((W - c0 - w) * H + (H - r0 - h))]
+        offs.append(len(counts))
     f = InstanceFitter(B, H, W, dev)
+    if os.environ.get("TL_RLE"):  # same masks as COCO run lengths (la3d_fit_instances_rle)
+        import ctypes as C
+
+        from labelany3d_amd._lib import check, lib
+        rc = torch.as_tensor(np.asarray(counts, np.int32), device=dev)
+        ro = torch.as_tensor(np.asarray(offs, np.int64), device=dev)
+        kf = K[None].expand(B, 3, 3).contiguous()
+        st = torch.cuda.current_stream()
+
+        def run_rle(*_):
+            check(lib.la3d_fit_instances_rle(C.c_void_p(depth.data_ptr()), H * W, None, C.c_void_p(rc.data_ptr()),
+                                             C.c_void_p(ro.data_ptr()), C.c_void_p(kf.data_ptr()), 9, None, None, B, H, W,
+                                             C.c_void_p(f.boxes[0].data_ptr()), C.c_void_p(f.status[0].data_ptr()),
+                                             C.c_void_p(f.aux[0].data_ptr()), C.c_void_p(f.workspace[0].data_ptr()),
+                                             C.c_void_p(st.cuda_stream)), "la3d_fit_instances_rle")
+        f.run = run_rle
+        sizes += " (run-length input)"
     for _ in range(5):
         f.run(depth, masks, K)
     torch.cuda.synchronize()
