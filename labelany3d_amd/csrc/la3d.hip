@@ -137,7 +137,7 @@ __device__ inline void sweep(const FitParams& p, const float* __restrict__ dpl, 
 #endif
 constexpr int TG = LA3D_TG;
 
-template <int PASS>
+template <int PASS, bool CHK>
 __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__ dpl, const unsigned* bits,
                                    const unsigned short* list, int nactive, const double* A0, const double* A1,
                                    const double* A2, int wave, int lane, double* acc, int* cnt) {
@@ -186,7 +186,7 @@ __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__
       const double r2 = fma(a20, ud, fma(a21, vd, a22));
       double r1 = 0;
       if (PASS == 1) r1 = fma(a10, ud, fma(a11, vd, a12));
-      quad_math<PASS>(nib[g], db, r0, r1, r2, a00, a10, a20, sv, &n);
+      quad_math<PASS, CHK>(nib[g], db, r0, r1, r2, a00, a10, a20, sv, &n);
     }
   }
 #pragma unroll
@@ -200,8 +200,10 @@ __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__
 // moments of all waves -> thread 0 (fixed order: bit-reproducible) -> status, yaw axis.
 // On return sh->st / sh->cyaw / sh->syaw are valid for every thread.  The aux record (with its atan2) is
 // written afterwards by thread 0 only, off the other waves' critical path.
+// allow_redo: the sums come from the optimistic pass (quad_math<0, false>); if they are not finite, set sh->redo and return
+// without deciding anything - the caller re-runs the checked pass and calls again with allow_redo = false.
 __device__ inline void stage_moments_to_axis(Shared* sh, const FitParams& p, int inst, const double* acc, int cnt,
-                                             int nmask, int tid, int wave, int lane) {
+                                             int nmask, int tid, int wave, int lane, bool allow_redo = false) {
   {
     const double r0 = wave_sum(acc[0]), r1 = wave_sum(acc[1]), r2 = wave_sum(acc[2]), r3 = wave_sum(acc[3]),
                  r4 = wave_sum(acc[4]);
@@ -229,6 +231,8 @@ __device__ inline void stage_moments_to_axis(Shared* sh, const FitParams& p, int
     if (sh->bad_ground) st = LA3D_BOX_BAD_GROUND;
     else if (n == 0) st = LA3D_BOX_EMPTY;
     else if (n == 1) st = LA3D_BOX_TOO_FEW;
+    const double chk = (s[0] + s[1]) + (s[2] + s[3]) + s[4];
+    sh->redo = (allow_redo && !sh->bad_ground && !(fabs(chk) <= 1.79769313486231570815e308)) ? 1 : 0;
     double cy = NAN, sy = NAN;
     if (st == LA3D_BOX_OK) axis_from_sums((double)n, s[0], s[1], s[2], s[3], s[4], &cy, &sy, &gap);
     sh->cyaw = cy; sh->syaw = sy;
@@ -236,6 +240,7 @@ __device__ inline void stage_moments_to_axis(Shared* sh, const FitParams& p, int
     sh->n_valid = n;
   }
   __syncthreads();
+  if (sh->redo) return;  // uniform
   if (tid == 0) {
     const int st = sh->st;
     if (p.aux) {
@@ -476,9 +481,12 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
       }
     }
   }
+  // TILED: optimistic pass first (no per-pixel finite test); a non-finite masked depth shows up as non-finite sums and
+  // the workgroup falls back to the checked passes.  Same records either way.
+  bool checked = !TILED;
 #ifndef LA3D_ABL_NO_PASSA
   if (!sampled) {
-    if (TILED) sweep_tiled<0>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt);
+    if (TILED) sweep_tiled<0, false>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt);
     else sweep<VEC, LDSMASK, 0>(p, dpl, mpl, bits, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, &nmask);
   }
 #else
@@ -486,7 +494,16 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
 #endif
 
   LA3D_STAMP(3);
-  stage_moments_to_axis(sh, p, inst, acc, cnt, nmask, tid, wave, lane);
+  stage_moments_to_axis(sh, p, inst, acc, cnt, nmask, tid, wave, lane, TILED && !sampled);
+  if (TILED && sh->redo) {  // uniform
+    __syncthreads();        // everyone has read sh->redo and the partials before they are rewritten
+#pragma unroll
+    for (int i = 0; i < 5; ++i) acc[i] = 0;
+    cnt = 0;
+    checked = true;
+    sweep_tiled<0, true>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt);
+    stage_moments_to_axis(sh, p, inst, acc, cnt, nmask, tid, wave, lane, false);
+  }
   LA3D_STAMP(4);
   if (sh->st != LA3D_BOX_OK) return;
 
@@ -505,7 +522,10 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
     double N0[3], N2[3];
     yaw_rows(sh, Mg, N0, N2);
     int d0 = 0, d1 = 0;
-    if (TILED) sweep_tiled<1>(p, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0);
+    if (TILED) {
+      if (checked) sweep_tiled<1, true>(p, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0);
+      else sweep_tiled<1, false>(p, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0);
+    }
     else sweep<VEC, LDSMASK, 1>(p, dpl, mpl, bits, N0, Mg + 3, N2, wave, lane, ext, &d0, &d1);
 #else
     ext[0] = 0; ext[1] = 1; ext[2] = 0; ext[3] = 1; ext[4] = 0; ext[5] = 1;

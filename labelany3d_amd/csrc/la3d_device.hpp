@@ -326,7 +326,7 @@ struct alignas(16) Shared {
   int n_valid;
   int st;
   int bad_ground;
-  int pad;
+  int redo;        // optimistic pass A met a non-finite masked depth: run the checked passes
 };
 
 __device__ inline void pix_uv(unsigned i, int W, float rcpW, unsigned* u, unsigned* v) {
@@ -340,14 +340,21 @@ __device__ inline void pix_uv(unsigned i, int W, float rcpW, unsigned* u, unsign
 
 // one pixel quad of a tile: PASS 0 accumulates count + moments, PASS 1 the six extents.
 // r0/r1/r2: ray components at the quad's first pixel; a00/a10/a20: their per-pixel (u+1) increments.
-template <int PASS>
+// CHK = false is the optimistic form: only the mask bit gates a pixel.  Its results are identical to CHK = true as long as
+// every masked depth is finite; a non-finite one turns the fp64 sums of pass 0 into inf/NaN for good (inf and NaN are
+// sticky under + and fma), which the caller detects after the reduce and answers by re-running the checked form.
+template <int PASS, bool CHK = true>
 __device__ inline void quad_math(unsigned nib, const unsigned* db, double r0, double r1, double r2, double a00,
                                  double a10, double a20, double* s, int* n) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    // 0 / -1 validity word: mask bit k set AND exponent field != 0xff
-    const int fin = ((int)(db[k] & 0x7fffffffu) - 0x7f800000) >> 31;
-    const int m = fin & -(int)((nib >> k) & 1u);
+    int m;  // 0 / -1 validity word
+    if (CHK) {  // mask bit k set AND exponent field != 0xff
+      const int fin = ((int)(db[k] & 0x7fffffffu) - 0x7f800000) >> 31;
+      m = fin & -(int)((nib >> k) & 1u);
+    } else {
+      m = -(int)((nib >> k) & 1u);
+    }
     if (PASS == 0) {
       const double d = (double)__uint_as_float(db[k] & (unsigned)m);   // invalid -> +0.0
       const double x = d * r0, z = d * r2;

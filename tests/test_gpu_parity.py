@@ -546,3 +546,38 @@ def test_launch_order_is_invisible(la, B, monkeypatch):
     assert torch.equal(torch.nan_to_num(res["0"][0], nan=-7.0), torch.nan_to_num(res["1"][0], nan=-7.0))
     assert torch.equal(res["0"][1], res["1"][1])
     assert torch.allclose(torch.nan_to_num(res["1"][0], nan=-7.0), torch.nan_to_num(out["1"][0], nan=-7.0), rtol=1e-12, atol=1e-12)
+
+
+def test_nonfinite_depth_in_tiled_frames(la, engine):
+    """The tiled instance kernel runs an optimistic pass without the per-pixel finite test and repeats the checked pass for
+    workgroups whose sums come out non-finite: instances with NaN / +-inf depth under the mask must drop exactly those
+    pixels, like the reference's NaN-row filter (src/util_3dbox.py:139-140), and instances without must be untouched."""
+    rs = np.random.RandomState(11)
+    B, H, W = 10, 128, 256
+    depth = rs.uniform(1, 5, (B, H, W)).astype(np.float32)
+    masks = np.zeros((B, H, W), bool)
+    for i in range(B):
+        h, w = rs.randint(20, 100), rs.randint(20, 200)
+        r0, c0 = rs.randint(0, H - h + 1), rs.randint(0, W - w + 1)
+        masks[i, r0:r0 + h, c0:c0 + w] = True
+        if i % 2:  # poison a few masked pixels of every second instance
+            rr, cc = np.nonzero(masks[i])
+            pick = rs.choice(len(rr), 5, replace=False)
+            depth[i, rr[pick], cc[pick]] = [np.nan, np.inf, -np.inf, np.nan, np.inf]
+        else:      # ... and some unmasked ones of the others (must not matter)
+            rr, cc = np.nonzero(~masks[i])
+            pick = rs.choice(len(rr), 5, replace=False)
+            depth[i, rr[pick], cc[pick]] = [np.nan, np.inf, -np.inf, np.nan, np.inf]
+    masks[B - 1] = False
+    masks[B - 1, 5, 7] = True
+    depth[B - 1, 5, 7] = np.inf            # its only pixel is invalid -> empty
+    ground = np.array([[0.02, -0.98, 0.1, 1.5]] * B) + 0.03 * rs.randn(B, 4)
+    boxes, status, aux = la.fit_instances(depth, masks, K640, ground=ground)
+    ref = [O.fit_instance(depth[i], masks[i], K640, ground[i]) for i in range(B)]
+    assert np_(status).tolist() == [r[1] for r in ref]
+    assert np_(status)[B - 1] == 1
+    a = np_(aux)
+    ok = np_(status) == 0
+    assert_records(np_(boxes)[ok], np.array([r[0] for r in ref])[ok], "tiled-nonfinite", gap=a[ok, 3])
+    np.testing.assert_array_equal(a[:, 1], [r[2]["n_valid"] for r in ref])
+    assert (a[1::2, 1][:-1] == a[1::2, 2][:-1] - 5).all()   # five masked pixels dropped in the poisoned instances
