@@ -97,6 +97,38 @@ def keep_instances(stats: torch.Tensor, image_height: int, from_rle: bool = True
     return (height.double() / image_height > 0.0625) & (stats[:, 3] < 10) & (stats[:, 0] >= scale_threshold)
 
 
+def filter_annotations(annotations, image_size, boundary_threshold: int = 10, scale_threshold: int = 100, device=None):
+    """The RLE branch of the reference's ``read_bounding_boxes_segmentations(annotations, image_size)``
+    (src/util.py:336-383) without ever decoding a mask plane: crowd annotations are skipped (:355-357), the four filter
+    quantities come from ``mask_stats_rle`` and the keep rule is :375 (height/H > 0.0625, not truncated, area >= 100).
+
+    annotations: list of COCO annotation dicts with 'iscrowd', 'bbox', 'category_id' and an RLE 'segmentation'
+    ({'size': [h, w], 'counts': list | str | bytes}); image_size = (width, height) as in the reference.
+    Returns ``(bboxes, rles, kept_index, category_ids)``: the kept annotations' boxes, their RLE objects (feed them to
+    ``fit_instances_rle`` or ``rle_decode``), their positions in ``annotations`` and their raw COCO category ids (the
+    reference maps those to super-category names with a table that is not part of this path).  Polygon segmentations
+    need ``cv2.fillPoly`` (src/util.py:386-392) and raise NotImplementedError."""
+    cand, idx = [], []
+    for i, a in enumerate(annotations):
+        if a.get("iscrowd"):
+            continue
+        seg = a.get("segmentation")
+        if seg is None:
+            continue
+        if not (isinstance(seg, dict) and "counts" in seg):
+            raise NotImplementedError("polygon segmentation: rasterise with cv2.fillPoly (reference src/util.py:386-392)")
+        cand.append({"size": seg["size"], "counts": seg["counts"]})
+        idx.append(i)
+    if not cand:
+        return [], [], np.zeros(0, np.int64), []
+    H = int(image_size[1])
+    keep = keep_instances(mask_stats_rle(cand, boundary_threshold, device=device), H, from_rle=True,
+                          scale_threshold=scale_threshold).cpu().numpy()
+    kept = [j for j in range(len(cand)) if keep[j]]
+    return ([annotations[idx[j]]["bbox"] for j in kept], [cand[j] for j in kept], np.asarray([idx[j] for j in kept], np.int64),
+            [annotations[idx[j]]["category_id"] for j in kept])
+
+
 def fit_instances_rle(depth, rles, K, ground=None, sample_idx=None, image_index=None, stream=None, device=None):
     """fit_instances with run-length masks: the runs are decoded inside the fit kernel, straight into its LDS
     bit image.  Arguments and returns as ``labelany3d_amd.fit_instances``; ``rles`` is a list of COCO RLE

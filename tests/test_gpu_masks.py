@@ -260,3 +260,24 @@ def test_mask_stats_rle_golden_and_compressed_strings(la, golden):
     over = [{"size": [48, 64], "counts": [10, 48 * 64 + 500]}]
     dec = np_(la.rle_decode(over))[0]
     np.testing.assert_array_equal(np_(la.mask_stats_rle(over))[0], np.array(O.mask_stats(dec)))
+
+
+def test_filter_annotations_matches_the_reference_rule(la):
+    """filter_annotations == the RLE branch of read_bounding_boxes_segmentations (src/util.py:336-383): crowds skipped,
+    height = rows holding a pixel, truncation and area rules — checked against the oracle's decode + stats + keep."""
+    rs = np.random.RandomState(3)
+    H, W = 120, 160
+    m = _random_masks(rs, 30, H, W)
+    annos = []
+    for i, x in enumerate(m):
+        rle = O.rle_encode(x)
+        if i % 3 == 0:
+            rle = {"size": rle["size"], "counts": O.rle_to_string(rle["counts"])}   # compressed string form
+        annos.append({"iscrowd": int(i % 7 == 0), "bbox": [i, i, 10, 10], "category_id": 1 + i % 5, "segmentation": rle})
+    bboxes, rles, kept, cats = la.filter_annotations(annos, (W, H))
+    want = [i for i, x in enumerate(m) if not annos[i]["iscrowd"] and O.keep_instance(O.mask_stats(x), H, True)]
+    assert kept.tolist() == want and len(want) > 0
+    assert bboxes == [annos[i]["bbox"] for i in want] and cats == [annos[i]["category_id"] for i in want]
+    np.testing.assert_array_equal(np_(la.rle_decode(rles)), m[want])
+    with pytest.raises(NotImplementedError):
+        la.filter_annotations([{"iscrowd": 0, "bbox": [0, 0, 1, 1], "category_id": 1, "segmentation": [[0, 0, 5, 0, 5, 5]]}], (W, H))
