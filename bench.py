@@ -325,7 +325,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "fit_instances_kernel<VEC,LDSMASK,SAMPLE=0,TILED> (instance engine; B <= 384 takes the split engine)",
+                "kernel": "fit_instances_kernel<VEC,LDSMASK,SAMPLE=0,TILED> (instance engine; B <= 336 takes the split engine)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",

@@ -8,7 +8,7 @@
 //
 // Memory-bound integer/byte + fp64 reduction work: no MFMA.  Layout, kernel design and measurements are in
 // DESIGN.md.  This file holds the INSTANCE ENGINE of la3d_fit_instances (one workgroup per instance; used for
-// B > 384, for run-length masks, for reference-subsample mode and for frames the split engine does not take —
+// B > 336, for run-length masks, for reference-subsample mode and for frames the split engine does not take —
 // la3d_split.hip is the other engine) and every other kernel of the C-ABI.  `fit_instances_kernel` in short:
 //   one 512-thread workgroup (8 wave64) per instance, 64 VGPRs / 40 KB LDS -> 4 workgroups per CU;
 //   phase 0  streams the u8 mask plane once with 16-byte non-temporal loads (or decodes COCO run lengths) into a

@@ -556,7 +556,7 @@ bool split_eligible(const FitParams& p, bool vec, bool ldsmask) {
   const char* e = getenv("LA3D_ENGINE");  // experiments only
   if (e && !strcmp(e, "instance")) return false;
   if (e && !strcmp(e, "split")) return true;
-  return p.B <= 384;
+  return p.B <= 336;  // measured crossover with the (size-ordered) instance engine: 320 -> split 82 vs 84 us, 352 -> 84 vs 81 us
 }
 
 // One call = one batch.  Sub-batch j: scan on the scan stream (scans are bandwidth-bound, so they run
