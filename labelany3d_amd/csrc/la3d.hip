@@ -197,9 +197,9 @@ __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__
 // ------------------------------------------------------------------------------------------
 // workgroup stages shared by the fit kernels (every thread of the workgroup must call them)
 // ------------------------------------------------------------------------------------------
-// moments of all waves -> thread 0 (fixed order: bit-reproducible) -> status, yaw axis.
+// moments of all waves -> wave 0 (fixed xor tree: bit-reproducible) -> status, yaw axis.
 // On return sh->st / sh->cyaw / sh->syaw are valid for every thread.  The aux record (with its atan2) is
-// written afterwards by thread 0 only, off the other waves' critical path.
+// written at the end of the kernel (stage_status_aux), off everybody's critical path.
 // allow_redo: the sums come from the optimistic pass (quad_math<0, false>); if they are not finite, set sh->redo and return
 // without deciding anything - the caller re-runs the checked pass and calls again with allow_redo = false.
 __device__ inline void stage_moments_to_axis(Shared* sh, const FitParams& p, int inst, const double* acc, int cnt,
@@ -216,17 +216,21 @@ __device__ inline void stage_moments_to_axis(Shared* sh, const FitParams& p, int
     }
   }
   __syncthreads();
-  double gap = NAN;
-  int nm = 0;
-  if (tid == 0) {
-    double s[5] = {0, 0, 0, 0, 0};
-    int n = 0;
-#pragma unroll 1
-    for (int w = 0; w < NWAVE; ++w) {  // fixed order (not unrolled: keeps thread 0's live set small)
-      for (int k = 0; k < 5; ++k) s[k] += sh->part[w][k];
-      n += sh->cnt[w];
-      nm += sh->nmask[w];
+  if (wave == 0) {
+    // the NWAVE partials: one per lane, then a fixed xor tree over those lanes (bit-reproducible)
+    double s[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) s[k] = lane < NWAVE ? sh->part[lane][k] : 0.0;
+    int n = lane < NWAVE ? sh->cnt[lane] : 0, nm = lane < NWAVE ? sh->nmask[lane] : 0;
+#pragma unroll
+    for (int o = 1; o < NWAVE; o <<= 1) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) s[k] += __shfl_xor(s[k], o);
+      n += __shfl_xor(n, o);
+      nm += __shfl_xor(nm, o);
     }
+    if (lane == 0) {
+    double gap = NAN;
     int st = LA3D_BOX_OK;
     if (sh->bad_ground) st = LA3D_BOX_BAD_GROUND;
     else if (n == 0) st = LA3D_BOX_EMPTY;
@@ -238,18 +242,31 @@ __device__ inline void stage_moments_to_axis(Shared* sh, const FitParams& p, int
     sh->cyaw = cy; sh->syaw = sy;
     sh->st = st;
     sh->n_valid = n;
+    sh->gap = gap;
+    sh->nm = nm;
+    }
   }
   __syncthreads();
   if (sh->redo) return;  // uniform
-  if (tid == 0) {
-    const int st = sh->st;
+  if (tid == 0 && sh->st != LA3D_BOX_OK) {  // rejected instance: the workgroup returns right after this call
     if (p.aux) {
       double* a = p.aux + (long long)inst * LA3D_AUX;
-      a[0] = atan2(sh->syaw, sh->cyaw); a[1] = (double)sh->n_valid; a[2] = (double)nm; a[3] = gap;
+      a[0] = atan2(sh->syaw, sh->cyaw); a[1] = (double)sh->n_valid; a[2] = (double)sh->nm; a[3] = sh->gap;
     }
-    p.status[inst] = st;
-    if (st != LA3D_BOX_OK) write_nan_box(p.out + (long long)inst * LA3D_REC);
+    p.status[inst] = sh->st;
+    write_nan_box(p.out + (long long)inst * LA3D_REC);
   }
+}
+
+// status and aux record of an accepted instance: written at the very end by lane 0 of wave 1, next to wave 0 writing the
+// box - the atan2 of the reported yaw is the only trigonometry of the kernel and nobody waits for it
+__device__ inline void stage_status_aux(const Shared* sh, const FitParams& p, int inst, int tid) {
+  if (tid != 64) return;
+  if (p.aux) {
+    double* a = p.aux + (long long)inst * LA3D_AUX;
+    a[0] = atan2(sh->syaw, sh->cyaw); a[1] = (double)sh->n_valid; a[2] = (double)sh->nm; a[3] = sh->gap;
+  }
+  p.status[inst] = LA3D_BOX_OK;
 }
 
 // extents (x,y,z : lo,hi) of all waves -> wave 0 -> the 39-double record, written lane-parallel
@@ -268,9 +285,16 @@ __device__ inline void stage_extents_to_box(Shared* sh, const FitParams& p, int 
     double lo[3], hi[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      lo[k] = wave_min(lane < NWAVE ? sh->part[lane][2 * k] : INFINITY);
-      hi[k] = wave_max(lane < NWAVE ? sh->part[lane][2 * k + 1] : -INFINITY);
+      lo[k] = lane < NWAVE ? sh->part[lane][2 * k] : INFINITY;
+      hi[k] = lane < NWAVE ? sh->part[lane][2 * k + 1] : -INFINITY;
     }
+#pragma unroll
+    for (int o = 1; o < NWAVE; o <<= 1) {   // only the first NWAVE lanes hold data
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { lo[k] = fmin(lo[k], __shfl_xor(lo[k], o)); hi[k] = fmax(hi[k], __shfl_xor(hi[k], o)); }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { lo[k] = __shfl(lo[k], 0); hi[k] = __shfl(hi[k], 0); }   // write_box_wave wants them in every lane
     double Rg[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) Rg[i] = sh->Rg[i];
@@ -385,32 +409,74 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
     const int ntiles = p.ntx * p.nty, per = p.tiles_per_wave;
     const int tbeg = wave * per, tend = min(tbeg + per, ntiles);
     int base = 0;
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
+    if (per <= 256) {
+      // one pass: a wave looks at up to 4 x 64 tiles; the ballots stay in SGPRs across the barrier, the eight row words
+      // of a tile are read back to back (rows past the frame re-read the last one), no integer division
+      unsigned long long bal[4];
       int wcount = 0;
-      for (int t0 = tbeg; t0 < tend; t0 += 64) {   // wave-uniform trip count
-        const int t = t0 + lane;
-        unsigned any = 0, packed = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int t = tbeg + k * 64 + lane;
+        unsigned any = 0;
         if (t < tend) {
-          const int ty = t / p.ntx, tx = t - ty * p.ntx;
-          const int rows = min(8, p.H - ty * 8);
+          const int ty = (int)(((float)t + 0.5f) * p.rcp_ntx), tx = t - ty * p.ntx;  // exact: see fit_dispatch
+          const int rmax = p.H - 1 - ty * 8;                                        // >= 0
           const unsigned* bw = bits + (ty * 8) * p.ntx + tx;
-          for (int rr = 0; rr < rows; ++rr) any |= bw[rr * p.ntx];
-          packed = ((unsigned)ty << 8) | (unsigned)tx;
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) any |= bw[min(rr, rmax) * p.ntx];
         }
-        const unsigned long long bal = __ballot(any != 0);
-        if (pass == 1 && any) list[base + wcount + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)packed;
-        wcount += __popcll(bal);
+        bal[k] = __ballot(any != 0);
+        wcount += __popcll(bal[k]);
       }
-      if (pass == 0) {
-        if (lane == 0) sh->scan[wave] = (unsigned)wcount;
-        __syncthreads();
-        for (int w = 0; w < NWAVE; ++w) {
-          const int c = (int)sh->scan[w];
-          if (w < wave) base += c;
-          nactive += c;
+      if (lane == 0) sh->scan[wave] = (unsigned)wcount;
+      __syncthreads();
+      for (int w = 0; w < NWAVE; ++w) {
+        const int c = (int)sh->scan[w];
+        if (w < wave) base += c;
+        nactive += c;
+      }
+      if (nactive > p.list_cap) {
+        nactive = -1;  // uniform: every thread sees the same total
+      } else {
+        int off = base;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if ((bal[k] >> lane) & 1ull) {
+            const int t = tbeg + k * 64 + lane;
+            const int ty = (int)(((float)t + 0.5f) * p.rcp_ntx), tx = t - ty * p.ntx;
+            list[off + __popcll(bal[k] & ((1ull << lane) - 1ull))] = (unsigned short)((ty << 8) | tx);
+          }
+          off += __popcll(bal[k]);
         }
-        if (nactive > p.list_cap) { nactive = -1; break; }  // uniform: every thread sees the same total
+      }
+    } else {
+#pragma unroll 1
+      for (int pass = 0; pass < 2; ++pass) {
+        int wcount = 0;
+        for (int t0 = tbeg; t0 < tend; t0 += 64) {   // wave-uniform trip count
+          const int t = t0 + lane;
+          unsigned any = 0, packed = 0;
+          if (t < tend) {
+            const int ty = t / p.ntx, tx = t - ty * p.ntx;
+            const int rows = min(8, p.H - ty * 8);
+            const unsigned* bw = bits + (ty * 8) * p.ntx + tx;
+            for (int rr = 0; rr < rows; ++rr) any |= bw[rr * p.ntx];
+            packed = ((unsigned)ty << 8) | (unsigned)tx;
+          }
+          const unsigned long long bal = __ballot(any != 0);
+          if (pass == 1 && any) list[base + wcount + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)packed;
+          wcount += __popcll(bal);
+        }
+        if (pass == 0) {
+          if (lane == 0) sh->scan[wave] = (unsigned)wcount;
+          __syncthreads();
+          for (int w = 0; w < NWAVE; ++w) {
+            const int c = (int)sh->scan[w];
+            if (w < wave) base += c;
+            nactive += c;
+          }
+          if (nactive > p.list_cap) { nactive = -1; break; }  // uniform: every thread sees the same total
+        }
       }
     }
     __syncthreads();
@@ -533,6 +599,7 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
   }
   LA3D_STAMP(5);
   stage_extents_to_box(sh, p, inst, ext, tid, wave, lane);
+  stage_status_aux(sh, p, inst, tid);
   LA3D_STAMP(6);
 }
 
@@ -1494,6 +1561,7 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   p.rcpW = 1.0f / (float)W;
   p.out = out; p.status = status; p.aux = aux;
   p.ntx = p.nty = p.tiles_per_wave = p.list_cap = 0;
+  p.rcp_ntx = 1.0f;
   p.perm = nullptr;
   const int bit_bytes = ((((p.HW + 15) / 16 + 1) / 2) * 4 + 15) & ~15;  // u16 per 16 px, padded to u32, 16-aligned
   const bool ldsmask = bit_bytes <= MAX_MASK_LDS;
@@ -1523,6 +1591,9 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   }
   // tiled fast path: 32-px-wide tiles map to exactly one bit-image word / one 128-B depth line per row
   p.ntx = W / 32; p.nty = (H + 7) / 8;
+  // ty = int((t + 0.5f) * rcp_ntx) is exact for t < 65536: the fraction of (t+0.5)/ntx stays at least 0.5/ntx away from
+  // an integer and the float error is below (65536/ntx) * 1.2e-7
+  p.rcp_ntx = 1.0f / (float)(p.ntx > 0 ? p.ntx : 1);
   p.tiles_per_wave = (p.ntx * p.nty + NWAVE - 1) / NWAVE;
   if (ldsmask && vec && W % 32 == 0 && p.ntx <= 255 && p.nty <= 255) {
     // LDS per workgroup: the largest number of workgroups per CU (160 KiB LDS) that still leaves room

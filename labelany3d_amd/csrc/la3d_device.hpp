@@ -305,6 +305,7 @@ struct FitParams {
   int ntx, nty;        // TILED: tiles of 32 px x 8 rows (ntx = W/32, nty = ceil(H/8))
   int tiles_per_wave;  // TILED: ceil(ntx*nty / NWAVE)
   int list_cap;        // TILED: entries of the active-tile list that fit the LDS budget
+  float rcp_ntx;       // TILED: 1 / ntx
   const int* perm;     // launch order: workgroup b fits instance perm[b] (nullptr: xcd_remap(b))
   double* out;
   int* status;
@@ -327,6 +328,9 @@ struct alignas(16) Shared {
   int st;
   int bad_ground;
   int redo;        // optimistic pass A met a non-finite masked depth: run the checked passes
+  double gap;      // relative eigenvalue gap (aux[3]), kept for the deferred aux write
+  int nm;          // mask pixels (aux[2])
+  int pad;
 };
 
 __device__ inline void pix_uv(unsigned i, int W, float rcpW, unsigned* u, unsigned* v) {
