@@ -581,3 +581,70 @@ def test_nonfinite_depth_in_tiled_frames(la, engine):
     assert_records(np_(boxes)[ok], np.array([r[0] for r in ref])[ok], "tiled-nonfinite", gap=a[ok, 3])
     np.testing.assert_array_equal(a[:, 1], [r[2]["n_valid"] for r in ref])
     assert (a[1::2, 1][:-1] == a[1::2, 2][:-1] - 5).all()   # five masked pixels dropped in the poisoned instances
+
+
+# ------------------------------------------------------------------------------------------
+# randomized differential sweep: every engine / input format against the oracle on many small configurations
+# ------------------------------------------------------------------------------------------
+def _fuzz_case(rs):
+    H = int(rs.choice([16, 24, 37, 64, 96, 128, 160]))
+    W = int(rs.choice([32, 48, 53, 64, 96, 128, 256, 320]))
+    B = int(rs.randint(1, 13))
+    depth = rs.uniform(0.3, 12, (B, H, W)).astype(np.float32)
+    if rs.rand() < 0.4:   # smooth surfaces instead of noise
+        vv, uu = np.mgrid[0:H, 0:W]
+        depth = (2 + 0.01 * uu[None] + 0.02 * vv[None] + rs.uniform(0, 3, (B, 1, 1))).astype(np.float32)
+    masks = np.zeros((B, H, W), bool)
+    for i in range(B):
+        kind = rs.randint(0, 5)
+        if kind == 0:
+            h, w = rs.randint(1, H + 1), rs.randint(1, W + 1)
+            r0, c0 = rs.randint(0, H - h + 1), rs.randint(0, W - w + 1)
+            masks[i, r0:r0 + h, c0:c0 + w] = True
+        elif kind == 1:
+            masks[i] = rs.rand(H, W) < rs.uniform(0.005, 0.7)
+        elif kind == 2:
+            vv, uu = np.mgrid[0:H, 0:W]
+            masks[i] = ((vv - rs.uniform(0, H)) / rs.uniform(1, H)) ** 2 + ((uu - rs.uniform(0, W)) / rs.uniform(1, W)) ** 2 < 1
+        elif kind == 3:
+            masks[i, rs.randint(0, H), rs.randint(0, W)] = True   # a single pixel: too few points
+        # kind 4: empty
+    if rs.rand() < 0.3:   # a few non-finite depths, some of them under masks
+        for _ in range(rs.randint(1, 6)):
+            depth[rs.randint(0, B), rs.randint(0, H), rs.randint(0, W)] = rs.choice([np.nan, np.inf, -np.inf])
+    ground = None
+    if rs.rand() < 0.5:
+        ground = np.array([[0.02, -0.98, 0.1, 1.5]] * B) + 0.05 * rs.randn(B, 4)
+        if rs.rand() < 0.3:
+            ground[rs.randint(0, B)] = [0, -1, 0, 1.0]   # parallel to the up axis: the reference's NaN rotation
+    K = np.array([[rs.uniform(40, 600), 0, W / 2 + rs.uniform(-5, 5)], [0, rs.uniform(40, 600), H / 2 + rs.uniform(-5, 5)], [0, 0, 1]])
+    return depth, masks, K, ground
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_randomized_differential_sweep(la, seed, monkeypatch):
+    from labelany3d_amd.masks import fit_instances_rle
+
+    rs = np.random.RandomState(1000 + seed)
+    for case in range(12):
+        depth, masks, K, ground = _fuzz_case(rs)
+        B = len(masks)
+        gl = [None] * B if ground is None else list(ground)
+        ref = [O.fit_instance(depth[i], masks[i], K, gl[i]) for i in range(B)]
+        rrec, rst = np.array([r[0] for r in ref]), [r[1] for r in ref]
+        tag = f"seed{seed}/case{case} {masks.shape}"
+        outs = {}
+        for eng in ("instance", "split"):
+            monkeypatch.setenv("LA3D_ENGINE", eng)
+            b, s, a = la.fit_instances(depth, masks, K, ground=ground)
+            assert np_(s).tolist() == rst, f"{tag} {eng} status"
+            ok = np_(s) == 0
+            assert_records(np_(b)[ok], rrec[ok], f"{tag} {eng}", gap=np_(a)[ok, 3])
+            assert np.isnan(np_(b)[~ok]).all()
+            np.testing.assert_array_equal(np_(a)[ok, 1], np.array([r[2]["n_valid"] for r in ref])[ok])  # (the oracle reports 0 for rejects)
+            outs[eng] = np_(b)
+        monkeypatch.setenv("LA3D_ENGINE", "instance")
+        b, s, a = fit_instances_rle(depth, [O.rle_encode(m) for m in masks], K, ground=ground)
+        assert np_(s).tolist() == rst, f"{tag} rle status"
+        np.testing.assert_allclose(np.nan_to_num(np_(b), nan=-7.0), np.nan_to_num(outs["instance"], nan=-7.0), rtol=1e-12, atol=1e-12,
+                                   err_msg=f"{tag} rle vs planes")
