@@ -28,3 +28,23 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+EXAMPLE_SRC = os.path.join(ROOT, "examples", "fit_from_c.cpp")
+EXAMPLE_BIN = os.path.join(HERE, "lib", "fit_from_c")
+
+
+def build_example(force: bool = False, verbose: bool = False) -> str:
+    """The plain host program that drives the C-ABI without Python (examples/fit_from_c.cpp), linked against the in-tree
+    library; tests/test_gpu_cabi.py runs it on the GPU box."""
+    lib = build(force=False, verbose=verbose)
+    if not force and os.path.exists(EXAMPLE_BIN) and os.path.getmtime(EXAMPLE_BIN) >= max(os.path.getmtime(EXAMPLE_SRC),
+                                                                                         os.path.getmtime(lib)):
+        return EXAMPLE_BIN
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O2", "-std=c++17", "-I", INCLUDE, EXAMPLE_SRC, "-L", os.path.dirname(lib), "-lla3d", "-Wl,-rpath,$ORIGIN",
+           "-o", EXAMPLE_BIN]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return EXAMPLE_BIN
+
+
