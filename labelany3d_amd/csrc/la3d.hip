@@ -1499,6 +1499,9 @@ const char* la3d_last_error(void) { return g_err; }
 
 double la3d_f16_round_host(double x) { return f16_round(x); }
 
+// Workspace layout (one per concurrently running call; contents need not be initialised or preserved):
+//   instance engine: [B] u32 sort keys, then [B] i32 block -> instance (the size-balanced launch order; 8*B bytes)
+//   split engine:    [B][GEO_D] f64 geometry, then bit images, tile lists and partial-sum slots (split_workspace_bytes)
 size_t la3d_workspace_bytes(int B, int H, int W) {
   if (B <= 0) return 0;
   const size_t inst = (size_t)B * GEO_D * sizeof(double);  // kept as the minimum (older callers size by it)
