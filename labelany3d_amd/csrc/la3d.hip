@@ -380,7 +380,7 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
 #else
         const u32x4 w = m4[g];
 #endif
-        const unsigned pat = nz4(w.x) | (nz4(w.y) << 4) | (nz4(w.z) << 8) | (nz4(w.w) << 12);
+        const unsigned pat = nz16(w.x, w.y, w.z, w.w);
         b16[g] = (unsigned short)pat;
         nmask += __popc(pat);
       }

@@ -263,6 +263,18 @@ __device__ inline int xcd_remap(int b, int nb) {
 }
 
 // 4 mask bytes -> 4 bits (bit k = byte k non-zero)
+// 16 pixels (four words of four bytes) -> 16-bit pattern, bit 4*k + j = byte j of word k is non-zero.  The per-byte flags
+// (0x80 or 0) are gathered with two dot products per half: sum flag_j * 2^(4k+j) = 128 * pattern.
+__device__ inline unsigned nz16(unsigned w0, unsigned w1, unsigned w2, unsigned w3) {
+  const unsigned f0 = (((w0 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w0) & 0x80808080u;
+  const unsigned f1 = (((w1 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w1) & 0x80808080u;
+  const unsigned f2 = (((w2 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w2) & 0x80808080u;
+  const unsigned f3 = (((w3 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w3) & 0x80808080u;
+  const unsigned lo = __builtin_amdgcn_udot4(f1, 0x80402010u, __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false), false);
+  const unsigned hi = __builtin_amdgcn_udot4(f3, 0x80402010u, __builtin_amdgcn_udot4(f2, 0x08040201u, 0u, false), false);
+  return (lo >> 7) | (hi << 1);
+}
+
 __device__ inline unsigned nz4(unsigned w) {
   const unsigned t = (((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u;  // high bit of each non-zero byte
   return ((t >> 7) * 0x01020408u) >> 24;                                       // gather bits 0,8,16,24 -> 0..3
