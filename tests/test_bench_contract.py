@@ -1,0 +1,54 @@
+"""The measurement harness itself: the all-cores CPU-baseline worker protocol (CPU) and the JSON line bench.py prints
+(GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpu_worker_protocol(tmp_path):
+    rs = np.random.RandomState(0)
+    d = rs.uniform(0.5, 10, (3, 48, 64)).astype(np.float32)
+    m = np.zeros((3, 48, 64), np.uint8)
+    m[:, 10:30, 20:50] = 1
+    np.save(tmp_path / "d.npy", d)
+    np.save(tmp_path / "m.npy", m)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    p = subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", str(tmp_path / "d.npy"), str(tmp_path / "m.npy"), "1", "4"],
+                         stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    assert p.stdout.readline().startswith("ready")
+    p.stdin.write("go\n")
+    p.stdin.flush()
+    line = p.stdout.readline()
+    p.wait(timeout=60)
+    assert line.startswith("done") and float(line.split()[1]) > 0
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_contract_line():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["metric"] == "fitted 3D boxes/sec @640x480" and d["unit"] == "boxes/s" and d["n_gpus"] == 1 and d["steps"] == 5
+    assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["higher_is_better"] is True and "workload" in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(d["value"] - 5 * 1024 / (d["ms_per_step"] * 5e-3)) / d["value"] < 1e-6
+    assert d["value"] > 2.08e6   # BASELINE target: 40 % of the HBM-read roofline
