@@ -166,7 +166,8 @@ __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__
         int tx, ty;
         if (dense) { ty = j / ntx; tx = j - ty * ntx; }
         else {
-          const unsigned t = __builtin_amdgcn_readfirstlane((unsigned)list[j]);  // wave-uniform -> SGPR
+          // pass B walks the list backwards: the tiles pass A read last are re-read first (L2 reuse)
+          const unsigned t = __builtin_amdgcn_readfirstlane((unsigned)list[PASS == 1 ? nsteps - 1 - j : j]);  // wave-uniform -> SGPR
           tx = (int)(t & 0xffu); ty = (int)(t >> 8);
         }
         txs[g] = tx; tys[g] = ty;
