@@ -178,8 +178,8 @@ def cpu_baseline(depth, masks, budget_s=8.0, max_inst=256):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU per step (config 2: 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rle", action="store_true",
