@@ -79,6 +79,58 @@ def make_config3(P, device, seed):
     return depth, masks, K, n_masked, torch.as_tensor(img, device=device)
 
 
+def make_config5(B, device, seed):
+    """BASELINE config 5 workload: private depth planes, mask areas log-uniform 8..100k px (rectangles below 400 px,
+    ellipses above; aspect ratio log-uniform in e^+-0.7), position uniform in the frame."""
+    rs = np.random.RandomState(seed)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    depth = torch.empty((B, H, W), dtype=torch.float32, device=device).uniform_(0.5, 10.0, generator=g)
+    area = np.exp(rs.uniform(np.log(8), np.log(100000), B))
+    asp = np.exp(rs.uniform(-0.7, 0.7, B))
+    ell = area >= 400
+    box_area = np.where(ell, area * 4 / np.pi, area)          # bounding box of the ellipse
+    hh = np.clip(np.round(np.sqrt(box_area * asp)), 2, H).astype(np.int64)
+    ww = np.clip(np.round(box_area / hh), 2, W).astype(np.int64)
+    r0 = (rs.rand(B) * (H - hh + 1)).astype(np.int64)
+    c0 = (rs.rand(B) * (W - ww + 1)).astype(np.int64)
+    masks = torch.empty((B, H, W), dtype=torch.uint8, device=device)
+    rows = torch.arange(H, device=device, dtype=torch.float32).view(1, H, 1)
+    cols = torch.arange(W, device=device, dtype=torch.float32).view(1, 1, W)
+    for a in range(0, B, 1024):   # chunked: the comparison temporaries are (chunk,H,W)
+        sl = slice(a, min(B, a + 1024))
+        t = lambda v: torch.as_tensor(v[sl], device=device, dtype=torch.float32).view(-1, 1, 1)  # noqa: E731
+        inside = (rows >= t(r0)) & (rows < t(r0 + hh)) & (cols >= t(c0)) & (cols < t(c0 + ww))
+        e = (((rows + 0.5 - t(r0) - t(hh) / 2) / (t(hh) / 2)) ** 2 + ((cols + 0.5 - t(c0) - t(ww) / 2) / (t(ww) / 2)) ** 2) <= 1.0
+        masks[sl] = (inside & (e | ~torch.as_tensor(ell[sl], device=device).view(-1, 1, 1))).to(torch.uint8)
+    K = torch.tensor(K640, dtype=torch.float64, device=device)
+    return depth, masks, K, int(masks.sum(dtype=torch.int64)), (r0, c0, hh, ww)
+
+
+def required_bytes(masks):
+    """HBM bytes the path cannot avoid for these inputs: every u8 mask plane once, the 128-byte depth lines of the 32 px x
+    8 row tiles that hold a mask pixel once (a depth line with no mask pixel need not be read), one 312-byte record per
+    instance.  Computed from the masks themselves, so it is checkable from the inputs alone."""
+    B, h, w = masks.shape
+    tiles = 0
+    hp, wp = (h + 7) // 8 * 8, (w + 31) // 32 * 32
+    for a in range(0, B, 512):
+        m = masks[a:a + 512]
+        if (hp, wp) != (h, w):
+            m = torch.nn.functional.pad(m, (0, wp - w, 0, hp - h))
+        tiles += int(m.view(m.shape[0], hp // 8, 8, wp // 32, 32).amax(dim=(2, 4)).ne(0).sum())
+    return B * h * w + tiles * 1024 + B * 39 * 8, tiles
+
+
+def kernel_source_sha256():
+    """Hash of the kernel sources: stamps the PMC traffic figure so that a stale constant is detectable."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("la3d.hip", "la3d_device.hpp", "la3d_split.hip"):
+        h.update(open(os.path.join(ROOT, "labelany3d_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
 def rect_rle(rects):
     """COCO run lengths (column-major, zeros first) of the same rectangles: the --rle input format."""
     r0, c0, hh, ww = rects
@@ -188,6 +240,8 @@ def main():
     ap.add_argument("--config3", type=int, default=0, metavar="IMAGES",
                     help="secondary mode: BASELINE config-3 stand-in — IMAGES shared depth planes, ~Poisson(7) instances per "
                          "image with log-uniform mask areas 400..100k px, all instances in ONE call per step")
+    ap.add_argument("--config5", action="store_true",
+                    help="secondary mode: BASELINE config-5 workload (mask areas log-uniform 8..100k px, private depth)")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the independent steps are issued on round-robin (1 = strictly serial steps)")
     args = ap.parse_args()
@@ -218,6 +272,8 @@ def main():
         depth, masks, K, n_masked, image_index = make_config3(args.config3, device, 1234 + rank)
         B = masks.shape[0]
         rects = None
+    elif args.config5:
+        depth, masks, K, n_masked, rects = make_config5(B, device, 1234 + rank)
     else:
         depth, masks, K, n_masked, rects = make_inputs(B, device, 1234 + rank)
     fitter = InstanceFitter(B, H, W, device, slots=(1 if args.config3 else max(steps, 1)), ws_slots=max(args.streams, 1))
@@ -291,12 +347,29 @@ def main():
         alg_bytes = B * ALG_BYTES_PER_BOX
         if args.config3:   # shared-depth layout: depth plane once per image, mask + record per instance
             alg_bytes = args.config3 * H * W * 4 + B * (H * W + 39 * 8)
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic, traffic_src = None, None
+        # bytes this input cannot be fitted without: every mask plane once + the 128-B depth lines of the 32x8 tiles that hold
+        # a mask pixel once + the records (computed from the masks; with run-length input the mask term is the run lengths)
+        req_bytes, active_tiles = required_bytes(masks)
+        if args.rle:
+            req_bytes += int(rle_c.numel()) * 4 - B * H * W
+        step_s = kern_ms * 1e-3
+        achieved = req_bytes / step_s / 1e9
+        traffic, traffic_src, traffic_stale = None, None, None
         tp = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
-        if os.path.exists(tp):
+        if os.path.exists(tp) and not (args.config3 or args.config5 or args.rle) and B == 1024:
             tj = json.load(open(tp))
             traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
+            traffic_stale = tj.get("kernel_source_sha256") != kernel_source_sha256()
+        if args.config3:
+            workload = (f"BASELINE config-3 stand-in: {args.config3} images with a SHARED 480x640 depth plane each, {B} instances "
+                        "(~Poisson(7) per image, elliptical u8 masks, log-uniform area 400..100k px) in one call per step")
+        elif args.config5:
+            workload = (f"BASELINE config 5 workload: {B} instances per GPU per step, private 480x640 f32 depth, u8 masks with "
+                        "log-uniform area 8..100k px (rectangles below 400 px, ellipses above), one call per step")
+        else:
+            workload = ("BASELINE config 2: 1024 instances per GPU per step, private 480x640 f32 depth ~U(0.5,10) "
+                        "+ u8 rectangular mask per instance, K=[[500,0,320],[0,500,240],[0,0,1]], ground=None, "
+                        "full-mask mode; inputs resident in HBM")
         out = {
             "metric": "fitted 3D boxes/sec @640x480",
             "value": value,
@@ -311,35 +384,40 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": (f"BASELINE config-3 stand-in: {args.config3} images with a SHARED 480x640 depth plane each, {B} instances "
-                             "(~Poisson(7) per image, elliptical u8 masks, log-uniform area 400..100k px) in one call per step"
-                             if args.config3 else
-                             "BASELINE config 2: 1024 instances per GPU per step, private 480x640 f32 depth ~U(0.5,10) "
-                             "+ u8 rectangular mask per instance, K=[[500,0,320],[0,500,240],[0,0,1]], ground=None, "
-                             "full-mask mode; inputs resident in HBM"),
+                "workload": workload,
                 "instances_per_gpu": B,
                 "frame": [H, W],
                 "mean_mask_occupancy": n_masked / (B * H * W),
+                "active_tiles_per_instance": active_tiles / B,
                 "sharding": "instances sharded per rank, one final RCCL gather of box records" if world > 1 else "single GPU",
                 "mask_input": "COCO run lengths (la3d_fit_instances_rle) — not the config-2 format" if args.rle else "u8 planes",
+                "streams": len(streams),
+                "default_steps": "1000 timed steps / 50 warm-up (0.11 s timed region); any --steps works",
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "fit_instances_kernel<VEC,LDSMASK,SAMPLE=0,TILED> (instance engine; B <= 336 takes the split engine)",
+                "kernel": "fit_instances_kernel<VEC,LDSMASK,SAMPLE=0,TILED,RLE,RET=0> (instance engine; B <= 336 takes the split engine)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "algorithmic_bytes_per_launch": alg_bytes,
+                "required_bytes_per_launch": req_bytes,
+                "byte_model": "B*H*W mask bytes once + 1024 B x (32 px x 8 row tiles holding a mask pixel) depth once + 312 B x B "
+                              "records; computed from the generated masks in this run",
                 "avg_launch_ms": kern_ms,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "algorithmic_GBps": alg_bytes / step_s / 1e9,
                 "traffic": traffic,
-                "traffic_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if (traffic and not args.config3 and not args.rle and B == 1024) else None,
+                "traffic_GBps": (traffic / step_s / 1e9) if traffic else None,
+                "traffic_frac_of_peak": (traffic / step_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                 "traffic_source": traffic_src,
-                "note": "achieved = 1,536,312 algorithmic B/box x boxes per launch / HIP-event time per step on the launch "
-                        "stream (max over ranks); a step = the fit kernel plus, for 256 < B <= 3072, its two ~5 us "
-                        "launch-order helper kernels. The kernel skips depth lines whose mask bits are all zero, so real "
-                        "HBM traffic (traffic, PMC-measured at B = 1024) is below the algorithmic count and frac can "
-                        "exceed 1; traffic_GBps = traffic / the same time (see DESIGN.md section 5).",
+                "traffic_stale": traffic_stale,
+                "note": "frac = required bytes (byte_model) / HIP-event time per step on the launch stream (max over ranks) / 8 TB/s. "
+                        "A step = the fit kernel plus, for 256 < B <= 3072, its two ~5 us launch-order helper kernels. "
+                        "algorithmic_GBps is SURVEY 8d's H*W*5+312 B/box figure (the kernel never loads depth lines without a mask "
+                        "pixel, so that figure exceeds the physical peak and is NOT a roofline fraction). traffic = PMC-measured "
+                        "HBM bytes per launch of the profiled build (profiles/, TCC_EA0_RDREQ x 128 B + WRITE_SIZE); "
+                        "traffic_stale = the kernel sources changed since that profile.",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -137,58 +137,147 @@ __device__ inline void sweep(const FitParams& p, const float* __restrict__ dpl, 
 #endif
 constexpr int TG = LA3D_TG;
 
+// Depth tiles kept on chip between the two passes (RET > 0: the "retaining" build of the kernel, 128 VGPRs, two workgroups
+// per CU).  The first RET steps of every wave (RET x TG tiles, i.e. RET x TG x NWAVE tiles per instance) keep their depth
+// quads and mask nibbles in registers after pass A; pass B computes on them without touching memory.  Tiles beyond that
+// are re-read in pass B exactly as in the RET = 0 build.  Register arrays need static indices, hence the unrolled steps.
+template <int RET>
+struct Keep {
+  uint4 dq[RET > 0 ? RET : 1][TG];
+  unsigned nib[RET > 0 ? RET : 1];   // TG nibbles per step
+};
+
+struct TileCtx {
+  int W, H, ntx, r, cq;
+  double a00, a01, a02, a10, a11, a12, a20, a21, a22;
+};
+
+// list entry j of this walk -> tile coordinates (wave-uniform, in SGPRs)
+__device__ inline void tile_coords(const TileCtx& c, const unsigned short* list, bool dense, int j, int rev_base, int* tx, int* ty) {
+  if (dense) { *ty = j / c.ntx; *tx = j - *ty * c.ntx; }
+  else {
+    // rev_base >= 0: pass B walks the not-retained part of the list backwards - the tiles pass A read last are re-read
+    // first (L2 reuse; extents are order independent)
+    const unsigned t = __builtin_amdgcn_readfirstlane((unsigned)list[rev_base >= 0 ? rev_base - j : j]);
+    *tx = (int)(t & 0xffu); *ty = (int)(t >> 8);
+  }
+}
+
+// stage 1 of a step (TG consecutive list entries of one wave): bit-image nibbles, then all depth loads back to back.
+// Returns the TG nibbles packed into one word.
+__device__ inline unsigned tile_fetch(const TileCtx& c, const float* __restrict__ dpl, const unsigned* bits,
+                                      const unsigned short* list, int nsteps, bool dense, int j0, int rev_base, uint4* dq) {
+  unsigned nib[TG];
+  int txs[TG], tys[TG];
+#pragma unroll
+  for (int g = 0; g < TG; ++g) {
+    const int j = j0 + g;
+    nib[g] = 0; txs[g] = 0; tys[g] = 0;
+    dq[g] = make_uint4(0u, 0u, 0u, 0u);
+    if (j < nsteps) {
+      tile_coords(c, list, dense, j, rev_base, &txs[g], &tys[g]);
+      const int row = tys[g] * 8 + c.r;
+      if (row < c.H) nib[g] = (bits[row * c.ntx + txs[g]] >> (c.cq * 4)) & 0xFu;
+    }
+  }
+  unsigned pk = 0;
+#pragma unroll
+  for (int g = 0; g < TG; ++g) {
+    if (nib[g]) dq[g] = *reinterpret_cast<const uint4*>(dpl + (long long)(tys[g] * 8 + c.r) * c.W + txs[g] * 32 + c.cq * 4);
+    pk |= nib[g] << (4 * g);
+  }
+  return pk;
+}
+
+// stage 2: the pixel math of a step on quads dq / nibbles pk (all lanes; unmasked lanes carry zeros / NaNs)
 template <int PASS, bool CHK>
+__device__ inline void tile_compute(const TileCtx& c, const unsigned short* list, int nsteps, bool dense, int j0, int rev_base,
+                                    const uint4* dq, unsigned pk, double* sv, int* n) {
+#pragma unroll
+  for (int g = 0; g < TG; ++g) {
+    const int j = j0 + g;
+    if (j >= nsteps) continue;   // wave-uniform
+    const unsigned nib = (pk >> (4 * g)) & 0xFu;
+    if (dense && __ballot(nib != 0) == 0) continue;
+    int tx, ty;
+    tile_coords(c, list, dense, j, rev_base, &tx, &ty);
+    const unsigned db[4] = {dq[g].x, dq[g].y, dq[g].z, dq[g].w};
+    const double vd = (double)(ty * 8 + c.r), ud = (double)(tx * 32 + c.cq * 4);
+    const double r0 = fma(c.a00, ud, fma(c.a01, vd, c.a02));
+    const double r2 = fma(c.a20, ud, fma(c.a21, vd, c.a22));
+    double r1 = 0;
+    if (PASS == 1) r1 = fma(c.a10, ud, fma(c.a11, vd, c.a12));
+    quad_math<PASS, CHK>(nib, db, r0, r1, r2, c.a00, c.a10, c.a20, sv, n);
+  }
+}
+
+constexpr int LDS_KEEP_WAVE = TG * 1024 + 256;   // bytes of the LDS-kept step per wave
+// lds_keep (RET > 0 builds with LDS to spare): one more step per wave kept in LDS (TG x 1 KiB per wave) instead of registers
+template <int PASS, bool CHK, int RET>
 __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__ dpl, const unsigned* bits,
                                    const unsigned short* list, int nactive, const double* A0, const double* A1,
-                                   const double* A2, int wave, int lane, double* acc, int* cnt) {
-  const int W = p.W, H = p.H, ntx = p.ntx;
-  const int r = lane >> 3, cq = lane & 7;
-  const double a00 = A0[0], a01 = A0[1], a02 = A0[2];
-  const double a20 = A2[0], a21 = A2[1], a22 = A2[2];
-  double a10 = 0, a11 = 0, a12 = 0;
-  if (PASS == 1) { a10 = A1[0]; a11 = A1[1]; a12 = A1[2]; }
+                                   const double* A2, int wave, int lane, double* acc, int* cnt, Keep<RET>& keep,
+                                   uint4* lds_keep = nullptr) {
+  TileCtx c;
+  c.W = p.W; c.H = p.H; c.ntx = p.ntx; c.r = lane >> 3; c.cq = lane & 7;
+  c.a00 = A0[0]; c.a01 = A0[1]; c.a02 = A0[2];
+  c.a20 = A2[0]; c.a21 = A2[1]; c.a22 = A2[2];
+  c.a10 = c.a11 = c.a12 = 0;
+  if (PASS == 1) { c.a10 = A1[0]; c.a11 = A1[1]; c.a12 = A1[2]; }
   double sv[6];
 #pragma unroll
   for (int i = 0; i < (PASS == 0 ? 5 : 6); ++i) sv[i] = acc[i];
   int n = *cnt;
   const bool dense = nactive < 0;                  // list overflow: walk every tile, skip empty ones
-  const int nsteps = dense ? ntx * p.nty : nactive;
-  for (int j0 = wave * TG; j0 < nsteps; j0 += NWAVE * TG) {
-    unsigned nib[TG];
-    int txs[TG], tys[TG];
-    uint4 dq[TG];
+  const int nsteps = dense ? p.ntx * p.nty : nactive;
+  int jstart = wave * TG, kept = 0;
+  if (RET > 0 && !dense) {
+    // the kept steps: pass A issues the loads of ALL of them before it computes (their destination registers are long-lived
+    // anyway, so RET x TG tiles are in flight per wave at no register cost); pass B touches no memory
+    if (PASS == 0) {
 #pragma unroll
-    for (int g = 0; g < TG; ++g) {   // stage 1: bit-image nibbles, then all depth loads back to back
-      const int j = j0 + g;
-      nib[g] = 0; txs[g] = 0; tys[g] = 0;
-      dq[g] = make_uint4(0u, 0u, 0u, 0u);
-      if (j < nsteps) {
-        int tx, ty;
-        if (dense) { ty = j / ntx; tx = j - ty * ntx; }
-        else {
-          // pass B walks the list backwards: the tiles pass A read last are re-read first (L2 reuse)
-          const unsigned t = __builtin_amdgcn_readfirstlane((unsigned)list[PASS == 1 ? nsteps - 1 - j : j]);  // wave-uniform -> SGPR
-          tx = (int)(t & 0xffu); ty = (int)(t >> 8);
-        }
-        txs[g] = tx; tys[g] = ty;
-        const int row = ty * 8 + r;
-        if (row < H) nib[g] = (bits[row * ntx + tx] >> (cq * 4)) & 0xFu;
+      for (int s = 0; s < RET; ++s) {
+        const int j0 = (s * NWAVE + wave) * TG;
+        keep.nib[s] = 0;
+        if (j0 < nsteps) keep.nib[s] = tile_fetch(c, dpl, bits, list, nsteps, false, j0, -1, keep.dq[s]);
       }
     }
 #pragma unroll
-    for (int g = 0; g < TG; ++g)
-      if (nib[g]) dq[g] = *reinterpret_cast<const uint4*>(dpl + (long long)(tys[g] * 8 + r) * W + txs[g] * 32 + cq * 4);
-#pragma unroll
-    for (int g = 0; g < TG; ++g) {   // stage 2: compute (all lanes; unmasked lanes carry zeros / NaNs)
-      if (dense && __ballot(nib[g] != 0) == 0) continue;
-      const unsigned db[4] = {dq[g].x, dq[g].y, dq[g].z, dq[g].w};
-      const double vd = (double)(tys[g] * 8 + r), ud = (double)(txs[g] * 32 + cq * 4);
-      const double r0 = fma(a00, ud, fma(a01, vd, a02));
-      const double r2 = fma(a20, ud, fma(a21, vd, a22));
-      double r1 = 0;
-      if (PASS == 1) r1 = fma(a10, ud, fma(a11, vd, a12));
-      quad_math<PASS, CHK>(nib[g], db, r0, r1, r2, a00, a10, a20, sv, &n);
+    for (int s = 0; s < RET; ++s) {
+      const int j0 = (s * NWAVE + wave) * TG;
+      if (j0 < nsteps) tile_compute<PASS, CHK>(c, list, nsteps, false, j0, -1, keep.dq[s], keep.nib[s], sv, &n);
     }
+    jstart = (RET * NWAVE + wave) * TG;
+    kept = RET * NWAVE * TG;
+    if (lds_keep != nullptr) {   // uniform
+      if (jstart < nsteps) {
+        // per wave: TG x 1 KiB of quads, then one word of nibbles per lane
+        unsigned char* base = reinterpret_cast<unsigned char*>(lds_keep) + wave * LDS_KEEP_WAVE;
+        uint4* slot = reinterpret_cast<uint4*>(base) + lane;
+        unsigned* nslot = reinterpret_cast<unsigned*>(base + TG * 1024) + lane;
+        uint4 dq[TG];
+        unsigned pk;
+        if (PASS == 0) {
+          pk = tile_fetch(c, dpl, bits, list, nsteps, false, jstart, -1, dq);
+#pragma unroll
+          for (int g = 0; g < TG; ++g) slot[g * 64] = dq[g];
+          *nslot = pk;
+        } else {
+#pragma unroll
+          for (int g = 0; g < TG; ++g) dq[g] = slot[g * 64];
+          pk = *nslot;
+        }
+        tile_compute<PASS, CHK>(c, list, nsteps, false, jstart, -1, dq, pk, sv, &n);
+      }
+      jstart += NWAVE * TG;
+      kept += NWAVE * TG;
+    }
+  }
+  const int rev_base = (PASS == 1 && !dense) ? kept + nsteps - 1 : -1;
+  for (int j0 = jstart; j0 < nsteps; j0 += NWAVE * TG) {
+    uint4 dq[TG];
+    const unsigned pk = tile_fetch(c, dpl, bits, list, nsteps, dense, j0, rev_base, dq);
+    tile_compute<PASS, CHK>(c, list, nsteps, dense, j0, rev_base, dq, pk, sv, &n);
   }
 #pragma unroll
   for (int i = 0; i < (PASS == 0 ? 5 : 6); ++i) acc[i] = sv[i];
@@ -316,8 +405,8 @@ __device__ inline void yaw_rows(const Shared* sh, const double* Mg, double* N0, 
 // ------------------------------------------------------------------------------------------
 // instance engine: one workgroup per instance
 // ------------------------------------------------------------------------------------------
-template <bool VEC, bool LDSMASK, bool SAMPLE, bool TILED, bool RLE>
-__global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitParams p) {
+template <bool VEC, bool LDSMASK, bool SAMPLE, bool TILED, bool RLE, int RET>
+__global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : NT / 64) void fit_instances_kernel(const FitParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned* bits = reinterpret_cast<unsigned*>(smem);
   Shared* sh = reinterpret_cast<Shared*>(smem + p.mask_lds_bytes);
@@ -374,16 +463,40 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
 #ifndef LA3D_P0_NT
 #define LA3D_P0_NT 1
 #endif
-#pragma unroll LA3D_P0_UNROLL
+      // Optimistic form: np.bool_ planes (the reference's layout, src/util.py:367,382) hold only 0 and 1, and then the
+      // 16-bit pattern of a 16-byte group is four dot products (sum byte_j * 2^j) - 11 VALU instructions per group instead
+      // of 27 for the general non-zero test.  Every word is ORed into `seen`; a byte above 1 anywhere in the plane sends the
+      // whole workgroup through the general loop below (same bit image either way).
+      unsigned seen = 0;
+#pragma unroll (RET > 0 ? 2 * LA3D_P0_UNROLL : LA3D_P0_UNROLL)
       for (int g = tid; g < ngroups; g += NT) {
 #if LA3D_P0_NT
         const u32x4 w = __builtin_nontemporal_load(m4 + g);
 #else
         const u32x4 w = m4[g];
 #endif
-        const unsigned pat = nz16(w.x, w.y, w.z, w.w);
+        const unsigned lo = __builtin_amdgcn_udot4(w.y, 0x80402010u, __builtin_amdgcn_udot4(w.x, 0x08040201u, 0u, false), false);
+        const unsigned hi = __builtin_amdgcn_udot4(w.w, 0x80402010u, __builtin_amdgcn_udot4(w.z, 0x08040201u, 0u, false), false);
+        const unsigned pat = lo | (hi << 8);
+        seen |= (w.x | w.y) | (w.z | w.w);
         b16[g] = (unsigned short)pat;
         nmask += __popc(pat);
+      }
+      const unsigned long long odd = __ballot((seen & 0xfefefefeu) != 0);
+      if (lane == 0) sh->scan[wave] = odd != 0 ? 1u : 0u;
+      __syncthreads();
+      unsigned general = 0;
+#pragma unroll
+      for (int w = 0; w < NWAVE; ++w) general |= sh->scan[w];
+      if (general) {   // uniform: some byte is neither 0 nor 1 (e.g. 255-valued masks)
+        nmask = 0;
+#pragma unroll LA3D_P0_UNROLL
+        for (int g = tid; g < ngroups; g += NT) {
+          const u32x4 w = m4[g];
+          const unsigned pat = nz16(w.x, w.y, w.z, w.w);
+          b16[g] = (unsigned short)pat;
+          nmask += __popc(pat);
+        }
       }
     } else {
       for (int g = tid; g < ngroups; g += NT) {
@@ -551,9 +664,14 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
   // TILED: optimistic pass first (no per-pixel finite test); a non-finite masked depth shows up as non-finite sums and
   // the workgroup falls back to the checked passes.  Same records either way.
   bool checked = !TILED;
+  Keep<RET> keep;   // RET > 0: depth quads of the first RET steps of this wave, kept in registers for pass B
+  uint4* lds_keep = (RET > 0 && p.lds_keep_off > 0) ? reinterpret_cast<uint4*>(smem + p.lds_keep_off) : nullptr;
 #ifndef LA3D_ABL_NO_PASSA
   if (!sampled) {
-    if (TILED) sweep_tiled<0, false>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt);
+    if (TILED) {
+      sweep_tiled<0, false, RET>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, lds_keep);
+      cnt = nmask;   // the optimistic pass does not count: with every masked depth finite, valid pixels = mask pixels
+    }
     else sweep<VEC, LDSMASK, 0>(p, dpl, mpl, bits, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, &nmask);
   }
 #else
@@ -568,7 +686,7 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
     for (int i = 0; i < 5; ++i) acc[i] = 0;
     cnt = 0;
     checked = true;
-    sweep_tiled<0, true>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt);
+    sweep_tiled<0, true, RET>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, lds_keep);
     stage_moments_to_axis(sh, p, inst, acc, cnt, nmask, tid, wave, lane, false);
   }
   LA3D_STAMP(4);
@@ -590,8 +708,8 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
     yaw_rows(sh, Mg, N0, N2);
     int d0 = 0, d1 = 0;
     if (TILED) {
-      if (checked) sweep_tiled<1, true>(p, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0);
-      else sweep_tiled<1, false>(p, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0);
+      if (checked) sweep_tiled<1, true, RET>(p, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0, keep, lds_keep);
+      else sweep_tiled<1, false, RET>(p, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0, keep, lds_keep);
     }
     else sweep<VEC, LDSMASK, 1>(p, dpl, mpl, bits, N0, Mg + 3, N2, wave, lane, ext, &d0, &d1);
 #else
@@ -1439,9 +1557,9 @@ inline int balance_max_rounds() {
   return v > 0 ? v : 3;  // measured: +21 % at one resident set, +9 % at two, +3 % at three, none at four, negative beyond
 }
 
-template <bool VEC, bool LDSMASK, bool SAMPLE, bool TILED, bool RLE>
+template <bool VEC, bool LDSMASK, bool SAMPLE, bool TILED, bool RLE, int RET = 0>
 int launch_fit_inst(const FitParams& p_in, size_t lds, hipStream_t s, void* workspace) {
-  auto kern = fit_instances_kernel<VEC, LDSMASK, SAMPLE, TILED, RLE>;
+  auto kern = fit_instances_kernel<VEC, LDSMASK, SAMPLE, TILED, RLE, RET>;
   static bool attr_done = false;  // one flag per instantiation
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1456,7 +1574,7 @@ int launch_fit_inst(const FitParams& p_in, size_t lds, hipStream_t s, void* work
   // the O(B^2) ranking is cheap for
   if (workspace && VEC && !SAMPLE && p.B > 256 && p.B <= ORDER_MAX_B && balance_enabled()) {
     const int max_rounds = balance_max_rounds();
-    int wg_per_cu = 2048 / NT;  // wave slots: 32 per CU
+    int wg_per_cu = (RET > 0 ? 1024 : 2048) / NT;  // wave slots: 32 per CU at 64 VGPRs, 16 at 128 (the retaining build)
     const int by_lds = (int)((160 * 1024) / (lds ? lds : 1));
     if (by_lds < wg_per_cu) wg_per_cu = by_lds;
     if (wg_per_cu >= 1 && p.B <= max_rounds * wg_per_cu * 256) {
@@ -1481,10 +1599,21 @@ int launch_fit_inst(const FitParams& p_in, size_t lds, hipStream_t s, void* work
 }
 
 // run-length input is its own instantiation (it needs the LDS bit image), so the u8 kernels carry no decode code
-template <bool VEC, bool LDSMASK, bool SAMPLE, bool TILED = false>
+template <bool VEC, bool LDSMASK, bool SAMPLE, bool TILED = false, int RET = 0>
 int launch_fit(const FitParams& p, size_t lds, hipStream_t s, void* workspace = nullptr) {
-  if (LDSMASK && p.rle_counts != nullptr) return launch_fit_inst<VEC, LDSMASK, SAMPLE, TILED, LDSMASK>(p, lds, s, workspace);
-  return launch_fit_inst<VEC, LDSMASK, SAMPLE, TILED, false>(p, lds, s, workspace);
+  if (LDSMASK && p.rle_counts != nullptr) return launch_fit_inst<VEC, LDSMASK, SAMPLE, TILED, LDSMASK, RET>(p, lds, s, workspace);
+  return launch_fit_inst<VEC, LDSMASK, SAMPLE, TILED, false, RET>(p, lds, s, workspace);
+}
+
+#ifndef LA3D_RET
+#define LA3D_RET 4
+#endif
+inline int retain_steps() {
+  // measurement switch: LA3D_RETAIN=1 selects the 128-VGPR build that keeps up to 160 depth tiles
+  // per instance on chip between the passes.  It moves 15-20 % fewer bytes and is NOT faster (two workgroups per CU instead
+  // of four), so the default is the 64-VGPR build.
+  const char* e = getenv("LA3D_RETAIN");
+  return (e && atoi(e) > 0) ? LA3D_RET : 0;
 }
 
 }  // namespace
@@ -1569,6 +1698,7 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   p.ntx = p.nty = p.tiles_per_wave = p.list_cap = 0;
   p.rcp_ntx = 1.0f;
   p.perm = nullptr;
+  p.lds_keep_off = 0;
   const int bit_bytes = ((((p.HW + 15) / 16 + 1) / 2) * 4 + 15) & ~15;  // u16 per 16 px, padded to u32, 16-aligned
   const bool ldsmask = bit_bytes <= MAX_MASK_LDS;
   p.mask_lds_bytes = ldsmask ? bit_bytes : 0;
@@ -1608,13 +1738,22 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
     const long ntiles = (long)p.ntx * p.nty;
     const long want = ntiles < 256 ? ntiles : 256;
     long cap = 0;
-    for (int wg_per_cu = 4; wg_per_cu >= 1 && cap < want; --wg_per_cu) {
+    const int ret = retain_steps();
+    for (int wg_per_cu = ret > 0 ? 2 : 4; wg_per_cu >= 1 && cap < want; --wg_per_cu) {
       const long budget = (160 * 1024 / wg_per_cu) & ~15L;
       cap = (budget - (long)fixed) / 2;
     }
     if (cap > ntiles) cap = ntiles;
     if (cap >= 64) {
       p.list_cap = (int)cap;
+      if (ret > 0) {
+        // one more kept step per wave in LDS when two workgroups per CU leave the room (NWAVE x LDS_KEEP_WAVE bytes)
+        size_t tot = (fixed + (size_t)cap * 2 + 15) & ~(size_t)15;
+        const size_t keep_bytes = (size_t)NWAVE * LDS_KEEP_WAVE;
+        const char* e = getenv("LA3D_LDSKEEP");
+        if (!(e && e[0] == '0') && tot + keep_bytes <= 80 * 1024) { p.lds_keep_off = (int)tot; tot += keep_bytes; }
+        return launch_fit<true, true, false, true, LA3D_RET>(p, tot, s, workspace);
+      }
       return launch_fit<true, true, false, true>(p, fixed + (size_t)cap * 2, s, workspace);
     }
   }

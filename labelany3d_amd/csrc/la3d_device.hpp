@@ -319,6 +319,7 @@ struct FitParams {
   int list_cap;        // TILED: entries of the active-tile list that fit the LDS budget
   float rcp_ntx;       // TILED: 1 / ntx
   const int* perm;     // launch order: workgroup b fits instance perm[b] (nullptr: xcd_remap(b))
+  int lds_keep_off;    // retaining build: byte offset in dynamic LDS of the per-wave kept step (0: none)
   double* out;
   int* status;
   double* aux;
@@ -376,7 +377,7 @@ __device__ inline void quad_math(unsigned nib, const unsigned* db, double r0, do
       const double x = d * r0, z = d * r2;
       s[0] += x; s[1] += z;
       s[2] = fma(x, x, s[2]); s[3] = fma(x, z, s[3]); s[4] = fma(z, z, s[4]);
-      *n -= m;
+      if (CHK) *n -= m;   // the optimistic form does not count: its caller takes the mask popcount
     } else {
       const double d = (double)__uint_as_float(db[k] | ~(unsigned)m);  // invalid -> NaN, ignored by min/max
       const double x = d * r0, y = d * r1, z = d * r2;

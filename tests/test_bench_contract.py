@@ -50,5 +50,25 @@ def test_bench_prints_one_contract_line():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert 0.0 < r["frac"] < 1.0, r["frac"]                      # a fraction of a physical roof
+    assert r["required_bytes_per_launch"] < r["algorithmic_bytes_per_launch"] and "byte_model" in r
+    assert abs(r["achieved"] - r["required_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert r["traffic_stale"] in (True, False, None)
     assert abs(d["value"] - 5 * 1024 / (d["ms_per_step"] * 5e-3)) / d["value"] < 1e-6
     assert d["value"] > 2.08e6   # BASELINE target: 40 % of the HBM-read roofline
+
+
+def test_required_bytes_model():
+    """bench.required_bytes: mask planes once + 1 KiB per 32x8 tile that holds a mask pixel + records (CPU tensors)."""
+    import torch
+
+    import bench
+
+    m = torch.zeros((3, 480, 640), dtype=torch.uint8)
+    m[0, 0, 0] = 1                       # one tile
+    m[1, 7:9, 31:33] = 1                 # straddles 2x2 tiles
+    req, tiles = bench.required_bytes(m)  # plane 2 empty
+    assert tiles == 5 and req == 3 * 480 * 640 + 5 * 1024 + 3 * 312
+    m2 = torch.ones((1, 50, 70), dtype=torch.uint8)   # ragged frame: ceil(50/8) x ceil(70/32) tiles
+    assert bench.required_bytes(m2)[1] == 7 * 3
+    assert len(bench.kernel_source_sha256()) == 64
