@@ -123,6 +123,31 @@ int la3d_mask_stats(const uint8_t* mask, int B, int H, int W, int boundary, int3
 int la3d_mask_stats_rle(const int32_t* counts, const int64_t* offsets, int B, int H, int W, int boundary, int32_t* stats,
                         void* stream);
 
+/* ---- polygon segmentations: the branch every kept COCONut instance takes in the reference -----------------------
+ * create_boolean_mask_from_polygon (src/util.py:386-400; producer src/download_coconut.py:178-199, :275-280): every part
+ * of a segmentation is truncated to int32 vertices (np.array(polygon).reshape(-1,2).astype(np.int32) — done by the
+ * caller) and filled on its own with cv2.fillPoly(mask, [points], 1): OpenCV's drawing.cpp rule for 8-bit images,
+ * LINE_8, shift 0 (sides drawn with the 8-connected LineIterator + even-odd scanline fill in 16.16 fixed point; parts
+ * are OR-ed).  Layout: poly_xy dev i32 [total_points][2] (x, y); ring_offsets dev i64 [R+1] point offsets of the parts;
+ * inst_rings dev i64 [B+1] part offsets of the instances (instance n = parts inst_rings[n]..inst_rings[n+1]).
+ * Vertices may lie outside the frame (clipped like cv::clipLine).  H*W <= 1048576. */
+
+/* la3d_fit_instances with the masks given as polygon parts, rasterised straight into the kernel's LDS bit image (no
+ * 1 B/px plane exists anywhere).  All other arguments as la3d_fit_instances. */
+int la3d_fit_instances_poly(const float* depth, int64_t depth_plane_stride, const int32_t* image_index,
+                            const int32_t* poly_xy, const int64_t* ring_offsets, const int64_t* inst_rings,
+                            const double* K, int32_t k_stride, const double* ground, const int32_t* sample_idx,
+                            int B, int H, int W, double* out, int32_t* status, double* aux, void* workspace, void* stream);
+
+/* create_boolean_mask_from_polygon for a batch: polygon parts -> u8 planes mask_out dev [B][H*W] (0/1). */
+int la3d_poly_decode(const int32_t* poly_xy, const int64_t* ring_offsets, const int64_t* inst_rings, int B, int H, int W,
+                     uint8_t* mask_out, void* stream);
+
+/* The four filter quantities of la3d_mask_stats for polygon annotations, rasterised in LDS (no plane is written):
+ * replaces create_boolean_mask_from_polygon + get_maximum_height + analyze_mask (src/util.py:291-335, :371-375). */
+int la3d_mask_stats_poly(const int32_t* poly_xy, const int64_t* ring_offsets, const int64_t* inst_rings, int B, int H, int W,
+                         int boundary, int32_t* stats, void* stream);
+
 /* HOST helper: COCO compressed RLE string (pycocotools rleFrString) -> run lengths.  Returns the number of
  * counts written, or -1 (malformed string / cap too small). */
 int la3d_rle_from_string_host(const char* s, int64_t len, int32_t* counts, int cap);

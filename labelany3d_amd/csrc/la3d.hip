@@ -20,6 +20,7 @@
 //   pass B   same walk, six extents in the yaw frame with NaN-ignoring raw v_min/v_max_f64;
 //   epilog   wave 0 writes center / dims / R_cam / fp16-quantised vertices, one lane per output group.
 #include "la3d_device.hpp"
+#include "la3d_poly.hpp"
 
 namespace la3d {
 thread_local char g_err[256] = "";
@@ -405,8 +406,10 @@ __device__ inline void yaw_rows(const Shared* sh, const double* Mg, double* N0, 
 // ------------------------------------------------------------------------------------------
 // instance engine: one workgroup per instance
 // ------------------------------------------------------------------------------------------
-template <bool VEC, bool LDSMASK, bool SAMPLE, bool TILED, bool RLE, int RET>
+// SRC: where the mask comes from - 0 = u8 plane, 1 = COCO run lengths, 2 = polygon parts (both decoded into the LDS bit image)
+template <bool VEC, bool LDSMASK, bool SAMPLE, bool TILED, int SRC, int RET>
 __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : NT / 64) void fit_instances_kernel(const FitParams p) {
+  constexpr bool RLE = SRC == 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned* bits = reinterpret_cast<unsigned*>(smem);
   Shared* sh = reinterpret_cast<Shared*>(smem + p.mask_lds_bytes);
@@ -452,6 +455,12 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : NT / 64) void fit_instance
     // masks arrive as COCO run lengths: decode straight into the LDS bit image — no u8 plane is ever read
     const long long o0 = p.rle_offsets[inst];
     nmask = rle_to_bits<NT>(p.rle_counts + o0, (int)(p.rle_offsets[inst + 1] - o0), bits, p.nwords, p.H, p.W, sh->scan, tid);
+  } else if (LDSMASK && SRC == 2) {
+    // masks arrive as polygon parts (the reference's create_boolean_mask_from_polygon, src/util.py:386-400): rasterised with
+    // cv2.fillPoly's rule straight into the LDS bit image; the side stage borrows the space of the tile list
+    nmask = poly_to_bits<NT>(p.poly_xy, p.poly_ring_off, p.poly_inst_rings[inst], p.poly_inst_rings[inst + 1],
+                             reinterpret_cast<PolySide*>(smem + p.mask_lds_bytes + sizeof(Shared)), sh->scan, bits, p.nwords, p.H,
+                             p.W, tid);
   } else if (LDSMASK) {
     unsigned short* b16 = reinterpret_cast<unsigned short*>(bits);
     const int ngroups = (HW + 15) >> 4;
@@ -1058,6 +1067,61 @@ __global__ __launch_bounds__(256) void rle_decode_kernel(const int* __restrict__
   }
 }
 
+// bit image in LDS -> u8 plane (0/1), coalesced 16-byte stores where the plane allows; 256 threads
+__device__ inline void bits_to_plane_256(const unsigned* bits, int HW, unsigned char* o, int tid) {
+  const unsigned short* b16 = reinterpret_cast<const unsigned short*>(bits);
+  if (HW % 16 == 0 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+    for (int g = tid; g < HW / 16; g += 256) {
+      const unsigned pat = b16[g];
+      uint4 v;
+      v.x = ((pat >> 0) & 1u) | (((pat >> 1) & 1u) << 8) | (((pat >> 2) & 1u) << 16) | (((pat >> 3) & 1u) << 24);
+      v.y = ((pat >> 4) & 1u) | (((pat >> 5) & 1u) << 8) | (((pat >> 6) & 1u) << 16) | (((pat >> 7) & 1u) << 24);
+      v.z = ((pat >> 8) & 1u) | (((pat >> 9) & 1u) << 8) | (((pat >> 10) & 1u) << 16) | (((pat >> 11) & 1u) << 24);
+      v.w = ((pat >> 12) & 1u) | (((pat >> 13) & 1u) << 8) | (((pat >> 14) & 1u) << 16) | (((pat >> 15) & 1u) << 24);
+      *reinterpret_cast<uint4*>(o + g * 16) = v;
+    }
+  } else {
+    for (int i = tid; i < HW; i += 256) o[i] = (bits[i >> 5] >> (i & 31)) & 1u;
+  }
+}
+
+// create_boolean_mask_from_polygon for a batch (reference src/util.py:386-400): polygon parts -> u8 planes.  Dynamic LDS:
+// bit image (16-aligned), side stage, flags.
+__global__ __launch_bounds__(256) void poly_decode_kernel(const int* __restrict__ xy, const long long* __restrict__ ring_off,
+                                                          const long long* __restrict__ inst_rings, int H, int W, int nwords,
+                                                          unsigned char* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned* bits = reinterpret_cast<unsigned*>(smem);
+  const size_t bit_bytes = ((size_t)nwords * 4 + 15) & ~(size_t)15;
+  PolySide* stage = reinterpret_cast<PolySide*>(smem + bit_bytes);
+  unsigned* flags = reinterpret_cast<unsigned*>(smem + bit_bytes + POLY_STAGE_BYTES);
+  const int tid = threadIdx.x;
+  (void)poly_to_bits<256>(xy, ring_off, inst_rings[blockIdx.x], inst_rings[blockIdx.x + 1], stage, flags, bits, nwords, H, W, tid);
+  bits_to_plane_256(bits, H * W, out + (long long)blockIdx.x * H * W, tid);
+}
+
+// The reference's filter quantities (mask_stats) for polygon annotations without materialising a plane: rasterise into
+// LDS, count there.  Dynamic LDS: bit image, side stage, flags (64 B), per-row counts (H ints), 20 ints.
+__global__ __launch_bounds__(256) void mask_stats_poly_kernel(const int* __restrict__ xy, const long long* __restrict__ ring_off,
+                                                              const long long* __restrict__ inst_rings, int H, int W, int nwords,
+                                                              int boundary, int* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned* bits = reinterpret_cast<unsigned*>(smem);
+  const size_t bit_bytes = ((size_t)nwords * 4 + 15) & ~(size_t)15;
+  PolySide* stage = reinterpret_cast<PolySide*>(smem + bit_bytes);
+  unsigned* flags = reinterpret_cast<unsigned*>(smem + bit_bytes + POLY_STAGE_BYTES);
+  int* rowcnt = reinterpret_cast<int*>(smem + bit_bytes + POLY_STAGE_BYTES + 64);
+  int* red = rowcnt + H;
+  const int tid = threadIdx.x;
+  (void)poly_to_bits<256>(xy, ring_off, inst_rings[blockIdx.x], inst_rings[blockIdx.x + 1], stage, flags, bits, nwords, H, W, tid);
+  int o4[4];
+  bits_stats_256(bits, H, W, boundary, rowcnt, red, tid, o4);
+  if (tid == 0) {
+    int* o = stats + (long long)blockIdx.x * 4;
+    o[0] = o4[0]; o[1] = o4[1]; o[2] = o4[2]; o[3] = o4[3];
+  }
+}
+
 // The quantities of the reference's instance filter (src/util.py:291-335, :367-376) per mask plane:
 // stats[0] = area, [1] = rows holding a pixel, [2] = last row - first row + 1, [3] = pixels inside the four
 // boundary strips of `boundary` px (corners counted twice, as analyze_mask does).
@@ -1467,13 +1531,30 @@ constexpr int KEY_IDX_BITS = 14;    // sort key = (area quantised to 18 bits) <<
 
 __global__ __launch_bounds__(256) void size_estimate_kernel(const unsigned char* __restrict__ mask,
                                                             const int* __restrict__ rle_counts,
-                                                            const long long* __restrict__ rle_offsets, int B, int HW,
+                                                            const long long* __restrict__ rle_offsets,
+                                                            const int* __restrict__ poly_xy, const long long* __restrict__ poly_ring_off,
+                                                            const long long* __restrict__ poly_inst_rings, int B, int HW,
                                                             int step, int shift, unsigned* __restrict__ keys) {
   const int lane = threadIdx.x & 63;
   const int inst = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (inst >= B) return;
   int c = 0;
-  if (rle_counts) {  // exact: the sum of the ones-runs (odd positions)
+  if (poly_xy) {  // shoelace area of every part (an estimate: parts may overlap or leave the frame)
+    long long tot = 0;
+    for (long long r = poly_inst_rings[inst]; r < poly_inst_rings[inst + 1]; ++r) {
+      const long long p0 = poly_ring_off[r], n = poly_ring_off[r + 1] - p0;
+      long long a2 = 0;
+      for (long long i = lane; i < n; i += 64) {
+        const long long j = (i + 1 == n) ? 0 : i + 1;
+        a2 += (long long)poly_xy[2 * (p0 + i)] * poly_xy[2 * (p0 + j) + 1] - (long long)poly_xy[2 * (p0 + j)] * poly_xy[2 * (p0 + i) + 1];
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) a2 += __shfl_xor(a2, o);
+      tot += (a2 < 0 ? -a2 : a2) / 2;
+    }
+    c = (int)(tot > (long long)HW ? HW : tot);
+    if (lane != 0) c = 0;   // the wave sum below adds the lanes
+  } else if (rle_counts) {  // exact: the sum of the ones-runs (odd positions)
     const long long lo = rle_offsets[inst], hi = rle_offsets[inst + 1];
     for (long long k = lo + 1 + 2 * lane; k < hi; k += 128) {
       const int v = rle_counts[k];
@@ -1557,9 +1638,9 @@ inline int balance_max_rounds() {
   return v > 0 ? v : 3;  // measured: +21 % at one resident set, +9 % at two, +3 % at three, none at four, negative beyond
 }
 
-template <bool VEC, bool LDSMASK, bool SAMPLE, bool TILED, bool RLE, int RET = 0>
+template <bool VEC, bool LDSMASK, bool SAMPLE, bool TILED, int SRC, int RET = 0>
 int launch_fit_inst(const FitParams& p_in, size_t lds, hipStream_t s, void* workspace) {
-  auto kern = fit_instances_kernel<VEC, LDSMASK, SAMPLE, TILED, RLE, RET>;
+  auto kern = fit_instances_kernel<VEC, LDSMASK, SAMPLE, TILED, SRC, RET>;
   static bool attr_done = false;  // one flag per instantiation
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1584,11 +1665,11 @@ int launch_fit_inst(const FitParams& p_in, size_t lds, hipStream_t s, void* work
       int step = 1;
       for (int cand : {EST_STEP, 31, 17, 7, 3})
         if ((p.HW >> 7) / cand >= 64) { step = cand; break; }
-      long long amax = p.rle_counts ? (long long)p.HW : (long long)p.HW / step + 128;
+      long long amax = (p.rle_counts || p.poly_xy) ? (long long)p.HW : (long long)p.HW / step + 128;
       int shift = 0;
       while ((amax >> shift) > 0x3ffff) ++shift;
-      hipLaunchKernelGGL(size_estimate_kernel, dim3((p.B + 3) / 4), dim3(256), 0, s, p.mask, p.rle_counts, p.rle_offsets, p.B,
-                         p.HW, step, shift, est);
+      hipLaunchKernelGGL(size_estimate_kernel, dim3((p.B + 3) / 4), dim3(256), 0, s, p.mask, p.rle_counts, p.rle_offsets, p.poly_xy,
+                         p.poly_ring_off, p.poly_inst_rings, p.B, p.HW, step, shift, est);
       hipLaunchKernelGGL(launch_order_kernel, dim3((p.B + 63) / 64), dim3(ORDER_WAVES * 64), 0, s, est, p.B, wg_per_cu * 256,
                          perm);
       p.perm = perm;
@@ -1601,8 +1682,9 @@ int launch_fit_inst(const FitParams& p_in, size_t lds, hipStream_t s, void* work
 // run-length input is its own instantiation (it needs the LDS bit image), so the u8 kernels carry no decode code
 template <bool VEC, bool LDSMASK, bool SAMPLE, bool TILED = false, int RET = 0>
 int launch_fit(const FitParams& p, size_t lds, hipStream_t s, void* workspace = nullptr) {
-  if (LDSMASK && p.rle_counts != nullptr) return launch_fit_inst<VEC, LDSMASK, SAMPLE, TILED, LDSMASK, RET>(p, lds, s, workspace);
-  return launch_fit_inst<VEC, LDSMASK, SAMPLE, TILED, false, RET>(p, lds, s, workspace);
+  if (LDSMASK && p.rle_counts != nullptr) return launch_fit_inst<VEC, LDSMASK, SAMPLE, TILED, LDSMASK ? 1 : 0, RET>(p, lds, s, workspace);
+  if (LDSMASK && p.poly_xy != nullptr) return launch_fit_inst<VEC, LDSMASK, SAMPLE, TILED, LDSMASK ? 2 : 0, RET>(p, lds, s, workspace);
+  return launch_fit_inst<VEC, LDSMASK, SAMPLE, TILED, 0, RET>(p, lds, s, workspace);
 }
 
 #ifndef LA3D_RET
@@ -1670,12 +1752,16 @@ int la3d_mask_counts(const uint8_t* mask, int B, int H, int W, int32_t* counts, 
   return check_launch("mask_counts_kernel");
 }
 
+struct PolyArgs { const int32_t* xy; const int64_t* ring_off; const int64_t* inst_rings; };
+
 static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const int32_t* image_index, const uint8_t* mask,
                         const int32_t* rle_counts, const int64_t* rle_offsets, const double* K, int32_t k_stride,
                         const double* ground, const int32_t* sample_idx, int B, int H, int W, double* out,
-                        int32_t* status, double* aux, void* workspace, void* stream, const char* who) {
-  const bool rle = rle_counts != nullptr;
-  if (!depth || (!mask && !rle) || (rle && !rle_offsets) || !K || !out || !status || B < 0 || H <= 0 || W <= 0 ||
+                        int32_t* status, double* aux, void* workspace, void* stream, const char* who,
+                        const PolyArgs* poly = nullptr) {
+  const bool rle = rle_counts != nullptr || poly != nullptr;   // "no u8 plane": the mask is decoded into the LDS bit image
+  if (!depth || (!mask && !rle) || (rle_counts && !rle_offsets) || (poly && (!poly->ring_off || !poly->inst_rings)) || !K ||
+      !out || !status || B < 0 || H <= 0 || W <= 0 ||
       depth_plane_stride < 0 || (k_stride != 0 && k_stride < 9) || (long long)H * W > (1LL << 28)) {
     snprintf(g_err, sizeof(g_err), "%s: bad argument", who);
     return LA3D_ERR_ARG;
@@ -1690,6 +1776,9 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   p.depth = depth; p.depth_plane_stride = depth_plane_stride; p.image_index = image_index;
   p.mask = mask; p.K = K; p.k_stride = k_stride; p.ground = ground; p.sample_idx = sample_idx;
   p.rle_counts = rle_counts; p.rle_offsets = reinterpret_cast<const long long*>(rle_offsets);
+  p.poly_xy = poly ? poly->xy : nullptr;
+  p.poly_ring_off = poly ? reinterpret_cast<const long long*>(poly->ring_off) : nullptr;
+  p.poly_inst_rings = poly ? reinterpret_cast<const long long*>(poly->inst_rings) : nullptr;
   p.B = B; p.H = H; p.W = W; p.HW = H * W;
   p.nwords = (p.HW + 31) / 32;
   p.rows_aligned = (W % 4 == 0);
@@ -1703,7 +1792,7 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   const bool ldsmask = bit_bytes <= MAX_MASK_LDS;
   p.mask_lds_bytes = ldsmask ? bit_bytes : 0;
   if (rle && !ldsmask) {
-    snprintf(g_err, sizeof(g_err), "%s: run-length masks need the bit image in LDS (H*W <= 1048576)", who);
+    snprintf(g_err, sizeof(g_err), "%s: run-length / polygon masks need the bit image in LDS (H*W <= 1048576)", who);
     return LA3D_ERR_UNSUPPORTED;
   }
   // 16-byte vector path: every plane base 16-aligned (the u8 mask only when it is read at all)
@@ -1711,6 +1800,8 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
                    ((reinterpret_cast<uintptr_t>(depth) & 15) == 0) && (depth_plane_stride % 4 == 0);
   const bool sample = sample_idx != nullptr;
   size_t lds = (size_t)p.mask_lds_bytes + sizeof(Shared);
+  // polygons: the side stage sits behind Shared, where the tile list / rank prefix go later (disjoint in time)
+  const size_t poly_stage = poly ? (size_t)POLY_STAGE_BYTES : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (!rle && split_eligible(p, vec, ldsmask)) return split_fit(p, workspace, s);
   if (sample) {
@@ -1718,7 +1809,7 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
       snprintf(g_err, sizeof(g_err), "%s: reference-subsample mode needs the bit image in LDS (H*W <= 1048576)", who);
       return LA3D_ERR_UNSUPPORTED;
     }
-    lds += (size_t)p.nwords * 4 + 16;
+    lds += (size_t)p.nwords * 4 + 16 > poly_stage ? (size_t)p.nwords * 4 + 16 : poly_stage;
     if (lds > 160 * 1024 - 256) {
       snprintf(g_err, sizeof(g_err), "%s: reference-subsample mode: frame too large for LDS", who);
       return LA3D_ERR_UNSUPPORTED;
@@ -1748,15 +1839,16 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
       p.list_cap = (int)cap;
       if (ret > 0) {
         // one more kept step per wave in LDS when two workgroups per CU leave the room (NWAVE x LDS_KEEP_WAVE bytes)
-        size_t tot = (fixed + (size_t)cap * 2 + 15) & ~(size_t)15;
+        size_t tot = (fixed + ((size_t)cap * 2 > poly_stage ? (size_t)cap * 2 : poly_stage) + 15) & ~(size_t)15;
         const size_t keep_bytes = (size_t)NWAVE * LDS_KEEP_WAVE;
         const char* e = getenv("LA3D_LDSKEEP");
         if (!(e && e[0] == '0') && tot + keep_bytes <= 80 * 1024) { p.lds_keep_off = (int)tot; tot += keep_bytes; }
         return launch_fit<true, true, false, true, LA3D_RET>(p, tot, s, workspace);
       }
-      return launch_fit<true, true, false, true>(p, fixed + (size_t)cap * 2, s, workspace);
+      return launch_fit<true, true, false, true>(p, fixed + ((size_t)cap * 2 > poly_stage ? (size_t)cap * 2 : poly_stage), s, workspace);
     }
   }
+  lds += poly_stage;
   if (ldsmask) return vec ? launch_fit<true, true, false>(p, lds, s, workspace) : launch_fit<false, true, false>(p, lds, s);
   return vec ? launch_fit<true, false, false>(p, lds, s) : launch_fit<false, false, false>(p, lds, s);
 }
@@ -1779,6 +1871,19 @@ int la3d_fit_instances_rle(const float* depth, int64_t depth_plane_stride, const
   }
   return fit_dispatch(depth, depth_plane_stride, image_index, nullptr, rle_counts, rle_offsets, K, k_stride, ground,
                       sample_idx, B, H, W, out, status, aux, workspace, stream, "la3d_fit_instances_rle");
+}
+
+int la3d_fit_instances_poly(const float* depth, int64_t depth_plane_stride, const int32_t* image_index,
+                            const int32_t* poly_xy, const int64_t* ring_offsets, const int64_t* inst_rings, const double* K,
+                            int32_t k_stride, const double* ground, const int32_t* sample_idx, int B, int H, int W, double* out,
+                            int32_t* status, double* aux, void* workspace, void* stream) {
+  if ((!poly_xy || !ring_offsets || !inst_rings) && B > 0) {
+    set_err("la3d_fit_instances_poly: bad argument");
+    return LA3D_ERR_ARG;
+  }
+  const PolyArgs pa{poly_xy, ring_offsets, inst_rings};
+  return fit_dispatch(depth, depth_plane_stride, image_index, nullptr, nullptr, nullptr, K, k_stride, ground, sample_idx, B, H, W,
+                      out, status, aux, workspace, stream, "la3d_fit_instances_poly", &pa);
 }
 
 int la3d_rle_from_string_host(const char* s, int64_t len, int32_t* counts, int cap) {
@@ -1823,6 +1928,56 @@ int la3d_rle_decode(const int32_t* counts, const int64_t* offsets, int B, int H,
   hipLaunchKernelGGL(rle_decode_kernel, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), counts,
                      reinterpret_cast<const long long*>(offsets), H, W, nwords, mask_out);
   return check_launch("rle_decode_kernel");
+}
+
+int la3d_poly_decode(const int32_t* poly_xy, const int64_t* ring_offsets, const int64_t* inst_rings, int B, int H, int W,
+                     uint8_t* mask_out, void* stream) {
+  if (((!poly_xy || !ring_offsets || !inst_rings || !mask_out) && B > 0) || B < 0 || H <= 0 || W <= 0 ||
+      (long long)H * W > (1LL << 20)) {
+    set_err("la3d_poly_decode: bad argument (H*W <= 1048576)");
+    return LA3D_ERR_ARG;
+  }
+  if (B == 0) return LA3D_SUCCESS;
+  const int nwords = (H * W + 31) / 32;
+  const size_t lds = (((size_t)nwords * 4 + 15) & ~(size_t)15) + POLY_STAGE_BYTES + 64;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(poly_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      (void)hipGetLastError();
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(poly_decode_kernel, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), poly_xy,
+                     reinterpret_cast<const long long*>(ring_offsets), reinterpret_cast<const long long*>(inst_rings), H, W, nwords,
+                     mask_out);
+  return check_launch("poly_decode_kernel");
+}
+
+int la3d_mask_stats_poly(const int32_t* poly_xy, const int64_t* ring_offsets, const int64_t* inst_rings, int B, int H, int W,
+                         int boundary, int32_t* stats, void* stream) {
+  if (((!poly_xy || !ring_offsets || !inst_rings || !stats) && B > 0) || B < 0 || H <= 0 || W <= 0 || boundary < 0 ||
+      (long long)H * W > (1LL << 20)) {
+    set_err("la3d_mask_stats_poly: bad argument (H*W <= 1048576)");
+    return LA3D_ERR_ARG;
+  }
+  if (B == 0) return LA3D_SUCCESS;
+  const int nwords = (H * W + 31) / 32;
+  const size_t lds = (((size_t)nwords * 4 + 15) & ~(size_t)15) + POLY_STAGE_BYTES + 64 + (size_t)H * 4 + 128;
+  if (lds > 160 * 1024 - 256) {
+    set_err("la3d_mask_stats_poly: frame too large for LDS");
+    return LA3D_ERR_UNSUPPORTED;
+  }
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mask_stats_poly_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      (void)hipGetLastError();
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(mask_stats_poly_kernel, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), poly_xy,
+                     reinterpret_cast<const long long*>(ring_offsets), reinterpret_cast<const long long*>(inst_rings), H, W, nwords,
+                     boundary, stats);
+  return check_launch("mask_stats_poly_kernel");
 }
 
 static void stats_lds_attr() {  // rows beyond 16 K need more than the default 64 KiB of dynamic LDS
@@ -1930,7 +2085,7 @@ int la3d_iou_matrix(const double* boxes_a, int na, const double* boxes_b, int nb
 
 int la3d_fit_points(const double* points, const int64_t* offsets, const double* ground, const int32_t* sample_idx,
                     int method, int B, double* out, int32_t* status, double* aux, void* stream) {
-  if (!offsets || !out || !status || B < 0 || (B > 0 && !points && false)) {
+  if (B < 0 || (B > 0 && (!offsets || !out || !status || !points))) {
     set_err("la3d_fit_points: bad argument");
     return LA3D_ERR_ARG;
   }

@@ -314,6 +314,9 @@ struct FitParams {
   double* geo;         // workspace: [B][GEO_D]
   const int* rle_counts;        // masks given as COCO run lengths (column-major, zeros first) instead of u8 planes
   const long long* rle_offsets; // [B+1] into rle_counts
+  const int* poly_xy;           // masks given as polygon parts: int32 (x, y) pairs ...
+  const long long* poly_ring_off;   // ... [R+1] point offsets of the parts ...
+  const long long* poly_inst_rings; // ... [B+1] part offsets of the instances
   int ntx, nty;        // TILED: tiles of 32 px x 8 rows (ntx = W/32, nty = ceil(H/8))
   int tiles_per_wave;  // TILED: ceil(ntx*nty / NWAVE)
   int list_cap;        // TILED: entries of the active-tile list that fit the LDS budget

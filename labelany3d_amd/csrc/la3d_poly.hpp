@@ -1,0 +1,270 @@
+// la3d_poly.hpp — polygon segmentations -> 1-bit-per-pixel image in LDS, with the semantics of the reference's
+// create_boolean_mask_from_polygon (/root/reference/src/util.py:386-400): every part (ring) of an instance is truncated to
+// int32 vertices on the host and filled on its own by cv2.fillPoly(mask, [points], 1) — OpenCV's drawing.cpp for an 8-bit
+// image, LINE_8, shift 0: CollectPolyEdges (each side drawn with the 8-connected LineIterator, clipped by clipLine, and turned
+// into a 16.16 fixed-point scan edge) + FillEdgeCollection (even-odd pairing of the x-sorted crossings of every scanline
+// y0 <= y < y1, columns x_left >> 16 .. x_right >> 16 inclusive).  The CPU restatement is oracle/poly_oracle.py (PARITY UNPINNED
+// against OpenCV itself: cv2 is not installed in the build container; see that file's header for what is pinned).
+//
+// GPU form (poly_to_bits): the sides of a ring go through LDS 32 at a time — one thread computes a side (clipLine, scan edge),
+// one wave paints its Bresenham pixels lane-parallel from the closed form  minor(i) = floor((2 i dmin + dmaj - 1) / (2 dmaj));
+// every scanline (one thread each) keeps the 8 smallest crossings in (x, side) order in registers while the sides stream by
+// and then ORs the paired spans into the bit image word by word; a scanline with more than 8 crossings takes further sweeps.
+// No global scratch, any number of sides / crossings.
+#pragma once
+#include "la3d_device.hpp"
+
+namespace la3d {
+
+struct alignas(8) PolyEdge {
+  int y0, y1;        // y0 < y1; y0 == y1: not a scan edge (horizontal side)
+  long long x, dx;   // 16.16 fixed point: x at scanline y0, increment per scanline
+};
+
+// one polygon side staged in LDS: its scan edge and the (clipped) segment Line() draws
+struct alignas(8) PolySide {
+  PolyEdge e;
+  int sx, sy, ex, ey;   // left-to-right end points of the drawn segment; sx > ex: nothing to draw
+};
+
+constexpr int POLY_XY_SHIFT = 16;
+constexpr int POLY_CHUNK = 32;                                   // sides staged per step
+constexpr int POLY_STAGE_BYTES = POLY_CHUNK * (int)sizeof(PolySide);
+constexpr int POLY_KEEP = 8;                                     // crossings a scanline keeps per sweep (more: another sweep)
+
+// cv::clipLine(Size2l, Point2l&, Point2l&): end points are updated in place even when the line misses the image
+__device__ inline bool poly_clip_line(long long width, long long height, long long& x1, long long& y1, long long& x2, long long& y2) {
+  const long long right = width - 1, bottom = height - 1;
+  int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+  int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+  if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+    long long a;
+    if (c1 & 12) {
+      a = c1 < 8 ? 0 : bottom;
+      x1 += (long long)((double)(a - y1) * (double)(x2 - x1) / (double)(y2 - y1));
+      y1 = a;
+      c1 = (x1 < 0) + (x1 > right) * 2;
+    }
+    if (c2 & 12) {
+      a = c2 < 8 ? 0 : bottom;
+      x2 += (long long)((double)(a - y2) * (double)(x2 - x1) / (double)(y2 - y1));
+      y2 = a;
+      c2 = (x2 < 0) + (x2 > right) * 2;
+    }
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+      if (c1) {
+        a = c1 == 1 ? 0 : right;
+        y1 += (long long)((double)(a - x1) * (double)(y2 - y1) / (double)(x2 - x1));
+        x1 = a;
+        c1 = 0;
+      }
+      if (c2) {
+        a = c2 == 1 ? 0 : right;
+        y2 += (long long)((double)(a - x2) * (double)(y2 - y1) / (double)(x2 - x1));
+        x2 = a;
+        c2 = 0;
+      }
+    }
+  }
+  return (c1 | c2) == 0;
+}
+
+// One polygon side p0 -> p1 (one thread): CollectPolyEdges for line_type 8, shift 0, offset 0 — the segment Line() draws
+// (LineIterator: 8-connected, left to right, clipped) and the scan edge.
+__device__ inline PolySide poly_side(int x0i, int y0i, int x1i, int y1i, int W, int H) {
+  const long long px0 = x0i, py0 = y0i, px1 = x1i, py1 = y1i;
+  long long ax = px0, ay = py0, bx = px1, by = py1;
+  const bool inside = (unsigned long long)px0 < (unsigned long long)W && (unsigned long long)px1 < (unsigned long long)W &&
+                      (unsigned long long)py0 < (unsigned long long)H && (unsigned long long)py1 < (unsigned long long)H;
+  bool draw = true;
+  if (!inside) draw = poly_clip_line(W, H, ax, ay, bx, by);
+  // (ax, ay, bx, by) are also what CollectPolyEdges sees after its own clipLine call (same function, same inputs)
+  PolySide s;
+  if (draw) {
+    if (bx < ax) { s.sx = (int)bx; s.sy = (int)by; s.ex = (int)ax; s.ey = (int)ay; }    // start from the left end point
+    else { s.sx = (int)ax; s.sy = (int)ay; s.ex = (int)bx; s.ey = (int)by; }
+  } else {
+    s.sx = 1; s.ex = 0; s.sy = s.ey = 0;
+  }
+  PolyEdge& e = s.e;
+  e.y0 = e.y1 = 0; e.x = e.dx = 0;
+  if (py0 == py1) return s;                                       // horizontal sides are not swept
+  long long c0x = (px0 << POLY_XY_SHIFT), c0y = py0, c1x = (px1 << POLY_XY_SHIFT), c1y = py1;
+  if (inside) {
+    c0x += 1 << (POLY_XY_SHIFT - 1);
+    c1x += 1 << (POLY_XY_SHIFT - 1);
+  } else if (ay != by) {                                          // clipped end points, without the half
+    c0x = ax << POLY_XY_SHIFT; c0y = ay;
+    c1x = bx << POLY_XY_SHIFT; c1y = by;
+  }
+  e.dx = (c1x - c0x) / (c1y - c0y);                               // C++ truncating division
+  if (py0 < py1) { e.y0 = (int)py0; e.y1 = (int)py1; e.x = c0x + (py0 - c0y) * e.dx; }
+  else { e.y0 = (int)py1; e.y1 = (int)py0; e.x = c1x + (py1 - c1y) * e.dx; }
+  return s;
+}
+
+__device__ inline void poly_set_bit(unsigned* bits, int W, int x, int y) {
+  const unsigned i = (unsigned)y * (unsigned)W + (unsigned)x;
+  atomicOr(&bits[i >> 5], 1u << (i & 31));
+}
+
+// the pixels of one drawn segment, lanes over the major axis: minor(i) = floor((2 i dmin + dmaj - 1) / (2 dmaj)) is the
+// closed form of LineIterator's err < 0 stepping (exact halves stay on the start side); everything fits 32 bits inside a frame
+__device__ inline void poly_draw(const PolySide& s, int W, unsigned* bits, int lane) {
+  if (s.sx > s.ex) return;
+  const int dx = s.ex - s.sx, dy = s.ey - s.sy;
+  const int ady = dy < 0 ? -dy : dy, sgn = dy < 0 ? -1 : 1;
+  if (ady > dx) {   // y is the major axis
+    for (int i = lane; i <= ady; i += 64) {
+      const int k = (int)((2u * (unsigned)i * (unsigned)dx + (unsigned)ady - 1u) / (2u * (unsigned)ady));
+      poly_set_bit(bits, W, s.sx + k, s.sy + sgn * i);
+    }
+  } else {
+    for (int i = lane; i <= dx; i += 64) {
+      const int k = dx ? (int)((2u * (unsigned)i * (unsigned)ady + (unsigned)dx - 1u) / (2u * (unsigned)dx)) : 0;
+      poly_set_bit(bits, W, s.sx + i, s.sy + sgn * k);
+    }
+  }
+}
+
+// OR the columns x1..x2 (inclusive, already clipped to the row) of row y into the bit image
+__device__ inline void poly_fill_span(unsigned* bits, int W, int y, int x1, int x2) {
+  const unsigned i1 = (unsigned)y * (unsigned)W + (unsigned)x1, i2 = (unsigned)y * (unsigned)W + (unsigned)x2;
+  const unsigned w1 = i1 >> 5, w2 = i2 >> 5;
+  const unsigned m1 = 0xffffffffu << (i1 & 31), m2 = 0xffffffffu >> (31 - (i2 & 31));
+  if (w1 == w2) { atomicOr(&bits[w1], m1 & m2); return; }
+  atomicOr(&bits[w1], m1);
+  for (unsigned w = w1 + 1; w < w2; ++w) atomicOr(&bits[w], 0xffffffffu);
+  atomicOr(&bits[w2], m2);
+}
+
+// All rings [r0, r1) of one instance -> bit image (zeroed here).  xy: int32 pairs; ring_off: point offsets of the rings
+// (ring r = points ring_off[r] .. ring_off[r+1]).  stage: LDS, POLY_STAGE_BYTES; flags: LDS, NTH/64 words.
+// Sides go through LDS POLY_CHUNK at a time (one thread computes a side, one wave draws it); every scanline (one thread
+// each) keeps the POLY_KEEP smallest crossings in (x, side) order in registers while the sides stream by, then fills the
+// pairs; a scanline with more crossings takes further sweeps over the ring.  Returns this thread's share of the pixel count.
+template <int NTH>
+__device__ inline int poly_to_bits(const int* __restrict__ xy, const long long* __restrict__ ring_off, long long r0, long long r1,
+                                   PolySide* stage, unsigned* flags, unsigned* bits, int nwords, int H, int W, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = NTH / 64;
+  constexpr long long XINF = 0x7fffffffffffffffLL;
+  for (int i = tid; i < nwords; i += NTH) bits[i] = 0;
+  for (long long r = r0; r < r1; ++r) {
+    const long long p0 = ring_off[r];
+    const int n = (int)(ring_off[r + 1] - p0);
+    for (int ybase = 0; ybase < H; ybase += NTH) {
+      const int y = ybase + tid;
+      long long lastx = -XINF - 1;
+      int lasti = -1;
+      bool first = ybase == 0;    // the outline is drawn once per ring
+      while (true) {              // sweeps over the ring (uniform); one unless a scanline has more than POLY_KEEP crossings
+        long long cx[POLY_KEEP];
+        int ci[POLY_KEEP];
+#pragma unroll
+        for (int k = 0; k < POLY_KEEP; ++k) { cx[k] = XINF; ci[k] = 0x7fffffff; }
+        int found = 0;
+        for (int c0 = 0; c0 < n; c0 += POLY_CHUNK) {
+          const int m = min(POLY_CHUNK, n - c0);
+          __syncthreads();                                          // the stage is free (and the zeroed image is published)
+          if (tid < m) {
+            const int i = c0 + tid, ip = (i == 0) ? n - 1 : i - 1;
+            stage[tid] = poly_side(xy[2 * (p0 + ip)], xy[2 * (p0 + ip) + 1], xy[2 * (p0 + i)], xy[2 * (p0 + i) + 1], W, H);
+          }
+          __syncthreads();
+          if (first)
+            for (int j = wave; j < m; j += NW) poly_draw(stage[j], W, bits, lane);
+          if (y < H && n >= 2) {
+            for (int j = 0; j < m; ++j) {
+              const int y0 = stage[j].e.y0, y1 = stage[j].e.y1;
+              if (y0 <= y && y < y1) {
+                long long x = stage[j].e.x + (long long)(y - y0) * stage[j].e.dx;
+                int i = c0 + j;
+                if (x > lastx || (x == lastx && i > lasti)) {       // not consumed by an earlier sweep
+                  ++found;
+#pragma unroll
+                  for (int k = 0; k < POLY_KEEP; ++k) {             // insertion: keeps the POLY_KEEP smallest (x, i)
+                    const bool lt = x < cx[k] || (x == cx[k] && i < ci[k]);
+                    const long long tx = lt ? cx[k] : x;
+                    const int ti = lt ? ci[k] : i;
+                    cx[k] = lt ? x : cx[k];
+                    ci[k] = lt ? i : ci[k];
+                    x = tx; i = ti;
+                  }
+                }
+              }
+            }
+          }
+        }
+        const int npairs = min(found, POLY_KEEP) >> 1;
+#pragma unroll
+        for (int k = 0; k < POLY_KEEP / 2; ++k) {
+          if (k < npairs) {
+            const long long c1 = cx[2 * k] >> POLY_XY_SHIFT, c2 = cx[2 * k + 1] >> POLY_XY_SHIFT;   // arithmetic shift = floor
+            if (c1 < W && c2 >= 0) poly_fill_span(bits, W, y, (int)(c1 < 0 ? 0 : c1), (int)(c2 >= W ? W - 1 : c2));
+          }
+        }
+        const bool more = found > POLY_KEEP;
+        if (more) { lastx = cx[POLY_KEEP - 1]; lasti = ci[POLY_KEEP - 1]; }
+        first = false;
+        const unsigned long long any = __ballot(more);
+        __syncthreads();                                            // every reader of flags from the previous sweep is done
+        if (lane == 0) flags[wave] = any != 0 ? 1u : 0u;
+        __syncthreads();
+        unsigned again = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) again |= flags[w];
+        if (!again) break;                                          // uniform
+      }
+    }
+  }
+  __syncthreads();
+  int nm = 0;
+  for (int i = tid; i < nwords; i += NTH) nm += __popc(bits[i]);
+  return nm;
+}
+
+// The four quantities of the reference's instance filter (src/util.py:291-335) from a bit image in LDS; 256 threads.
+// red: LDS, 16 ints.  Results valid in thread 0.
+__device__ inline void bits_stats_256(const unsigned* bits, int H, int W, int boundary, int* rowcnt, int* red, int tid, int* out4) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int bc = min(boundary, W), br = min(boundary, H);
+  int area = 0, edge = 0;
+  for (int r = tid; r < H; r += 256) {
+    int cnt = 0, e = 0;
+    const unsigned base = (unsigned)r * (unsigned)W;
+    for (int c0 = 0; c0 < W; c0 += 32) {       // 32 columns at a time (unaligned rows: assemble the word from two)
+      const unsigned i = base + c0, wi = i >> 5, sh = i & 31;
+      unsigned w = bits[wi] >> sh;
+      if (sh && c0 + (32 - (int)sh) < W) w |= bits[wi + 1] << (32 - sh);
+      const int valid = min(32, W - c0);
+      if (valid < 32) w &= (1u << valid) - 1u;
+      cnt += __popc(w);
+      // columns c0..c0+31 inside the left strip [0, bc) or the right strip [W-bc, W)
+      const int nlo = min(max(bc - c0, 0), 32), fhi = min(max(W - bc - c0, 0), 32);
+      e += __popc(nlo >= 32 ? w : (w & ((1u << nlo) - 1u))) + __popc(fhi >= 32 ? 0u : (w & ~((1u << fhi) - 1u)));
+    }
+    rowcnt[r] = cnt;
+    area += cnt;
+    edge += e + cnt * ((r < br ? 1 : 0) + (r >= H - br ? 1 : 0));
+  }
+  area = wave_sum_i(area);
+  edge = wave_sum_i(edge);
+  if (lane == 0) { red[12 + wave] = area; red[16 + wave] = edge; }
+  __syncthreads();
+  int rows = 0, first = H, last = -1;
+  for (int r = tid; r < H; r += 256)
+    if (rowcnt[r] != 0) { rows += 1; first = min(first, r); last = max(last, r); }
+  rows = wave_sum_i(rows);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { first = min(first, __shfl_xor(first, o)); last = max(last, __shfl_xor(last, o)); }
+  if (lane == 0) { red[wave] = rows; red[4 + wave] = first; red[8 + wave] = last; }
+  __syncthreads();
+  if (tid == 0) {
+    int rw = 0, f = H, l = -1, a = 0, ed = 0;
+    for (int w = 0; w < 4; ++w) { rw += red[w]; f = min(f, red[4 + w]); l = max(l, red[8 + w]); a += red[12 + w]; ed += red[16 + w]; }
+    out4[0] = a; out4[1] = rw; out4[2] = (l >= f) ? l - f + 1 : 0; out4[3] = ed;
+  }
+}
+
+}  // namespace la3d

@@ -9,6 +9,15 @@ run lengths go to the GPU as they are (a few hundred bytes per instance instead 
     boxes, status, aux = fit_instances_rle(depth, (counts, offsets, H, W), K, ...)   # no dense mask at all
     masks = rle_decode((counts, offsets, H, W))                         # the reference's mask array, on the GPU
     keep  = keep_instances(mask_stats(masks), H, from_rle=True)         # the reference's three filters
+
+Polygon segmentations — what every kept COCONut instance carries (the converter writes polygons for all non-crowd
+instances, src/download_coconut.py:275-280) — take ``create_boolean_mask_from_polygon`` in the reference
+(``cv2.fillPoly`` per part, src/util.py:386-400); here the parts go to the GPU as int32 vertex lists:
+
+    polys = pack_polygons([a["segmentation"] for a in annos], H, W)    # host: truncation to int32 like :398
+    boxes, status, aux = fit_instances_poly(depth, polys, K, ...)       # rasterised inside the fit kernel
+    masks = poly_decode(polys)                                          # the reference's boolean masks, on the GPU
+    keep  = keep_instances(mask_stats_poly(polys), H, from_rle=False)   # height = last row - first row + 1 (:328-335)
 """
 from __future__ import annotations
 
@@ -97,51 +106,139 @@ def keep_instances(stats: torch.Tensor, image_height: int, from_rle: bool = True
     return (height.double() / image_height > 0.0625) & (stats[:, 3] < 10) & (stats[:, 0] >= scale_threshold)
 
 
-def filter_annotations(annotations, image_size, boundary_threshold: int = 10, scale_threshold: int = 100, device=None):
-    """The RLE branch of the reference's ``read_bounding_boxes_segmentations(annotations, image_size)``
-    (src/util.py:336-383) without ever decoding a mask plane: crowd annotations are skipped (:355-357), the four filter
-    quantities come from ``mask_stats_rle`` and the keep rule is :375 (height/H > 0.0625, not truncated, area >= 100).
+def pack_polygons(segmentations, H=None, W=None):
+    """List of polygon segmentations (each a list of parts, each part a flat [x0, y0, x1, y1, ...] list as in the COCO /
+    COCONut JSON) -> ``(xy int32 (T,2), ring_offsets int64 (R+1,), inst_rings int64 (B+1,), H, W)``.  Vertices are
+    truncated exactly like the reference: ``np.array(polygon).reshape(-1, 2).astype(np.int32)`` (src/util.py:398) — an odd
+    number of coordinates raises the same ``ValueError`` from ``reshape``."""
+    if isinstance(segmentations, tuple) and len(segmentations) == 5:
+        return segmentations
+    if H is None or W is None:
+        raise ValueError("pack_polygons needs the frame size (H, W)")
+    pts, ring_off, inst_rings = [], [0], [0]
+    for seg in segmentations:
+        if not isinstance(seg, (list, tuple)):
+            raise TypeError("polygon segmentation must be a list of parts")
+        for polygon in seg:
+            q = np.array(polygon).reshape(-1, 2).astype(np.int32)
+            pts.append(q)
+            ring_off.append(ring_off[-1] + len(q))
+        inst_rings.append(len(ring_off) - 1)
+    xy = np.concatenate(pts).astype(np.int32) if pts and ring_off[-1] else np.zeros((1, 2), np.int32)
+    return xy, np.asarray(ring_off, np.int64), np.asarray(inst_rings, np.int64), int(H), int(W)
 
-    annotations: list of COCO annotation dicts with 'iscrowd', 'bbox', 'category_id' and an RLE 'segmentation'
-    ({'size': [h, w], 'counts': list | str | bytes}); image_size = (width, height) as in the reference.
-    Returns ``(bboxes, rles, kept_index, category_ids)``: the kept annotations' boxes, their RLE objects (feed them to
-    ``fit_instances_rle`` or ``rle_decode``), their positions in ``annotations`` and their raw COCO category ids (the
-    reference maps those to super-category names with a table that is not part of this path).  Polygon segmentations
-    need ``cv2.fillPoly`` (src/util.py:386-392) and raise NotImplementedError."""
-    cand, idx = [], []
+
+def _poly_dev(polys, dev):
+    xy, ro, ir, H, W = polys
+    return (_as_dev(xy, torch.int32, dev), _as_dev(ro, torch.int64, dev), _as_dev(ir, torch.int64, dev), H, W)
+
+
+def poly_decode(polys, device=None, stream=None) -> torch.Tensor:
+    """``create_boolean_mask_from_polygon`` (reference src/util.py:386-400) for a batch: (B,H,W) bool tensor on the GPU.
+    ``polys`` is the tuple from ``pack_polygons``."""
+    dev = _dev(device)
+    xy, ro, ir, H, W = _poly_dev(polys, dev)
+    B = ir.numel() - 1
+    out = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.la3d_poly_decode(_ptr(xy), _ptr(ro), _ptr(ir), B, H, W, _ptr(out), _stream(stream)), "la3d_poly_decode")
+    return out.view(torch.bool)
+
+
+def mask_stats_poly(polys, boundary_threshold: int = 10, stream=None, device=None) -> torch.Tensor:
+    """``mask_stats`` for polygon annotations, rasterised in LDS (no plane is written).  With ``keep_instances(...,
+    from_rle=False)`` this is the polygon branch of read_bounding_boxes_segmentations (src/util.py:371-376)."""
+    dev = _dev(device)
+    xy, ro, ir, H, W = _poly_dev(polys, dev)
+    B = ir.numel() - 1
+    out = torch.empty((B, 4), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.la3d_mask_stats_poly(_ptr(xy), _ptr(ro), _ptr(ir), B, H, W, int(boundary_threshold), _ptr(out), _stream(stream)),
+              "la3d_mask_stats_poly")
+    return out
+
+
+def filter_annotations(annotations, image_size, boundary_threshold: int = 10, scale_threshold: int = 100, device=None):
+    """The reference's ``read_bounding_boxes_segmentations(annotations, image_size)`` (src/util.py:336-383) without ever
+    materialising a mask plane: crowd annotations are skipped (:355-357); RLE segmentations take ``mask_stats_rle`` with
+    height = rows holding a pixel (:364-369), polygon segmentations take ``mask_stats_poly`` with height = last row - first
+    row + 1 (``create_boolean_mask_from_polygon`` -> ``get_maximum_height``, :371-372, :328-335); the keep rule is :375
+    (height/H > 0.0625, fewer than 10 boundary pixels, area >= 100).
+
+    annotations: list of COCO annotation dicts with 'iscrowd', 'bbox', 'category_id' and a 'segmentation' that is an RLE
+    ({'size': [h, w], 'counts': list | str | bytes}) or a list of polygon parts; image_size = (width, height) as in the
+    reference.  Returns ``(bboxes, segmentations, kept_index, category_ids)``: the kept annotations' boxes, their
+    segmentations in annotation order (RLE dicts -> ``fit_instances_rle`` / ``rle_decode``; part lists ->
+    ``fit_instances_poly`` / ``poly_decode``; a mixed list -> ``segmentations_to_masks``), their positions in
+    ``annotations`` and their raw COCO category ids (the reference maps those to super-category names with a table that is
+    not part of this path)."""
+    W_img, H_img = int(image_size[0]), int(image_size[1])
+    rle_c, rle_i, poly_c, poly_i = [], [], [], []
     for i, a in enumerate(annotations):
         if a.get("iscrowd"):
             continue
-        seg = a.get("segmentation")
-        if seg is None:
+        if "segmentation" not in a:
             continue
-        if not (isinstance(seg, dict) and "counts" in seg):
-            raise NotImplementedError("polygon segmentation: rasterise with cv2.fillPoly (reference src/util.py:386-392)")
-        cand.append({"size": seg["size"], "counts": seg["counts"]})
-        idx.append(i)
-    if not cand:
-        return [], [], np.zeros(0, np.int64), []
-    H = int(image_size[1])
-    keep = keep_instances(mask_stats_rle(cand, boundary_threshold, device=device), H, from_rle=True,
-                          scale_threshold=scale_threshold).cpu().numpy()
-    kept = [j for j in range(len(cand)) if keep[j]]
-    return ([annotations[idx[j]]["bbox"] for j in kept], [cand[j] for j in kept], np.asarray([idx[j] for j in kept], np.int64),
-            [annotations[idx[j]]["category_id"] for j in kept])
+        seg = a["segmentation"]
+        if isinstance(seg, dict) and "counts" in seg:
+            rle_c.append({"size": seg["size"], "counts": seg["counts"]})
+            rle_i.append(i)
+        else:
+            poly_c.append(seg)
+            poly_i.append(i)
+    keep = {}
+    if rle_c:
+        k = keep_instances(mask_stats_rle(rle_c, boundary_threshold, device=device), H_img, from_rle=True,
+                           scale_threshold=scale_threshold).cpu().numpy()
+        keep.update({i: (bool(f), c) for i, f, c in zip(rle_i, k, rle_c)})
+    if poly_c:
+        k = keep_instances(mask_stats_poly(pack_polygons(poly_c, H_img, W_img), boundary_threshold, device=device), H_img,
+                           from_rle=False, scale_threshold=scale_threshold).cpu().numpy()
+        keep.update({i: (bool(f), c) for i, f, c in zip(poly_i, k, poly_c)})
+    kept = [i for i in sorted(keep) if keep[i][0]]
+    return ([annotations[i]["bbox"] for i in kept], [keep[i][1] for i in kept], np.asarray(kept, np.int64),
+            [annotations[i]["category_id"] for i in kept])
 
 
-def fit_instances_rle(depth, rles, K, ground=None, sample_idx=None, image_index=None, stream=None, device=None):
-    """fit_instances with run-length masks: the runs are decoded inside the fit kernel, straight into its LDS
-    bit image.  Arguments and returns as ``labelany3d_amd.fit_instances``; ``rles`` is a list of COCO RLE
-    objects or the tuple from ``pack_rle``."""
-    counts, offsets, H, W = pack_rle(rles)
+def segmentations_to_masks(segmentations, H: int, W: int, device=None) -> torch.Tensor:
+    """A list mixing RLE dicts and polygon part lists (what ``filter_annotations`` returns) -> (B,H,W) bool masks on the
+    GPU in list order: the reference's ``np.array(segmentation_mask)`` (src/util.py:382)."""
     dev = _dev(device)
-    c, o = _as_dev(counts, torch.int32, dev), _as_dev(offsets, torch.int64, dev)
-    B = o.numel() - 1
+    out = torch.zeros((len(segmentations), H, W), dtype=torch.bool, device=dev)
+    ri = [i for i, s in enumerate(segmentations) if isinstance(s, dict)]
+    pi = [i for i, s in enumerate(segmentations) if not isinstance(s, dict)]
+    if ri:
+        out[torch.as_tensor(ri, device=dev)] = rle_decode([segmentations[i] for i in ri], device=dev)
+    if pi:
+        out[torch.as_tensor(pi, device=dev)] = poly_decode(pack_polygons([segmentations[i] for i in pi], H, W), device=dev)
+    return out
+
+
+def fit_instances_poly(depth, polys, K, ground=None, sample_idx=None, image_index=None, stream=None, device=None):
+    """fit_instances with polygon masks: the parts are rasterised inside the fit kernel, straight into its LDS bit image
+    (cv2.fillPoly semantics, reference src/util.py:386-400).  Arguments and returns as ``labelany3d_amd.fit_instances``;
+    ``polys`` is the tuple from ``pack_polygons``."""
+    dev = _dev(device)
+    xy, ro, ir, H, W = _poly_dev(polys, dev)
+    B = ir.numel() - 1
+    d, k, P, ii, g, si = _fit_common(depth, K, H, W, B, ground, sample_idx, image_index, dev, "polygon")
+    with torch.cuda.device(dev):
+        f = InstanceFitter(B, H, W, dev)
+        if B == 0:
+            return f.boxes[0], f.status[0], f.aux[0]
+        rc = lib.la3d_fit_instances_poly(_ptr(d), H * W if P > 1 else 0, _ptr(ii), _ptr(xy), _ptr(ro), _ptr(ir), _ptr(k),
+                                         9 if k.shape[0] > 1 else 0, _ptr(g), _ptr(si), B, H, W, _ptr(f.boxes[0]),
+                                         _ptr(f.status[0]), _ptr(f.aux[0]), _ptr(f.workspace[0]), _stream(stream))
+        check(rc, "la3d_fit_instances_poly")
+    return f.boxes[0], f.status[0], f.aux[0]
+
+
+def _fit_common(depth, K, H, W, B, ground, sample_idx, image_index, dev, what):
     d = _as_dev(depth, torch.float32, dev)
     if d.dim() == 2:
         d = d[None]
     if d.shape[1:] != (H, W):
-        raise ValueError(f"depth planes {tuple(d.shape[1:])} do not match the RLE frame {(H, W)}")
+        raise ValueError(f"depth planes {tuple(d.shape[1:])} do not match the {what} frame {(H, W)}")
     k = _as_dev(K, torch.float64, dev)
     if k.dim() == 2:
         k = k[None]
@@ -153,6 +250,18 @@ def fit_instances_rle(depth, rles, K, ground=None, sample_idx=None, image_index=
         raise ValueError("without image_index, depth must have 1 or B planes")
     g = None if ground is None else _as_dev(ground, torch.float64, dev)
     si = None if sample_idx is None else _as_dev(sample_idx, torch.int32, dev)
+    return d, k, P, ii, g, si
+
+
+def fit_instances_rle(depth, rles, K, ground=None, sample_idx=None, image_index=None, stream=None, device=None):
+    """fit_instances with run-length masks: the runs are decoded inside the fit kernel, straight into its LDS
+    bit image.  Arguments and returns as ``labelany3d_amd.fit_instances``; ``rles`` is a list of COCO RLE
+    objects or the tuple from ``pack_rle``."""
+    counts, offsets, H, W = pack_rle(rles)
+    dev = _dev(device)
+    c, o = _as_dev(counts, torch.int32, dev), _as_dev(offsets, torch.int64, dev)
+    B = o.numel() - 1
+    d, k, P, ii, g, si = _fit_common(depth, K, H, W, B, ground, sample_idx, image_index, dev, "RLE")
     with torch.cuda.device(dev):
         f = InstanceFitter(B, H, W, dev)
         if B == 0:

@@ -1,0 +1,199 @@
+"""GPU tests of polygon mask ingestion (the branch every kept COCONut instance takes in the reference:
+create_boolean_mask_from_polygon -> cv2.fillPoly, /root/reference/src/util.py:386-400).
+
+PARITY UNPINNED against OpenCV: cv2 is not installed in the build container, so the checker is oracle/poly_oracle.py, a
+restatement of OpenCV 4.x drawing.cpp (see its header and tests/test_oracle_poly.py for what pins it).  The HIP
+rasteriser must agree with that restatement bit for bit on every polygon below."""
+import numpy as np
+import pytest
+
+from oracle import la3d_oracle as O
+from oracle import poly_oracle as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def la():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import labelany3d_amd
+
+    return labelany3d_amd
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+class _instance_engine:
+    """Pin the instance engine for the u8-plane call (small batches of planes take the split engine, whose partial sums are
+    grouped differently; polygon / run-length input always takes the instance engine)."""
+
+    def __enter__(self):
+        import os
+        os.environ["LA3D_ENGINE"] = "instance"
+
+    def __exit__(self, *a):
+        import os
+        del os.environ["LA3D_ENGINE"]
+
+
+def _star(rs, w, h, n, jitter=0.6, margin=0.0):
+    """A simple (mostly) star-shaped ring with n vertices; margin > 0 pushes vertices out of the frame."""
+    ang = np.sort(rs.uniform(0, 2 * np.pi, n))
+    cx, cy = rs.uniform(0.2 * w, 0.8 * w), rs.uniform(0.2 * h, 0.8 * h)
+    rad = rs.uniform(1 - jitter, 1.0, n)
+    rx, ry = rs.uniform(2, (0.5 + margin) * w), rs.uniform(2, (0.5 + margin) * h)
+    return np.stack([cx + rx * rad * np.cos(ang), cy + ry * rad * np.sin(ang)], 1)
+
+
+def _random_segmentation(rs, w, h, kind):
+    if kind == 0:     # one in-frame star ring, float coordinates (the reference truncates them)
+        q = np.clip(_star(rs, w, h, rs.randint(3, 40)), 0, [w - 1, h - 1])
+        return [q.ravel().tolist()]
+    if kind == 1:     # vertices outside the frame: clipLine paths
+        return [_star(rs, w, h, rs.randint(3, 25), margin=0.5).ravel().tolist()]
+    if kind == 2:     # several parts, overlapping or not
+        return [np.clip(_star(rs, w, h, rs.randint(3, 15)), 0, [w - 1, h - 1]).ravel().tolist() for _ in range(rs.randint(2, 5))]
+    if kind == 3:     # self-intersecting: random vertex order (even-odd inside one fillPoly call)
+        return [rs.uniform(0, [w - 1, h - 1], (rs.randint(4, 12), 2)).ravel().tolist()]
+    if kind == 4:     # degenerate parts: a dot, a segment, repeated vertices, collinear points
+        x, y = rs.randint(0, w), rs.randint(0, h)
+        return [[x, y], [x, y, (x + 7) % w, (y + 3) % h], [3, 3, 3, 3, 9, 9, 9, 9], [1, 1, 5, 5, 9, 9]]
+    if kind == 5:     # a comb: many crossings per scanline (more than the 8 a scanline keeps per sweep)
+        teeth = rs.randint(6, 14)
+        xs = np.linspace(2, w - 3, 2 * teeth + 1)
+        top, bot = rs.randint(1, h // 3), rs.randint(2 * h // 3, h - 1)
+        pts = [(xs[0], bot)]
+        for k in range(2 * teeth):
+            pts.append((xs[k + 1], top if k % 2 == 0 else bot - 2))
+        pts.append((xs[-1], bot))
+        return [np.asarray(pts).ravel().tolist()]
+    if kind == 6:     # axis-aligned rectangle
+        x0, x1 = sorted(rs.randint(0, w, 2))
+        y0, y1 = sorted(rs.randint(0, h, 2))
+        return [[x0, y0, x1, y0, x1, y1, x0, y1]]
+    # very many vertices (more than one stage of 32 sides, long sweeps)
+    return [np.clip(_star(rs, w, h, rs.randint(100, 400), jitter=0.3), 0, [w - 1, h - 1]).ravel().tolist()]
+
+
+@pytest.mark.parametrize("H,W,seed", [(48, 64, 0), (37, 53, 1), (480, 640, 2), (120, 100, 3)])
+def test_poly_decode_equals_fillpoly_oracle(la, H, W, seed):
+    rs = np.random.RandomState(seed)
+    n = 40 if H * W > 100000 else 90          # 260 polygons over the four frames
+    segs = [_random_segmentation(rs, W, H, k % 8) for k in range(n)]
+    segs.append([])                            # an instance without parts: empty mask
+    polys = la.pack_polygons(segs, H, W)
+    got = np_(la.poly_decode(polys))
+    assert got.shape == (len(segs), H, W) and got.dtype == np.bool_
+    stats = np_(la.mask_stats_poly(polys))
+    for i, seg in enumerate(segs):
+        want, height = P.create_boolean_mask_from_polygon((W, H), seg)
+        bad = np.argwhere(got[i] != want)
+        assert bad.size == 0, (i, i % 8, bad[:5], seg if len(str(seg)) < 400 else "...")
+        ws = O.mask_stats(want)
+        assert tuple(stats[i]) == ws, (i, stats[i], ws)
+        assert ws[2] == height                 # get_maximum_height
+    assert got[-1].sum() == 0
+
+
+def test_fit_from_polygons_equals_fit_from_planes(la):
+    """The composed path fed with polygon parts gives the records of the same path fed with the rasterised planes
+    (bit for bit), and those agree with the oracle fit on the oracle's masks."""
+    rs = np.random.RandomState(5)
+    B, H, W = 40, 480, 640
+    K = np.array([[500.0, 0, 320], [0, 500.0, 240], [0, 0, 1]])
+    depth = rs.uniform(0.5, 10, (B, H, W)).astype(np.float32)
+    segs = [_random_segmentation(rs, W, H, k % 8) for k in range(B - 1)] + [[]]
+    ground = np.array([[0.05, -0.97, 0.1, 1.2]] * B) + 0.02 * rs.randn(B, 4)
+    polys = la.pack_polygons(segs, H, W)
+    b1, s1, a1 = la.fit_instances_poly(depth, polys, K, ground=ground)
+    masks = la.poly_decode(polys)
+    with _instance_engine():
+        b2, s2, a2 = la.fit_instances(depth, masks, K, ground=ground)
+    np.testing.assert_array_equal(np_(s1), np_(s2))
+    np.testing.assert_array_equal(np_(b1), np_(b2))
+    np.testing.assert_array_equal(np_(a1), np_(a2))
+    assert np_(s1)[-1] == 1                    # the empty instance: "No valid points"
+    for i in range(0, B - 1, 5):
+        want, _ = P.create_boolean_mask_from_polygon((W, H), segs[i])
+        ref, rst, _, _ = O.fit_instances(depth[i:i + 1], want[None], K[None], ground=ground[i:i + 1])
+        assert np_(s1)[i] == rst[0]
+        if rst[0] == 0:
+            np.testing.assert_allclose(np_(b1)[i, :15], ref[0, :15], rtol=0, atol=1e-9)
+            np.testing.assert_allclose(np_(b1)[i, 15:], ref[0, 15:], rtol=0, atol=2e-2)   # fp16-quantised corners
+
+
+def test_fit_from_polygons_large_batch_shared_depth(la):
+    """More instances than one resident round, one depth plane per image (the COCO layout), launch order on."""
+    rs = np.random.RandomState(6)
+    P_img, H, W = 60, 480, 640
+    K = np.array([[500.0, 0, 320], [0, 500.0, 240], [0, 0, 1]])
+    depth = rs.uniform(0.5, 10, (P_img, H, W)).astype(np.float32)
+    img = np.repeat(np.arange(P_img), rs.randint(3, 12, P_img)).astype(np.int32)
+    segs = [_random_segmentation(rs, W, H, [0, 2, 6, 7][k % 4]) for k in range(len(img))]
+    polys = la.pack_polygons(segs, H, W)
+    b1, s1, _ = la.fit_instances_poly(depth, polys, K, image_index=img)
+    with _instance_engine():
+        b2, s2, _ = la.fit_instances(depth, la.poly_decode(polys), K, image_index=img)
+    np.testing.assert_array_equal(np_(s1), np_(s2))
+    np.testing.assert_array_equal(np_(b1), np_(b2))
+
+
+def test_filter_annotations_polygon_and_rle_branches(la):
+    """read_bounding_boxes_segmentations (src/util.py:336-383): crowd skip, RLE height = rows with a pixel, polygon
+    height = last - first + 1, keep rule :375 — against the oracle's restatement of the same rule."""
+    rs = np.random.RandomState(9)
+    H, W = 240, 320
+    annos, want_keep = [], []
+    for i in range(60):
+        kind = i % 6
+        a = {"iscrowd": 0, "bbox": [float(i), 1.0, 2.0, 3.0], "category_id": 1 + i % 80}
+        if kind == 0:      # crowd: skipped before anything is looked at
+            a["iscrowd"] = 1
+            a["segmentation"] = O.rle_encode(rs.rand(H, W) < 0.3)
+            annos.append(a)
+            continue
+        if kind == 1:      # RLE (uncompressed or compressed string)
+            m = np.zeros((H, W), bool)
+            h, w = rs.randint(2, 120), rs.randint(2, 160)
+            r0, c0 = rs.randint(0, H - h + 1), rs.randint(0, W - w + 1)
+            m[r0:r0 + h, c0:c0 + w] = True
+            m[r0 + h // 2, :] &= rs.rand(W) < 0.5       # a row with holes, maybe an empty row: rows != span
+            rle = O.rle_encode(m)
+            if i % 12 == 1:
+                rle["counts"] = O.rle_to_string(rle["counts"])
+            a["segmentation"] = rle
+            st, from_rle = O.mask_stats(m), True
+        else:              # polygon parts
+            seg = _random_segmentation(rs, W, H, [0, 2, 6, 0, 1][kind - 1] if kind > 1 else 0)
+            a["segmentation"] = seg
+            m, _ = P.create_boolean_mask_from_polygon((W, H), seg)
+            st, from_rle = O.mask_stats(m), False
+        annos.append(a)
+        want_keep.append((len(annos) - 1, O.keep_instance(st, H, from_rle)))
+    bboxes, segs, kept, cats = la.filter_annotations(annos, (W, H))
+    want = [i for i, k in want_keep if k]
+    assert list(kept) == want and 0 < len(want) < len(want_keep)
+    assert bboxes == [annos[i]["bbox"] for i in want] and cats == [annos[i]["category_id"] for i in want]
+    masks = np_(la.segmentations_to_masks(segs, H, W))
+    for j, i in enumerate(want):
+        seg = annos[i]["segmentation"]
+        if isinstance(seg, dict):
+            c = seg["counts"]
+            ref = O.rle_decode(O.rle_from_string(c) if isinstance(c, (str, bytes)) else c, H, W)
+        else:
+            ref, _ = P.create_boolean_mask_from_polygon((W, H), seg)
+        np.testing.assert_array_equal(masks[j], ref.astype(bool))
+
+
+def test_polygon_argument_errors(la):
+    with pytest.raises(ValueError):
+        la.pack_polygons([[[1, 2, 3]]], 48, 64)          # odd number of coordinates: reshape(-1, 2) fails like the reference
+    with pytest.raises(ValueError):
+        la.pack_polygons([[[1, 2, 3, 4]]])               # frame size is required
+    polys = la.pack_polygons([], 48, 64)
+    assert tuple(la.poly_decode(polys).shape) == (0, 48, 64)
