@@ -5,10 +5,15 @@ The reference scales out only by running separate processes over contiguous inde
 are independent, so the data path needs no collective.  The only exchange is the final gather of
 the (n_i, 39) box tensors (+ status) to one rank — RCCL over xGMI on GPUs (torch.distributed backend
 "nccl"), gloo on CPU in the tests.
+
+Partitioning works on METADATA only (image index and an area per instance — the annotation's ``area`` field, or
+``mask_stats_rle`` / ``mask_stats_poly``): no rank ever looks at another rank's masks, so a rank only has to hold
+(or load) the depth planes and masks of its own contiguous image range (COCO-train: 264 GB of u8 masks in total,
+33 GB per rank with 8 GPUs).
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+from typing import Callable, List, NamedTuple, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -37,16 +42,63 @@ def partition_contiguous(costs: Sequence[float], world: int) -> List[Tuple[int, 
     return [(cuts[i], cuts[i + 1]) for i in range(world)]
 
 
+class Shard(NamedTuple):
+    """One rank's share: images [img_lo, img_hi) and their instances [inst_lo, inst_hi) of the global lists."""
+    img_lo: int
+    img_hi: int
+    inst_lo: int
+    inst_hi: int
+
+
+def plan_shards(image_index, num_images: int, world: int, areas=None, frame_pixels: int = 640 * 480) -> List[Shard]:
+    """Cost-balanced contiguous image ranges from metadata only.
+
+    image_index  (B,) non-decreasing image of every instance
+    areas        (B,) mask area per instance in pixels (annotation ``area``, ``mask_stats_rle(...)[:, 0]``, ...) or None
+                 (then every instance counts as one mean-size mask)
+    Cost model of an image (what the fit kernel moves for it): one depth plane (4 B/px) if it has instances + per
+    instance one mask plane (1 B/px) + its masked depth pixels twice (2 x 4 B x area)."""
+    img = np.asarray(image_index.cpu() if isinstance(image_index, torch.Tensor) else image_index).astype(np.int64)
+    if img.size and (np.diff(img) < 0).any():
+        raise ValueError("image_index must be non-decreasing (instances grouped by image)")
+    if img.size and (img.min() < 0 or img.max() >= num_images):
+        raise ValueError("image_index out of range")
+    hw = float(frame_pixels)
+    if areas is None:
+        a = np.full(img.shape, 0.1 * hw)
+    else:
+        a = np.asarray(areas.cpu() if isinstance(areas, torch.Tensor) else areas, dtype=np.float64)
+        if a.shape != img.shape:
+            raise ValueError("areas must have one entry per instance")
+    per_inst = hw + 8.0 * a
+    cost = np.bincount(img, weights=per_inst, minlength=num_images) + 4.0 * hw * (np.bincount(img, minlength=num_images) > 0)
+    out = []
+    for lo, hi in partition_contiguous(cost, world):
+        ilo, ihi = int(np.searchsorted(img, lo, side="left")), int(np.searchsorted(img, hi, side="left"))
+        out.append(Shard(lo, hi, ilo, ihi))
+    return out
+
+
+def _is_gloo(group) -> bool:
+    try:
+        return dist.get_backend(group) == "gloo"
+    except Exception:  # noqa: BLE001
+        return False
+
+
 def gather_boxes(boxes: torch.Tensor, status: torch.Tensor, dst: int = 0, group=None):
     """Gather every rank's (n_i, 39) float64 records and (n_i,) int32 status to ``dst`` in rank order.
 
     Ranks may hold different n_i: counts are exchanged first (one tiny all_gather), payloads are padded
     to the maximum and gathered with a single ``dist.gather`` each.  Returns ``(boxes, status, counts)``
     on ``dst`` and ``None`` elsewhere.  ~312 B per box: 860k boxes over 8 GPUs is 33 MB per rank —
-    irrelevant next to the compute, so the simplest correct collective is used.
+    irrelevant next to the compute, so the simplest correct collective is used.  With the gloo backend (CPU tests,
+    two ranks on one GPU) device tensors are staged through the host.
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    if _is_gloo(group) and boxes.is_cuda:
+        boxes, status = boxes.cpu(), status.cpu()
     n = torch.tensor([boxes.shape[0]], dtype=torch.int64, device=boxes.device)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n, group=group)
@@ -74,32 +126,44 @@ def gather_boxes(boxes: torch.Tensor, status: torch.Tensor, dst: int = 0, group=
     return (torch.cat([g[:c] for g, c in zip(gb, counts)]), torch.cat([g[:c] for g, c in zip(gs, counts)]), counts)
 
 
-def fit_instances_sharded(depth, masks, K, image_index, ground=None, sample_idx=None, dst: int = 0, group=None,
-                          fit_fn=None):
-    """Every rank passes the SAME global description (or at least its own slice of it); images are
-    split into contiguous, cost-balanced ranges, each rank fits the instances of its images on its own
-    GPU and the records are gathered on ``dst`` in global instance order.
+def fit_instances_sharded(depth, masks, K, image_index, ground=None, sample_idx=None, areas=None, dst: int = 0, group=None,
+                          fit_fn: Optional[Callable] = None, load_fn: Optional[Callable] = None):
+    """Every rank passes the same METADATA (``image_index``, optionally ``areas``); images are split into contiguous,
+    cost-balanced ranges (``plan_shards``), each rank fits the instances of its images on its own GPU and the records are
+    gathered on ``dst`` in global instance order.
 
-    depth (P,H,W), K (P,3,3) or (3,3), masks (B,H,W), image_index (B,) non-decreasing.
-    ``fit_fn`` defaults to labelany3d_amd.fit_instances (injectable so the sharding logic is testable
-    on CPU with gloo)."""
+    Two ways to supply the tensors:
+      * global tensors ``depth (P,H,W)``, ``masks (B,H,W)``, ``K (P,3,3) | (3,3)``, ``ground``, ``sample_idx``: only this
+        rank's slices are ever indexed (views — nothing is computed over the global tensors);
+      * ``load_fn(shard) -> (depth, masks, K, ground, sample_idx)`` returning ONLY this rank's images / instances (depth planes
+        img_lo..img_hi, masks inst_lo..inst_hi); pass ``depth=(P, H, W)`` (the global shape) and ``masks=None``.
+    ``areas`` (B,) are per-instance mask areas for the balance (None: count-based).  ``fit_fn`` defaults to
+    labelany3d_amd.fit_instances (injectable so the sharding logic is testable on CPU with gloo)."""
     if fit_fn is None:
         from .batched import fit_instances as fit_fn
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     img = np.asarray(image_index.cpu() if isinstance(image_index, torch.Tensor) else image_index).astype(np.int64)
-    if (np.diff(img) < 0).any():
-        raise ValueError("image_index must be non-decreasing (instances grouped by image)")
-    P = depth.shape[0]
-    m = masks if isinstance(masks, torch.Tensor) else torch.as_tensor(np.asarray(masks))
-    area = m.reshape(m.shape[0], -1).ne(0).sum(1).cpu().numpy().astype(np.float64)
-    hw = float(m.shape[1] * m.shape[2])
-    cost = np.bincount(img, weights=area + hw, minlength=P) + 4.0 * hw * (np.bincount(img, minlength=P) > 0)
-    lo_img, hi_img = partition_contiguous(cost, world)[rank]
-    sel = np.nonzero((img >= lo_img) & (img < hi_img))[0]
-    lo, hi = (int(sel[0]), int(sel[-1]) + 1) if len(sel) else (0, 0)
-    sl = slice(lo, hi)
-    boxes, status, _ = fit_fn(depth, masks[sl], K, ground=None if ground is None else ground[sl],
-                              sample_idx=None if sample_idx is None else sample_idx[sl],
-                              image_index=image_index[sl])
+    if load_fn is not None:
+        P, H, W = (int(v) for v in depth)
+    else:
+        P, H, W = depth.shape
+    sh = plan_shards(img, P, world, areas=areas, frame_pixels=H * W)[rank]
+    local_img = (img[sh.inst_lo:sh.inst_hi] - sh.img_lo).astype(np.int32)
+    if load_fn is not None:
+        d, m, k, g, si = load_fn(sh)
+    else:
+        d = depth[sh.img_lo:sh.img_hi]
+        m = masks[sh.inst_lo:sh.inst_hi]
+        k = K
+        if hasattr(K, "shape") and len(K.shape) == 3 and K.shape[0] == P:
+            k = K[sh.img_lo:sh.img_hi]
+        g = None if ground is None else ground[sh.inst_lo:sh.inst_hi]
+        si = None if sample_idx is None else sample_idx[sh.inst_lo:sh.inst_hi]
+    if sh.inst_hi > sh.inst_lo:
+        boxes, status, _ = fit_fn(d, m, k, ground=g, sample_idx=si, image_index=local_img)
+    else:  # a rank without instances still takes part in the gather
+        dev = m.device if isinstance(m, torch.Tensor) else torch.device("cpu")
+        boxes = torch.zeros((0, 39), dtype=torch.float64, device=dev)
+        status = torch.zeros((0,), dtype=torch.int32, device=dev)
     return gather_boxes(boxes, status, dst=dst, group=group)

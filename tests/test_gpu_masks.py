@@ -279,5 +279,6 @@ def test_filter_annotations_matches_the_reference_rule(la):
     assert kept.tolist() == want and len(want) > 0
     assert bboxes == [annos[i]["bbox"] for i in want] and cats == [annos[i]["category_id"] for i in want]
     np.testing.assert_array_equal(np_(la.rle_decode(rles)), m[want])
-    with pytest.raises(NotImplementedError):
-        la.filter_annotations([{"iscrowd": 0, "bbox": [0, 0, 1, 1], "category_id": 1, "segmentation": [[0, 0, 5, 0, 5, 5]]}], (W, H))
+    # a polygon annotation takes the polygon branch (tests/test_gpu_poly.py); this small triangle fails the height / area rules
+    out = la.filter_annotations([{"iscrowd": 0, "bbox": [0, 0, 1, 1], "category_id": 1, "segmentation": [[0, 0, 5, 0, 5, 5]]}], (W, H))
+    assert out[0] == [] and out[1] == [] and out[2].tolist() == [] and out[3] == []

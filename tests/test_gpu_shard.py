@@ -1,0 +1,165 @@
+"""BASELINE configs 4 and 5 on ONE GPU.
+
+config 4 (per-image sharding + one gather of box records): the sharded driver with the REAL fit, two processes on the
+same device joined by a gloo group (RCCL refuses two ranks on one GPU; the nccl path itself runs in bench.py --gpus N).
+Records must arrive on rank 0 in global instance order and agree with the oracle.
+
+config 5 (mask areas log-uniform 8..100k px, private depth): both engines, batches below and above the three resident
+sets the size-balanced launch order covers."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import la3d_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+H, W = 480, 640
+K640 = np.array([[500.0, 0, 320], [0, 500.0, 240], [0, 0, 1]])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _scene(seed=11, P=9):
+    rs = np.random.RandomState(seed)
+    depth = rs.uniform(0.5, 10, (P, H, W)).astype(np.float32)
+    per = rs.randint(0, 6, P)
+    per[3] = 0
+    img = np.repeat(np.arange(P), per).astype(np.int32)
+    B = len(img)
+    masks = np.zeros((B, H, W), bool)
+    for i in range(B):
+        h, w = rs.randint(4, 200), rs.randint(4, 260)
+        r0, c0 = rs.randint(0, H - h + 1), rs.randint(0, W - w + 1)
+        masks[i, r0:r0 + h, c0:c0 + w] = True
+    Ks = np.repeat(K640[None], P, 0) * (1 + 0.01 * np.arange(P))[:, None, None]
+    Ks[:, 2, 2] = 1
+    ground = np.array([[0.03, -0.98, 0.08, 1.4]] * B) + 0.02 * rs.randn(B, 4)
+    return depth, masks, Ks, img, ground
+
+
+def _worker(rank, world, port, q):
+    import traceback
+
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from labelany3d_amd.shard import fit_instances_sharded, plan_shards
+
+        torch.cuda.set_device(0)
+        depth, masks, Ks, img, ground = _scene()
+        areas = masks.reshape(len(img), -1).sum(1)
+        shard = plan_shards(img, depth.shape[0], world, areas=areas, frame_pixels=H * W)[rank]
+
+        def load(sh):   # this rank uploads ONLY its own images / instances
+            assert sh == shard
+            dev = torch.device("cuda", 0)
+            return (torch.as_tensor(depth[sh.img_lo:sh.img_hi], device=dev), torch.as_tensor(masks[sh.inst_lo:sh.inst_hi], device=dev),
+                    torch.as_tensor(Ks[sh.img_lo:sh.img_hi], device=dev), ground[sh.inst_lo:sh.inst_hi], None)
+
+        out = fit_instances_sharded(depth.shape, None, None, img, areas=areas, load_fn=load)
+        # and the global-tensor form (views of the same arrays)
+        out2 = fit_instances_sharded(depth, masks, Ks, img, ground=ground, areas=areas)
+        if rank == 0:
+            b, s, counts = out
+            q.put((rank, "ok", b.cpu().numpy(), s.cpu().numpy(), counts, out2[0].cpu().numpy()))
+        else:
+            assert out is None and out2 is None
+            q.put((rank, "ok", shard.inst_hi - shard.inst_lo))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, repr(e) + traceback.format_exc()[-800:]))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config4_two_ranks_one_gpu_real_fit():
+    import torch
+    import torch.multiprocessing as mp
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+    assert res[0][1] == "ok" and res[1][1] == "ok", res
+    _, _, boxes, status, counts, boxes2 = res[0]
+    depth, masks, Ks, img, ground = _scene()
+    assert sum(counts) == len(img) and counts[1] == res[1][2] and min(counts) > 0
+    ref, rst, _, _ = O.fit_instances(depth, masks, Ks, ground=ground, depth_index=img)
+    assert status.tolist() == rst.tolist()
+    ok = rst == 0
+    np.testing.assert_allclose(boxes[ok][:, :15], ref[ok][:, :15], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(boxes[ok][:, 15:], ref[ok][:, 15:], rtol=0, atol=2e-2)
+    np.testing.assert_array_equal(boxes, boxes2)          # load_fn form == global-tensor form
+
+
+@pytest.fixture(scope="module")
+def la():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import labelany3d_amd
+
+    return labelany3d_amd
+
+
+@pytest.mark.parametrize("B", [1024, 4096, 16384])
+def test_config5_size_distribution(la, B):
+    """Areas log-uniform 8..100k px: the instance engine (with and without its launch order; 16384 is past the three
+    resident sets the order covers), the split engine on a sub-batch, and the oracle on a sample."""
+    import torch
+
+    import bench
+
+    dev = torch.device("cuda", 0)
+    depth, masks, K, n_masked, _ = bench.make_config5(B, dev, 77)
+    area = masks.reshape(B, -1).sum(1, dtype=torch.int64).cpu().numpy()
+    assert area.min() >= 4 and area.max() <= 110000 and np.median(area) < 3000     # log-uniform: mostly small, a few huge
+    os.environ["LA3D_ENGINE"] = "instance"
+    try:
+        b1, s1, a1 = la.fit_instances(depth, masks, K)
+        os.environ["LA3D_BALANCE"] = "0"
+        b0, s0, _ = la.fit_instances(depth, masks, K)
+    finally:
+        os.environ.pop("LA3D_ENGINE", None)
+        os.environ.pop("LA3D_BALANCE", None)
+    torch.cuda.synchronize()
+    assert int((s1 != 0).sum()) == 0
+    assert torch.equal(b1, b0) and torch.equal(s1, s0)            # the launch order is invisible in the records
+    assert torch.equal(a1[:, 2].long().cpu(), torch.as_tensor(area))  # n_masked
+    # split engine on the first 256 (its batch range): same records to rounding
+    os.environ["LA3D_ENGINE"] = "split"
+    try:
+        bs, ss, _ = la.fit_instances(depth[:256], masks[:256], K)
+    finally:
+        os.environ.pop("LA3D_ENGINE", None)
+    assert int((ss != 0).sum()) == 0
+    np.testing.assert_allclose(bs[:, :15].cpu().numpy(), b1[:256, :15].cpu().numpy(), rtol=0, atol=1e-9)
+    # oracle on the smallest, the largest and a spread of instances
+    order = np.argsort(area)
+    pick = np.unique(np.concatenate([order[:6], order[-4:], order[:: max(1, B // 22)]]))
+    d, m = depth[pick].cpu().numpy(), masks[pick].cpu().numpy().astype(bool)
+    ref, rst, _, _ = O.fit_instances(d, m, np.repeat(K640[None], len(pick), 0))
+    got = b1[pick].cpu().numpy()
+    assert (rst == 0).all()
+    np.testing.assert_allclose(got[:, :15], ref[:, :15], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(got[:, 15:], ref[:, 15:], rtol=0, atol=2e-2)

@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from labelany3d_amd.shard import fit_instances_sharded, gather_boxes, partition_contiguous
+from labelany3d_amd.shard import Shard, fit_instances_sharded, gather_boxes, partition_contiguous, plan_shards
 
 
 def test_partition_contiguous_balances_cost():
@@ -25,6 +25,32 @@ def test_partition_contiguous_balances_cost():
     assert partition_contiguous([5.0], 3) in ([(0, 0), (0, 0), (0, 1)], [(0, 1), (1, 1), (1, 1)], [(0, 0), (0, 1), (1, 1)])
 
 
+def test_plan_shards_uses_metadata_only():
+    rs = np.random.RandomState(1)
+    P = 50
+    per = rs.randint(0, 9, P)
+    per[10:14] = 0                                   # images without instances
+    img = np.repeat(np.arange(P), per)
+    areas = rs.randint(8, 100000, len(img)).astype(np.float64)
+    for world in (1, 2, 3, 8):
+        sh = plan_shards(img, P, world, areas=areas)
+        assert len(sh) == world and sh[0].img_lo == 0 and sh[-1].img_hi == P and sh[0].inst_lo == 0 and sh[-1].inst_hi == len(img)
+        for a, b in zip(sh, sh[1:]):
+            assert a.img_hi == b.img_lo and a.inst_hi == b.inst_lo
+        for s in sh:                                  # an image's instances never straddle two ranks
+            assert ((img[s.inst_lo:s.inst_hi] >= s.img_lo) & (img[s.inst_lo:s.inst_hi] < s.img_hi)).all()
+        cost = np.array([(307200 + 8 * areas[s.inst_lo:s.inst_hi]).sum() for s in sh])
+        assert cost.max() <= cost.sum() / world + (307200 + 8 * 100000) * 9 + 4 * 307200
+    # count-based when no areas are known; torch inputs
+    sh = plan_shards(torch.as_tensor(img), P, 2)
+    assert abs((sh[0].inst_hi - sh[0].inst_lo) - len(img) / 2) < 20
+    with pytest.raises(ValueError):
+        plan_shards(img[::-1], P, 2)
+    with pytest.raises(ValueError):
+        plan_shards(img, P, 2, areas=areas[:-1])
+    assert plan_shards(np.zeros(0, np.int64), 0, 2) == [Shard(0, 0, 0, 0), Shard(0, 0, 0, 0)]
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -34,10 +60,12 @@ def _free_port():
 
 
 def _fake_fit(depth, masks, K, ground=None, sample_idx=None, image_index=None):
-    """CPU stand-in with the product function's contract: record n encodes (image, mask area)."""
+    """CPU stand-in with the product function's contract (depth / K / image_index are the rank's LOCAL slice): record n
+    encodes (global image read off the depth plane, mask area)."""
     B = masks.shape[0]
     rec = torch.zeros((B, 39), dtype=torch.float64)
-    rec[:, 0] = torch.as_tensor(np.asarray(image_index), dtype=torch.float64)
+    assert depth.shape[0] > int(np.asarray(image_index).max(initial=-1))     # local indices address the local planes
+    rec[:, 0] = depth[torch.as_tensor(np.asarray(image_index), dtype=torch.long), 1, 1].double()
     rec[:, 1] = masks.reshape(B, -1).ne(0).sum(1).double()
     rec[:, 2] = depth[torch.as_tensor(np.asarray(image_index), dtype=torch.long), 0, 0].double()
     return rec, torch.zeros(B, dtype=torch.int32), None
@@ -79,9 +107,29 @@ def _worker(rank, world, port, q):
             assert b[:, 1].tolist() == masks.reshape(Bt, -1).sum(1).double().tolist()
             assert b[:, 2].tolist() == img.astype(float).tolist()           # each instance saw its own depth plane
             assert all(c > 0 for c in counts)
+        # the same through load_fn: a rank materialises ONLY its own slice; areas drive the balance
+        areas = masks.reshape(Bt, -1).sum(1).numpy()
+        seen = {}
+
+        def load(sh):
+            seen["shard"] = sh
+            return depth[sh.img_lo:sh.img_hi].clone(), masks[sh.inst_lo:sh.inst_hi].clone(), np.eye(3), None, None
+
+        out2 = fit_instances_sharded((P, H, W), None, None, img, areas=areas, fit_fn=_fake_fit, load_fn=load)
+        assert seen["shard"] == plan_shards(img, P, world, areas=areas, frame_pixels=H * W)[rank]
+        if rank == 0:
+            assert torch.equal(out2[0], b) or out2[2] != counts     # same records whenever the cut is the same ...
+            assert out2[0][:, 0].tolist() == img.astype(float).tolist()   # ... and always in global order
+            assert out2[0][:, 1].tolist() == areas.astype(float).tolist()
+        # every instance on rank 0 (all images but the first are empty): rank 1 joins the gather with nothing
+        img1 = np.zeros(3, np.int32)
+        out3 = fit_instances_sharded(depth, masks[:3], np.eye(3), img1, fit_fn=_fake_fit)
+        if rank == 0:
+            assert sorted(out3[2]) == [0, 3] and out3[0].shape == (3, 39)
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
-        q.put((rank, repr(e)))
+        import traceback
+        q.put((rank, repr(e) + " " + traceback.format_exc()[-600:]))
         raise
     finally:
         dist.destroy_process_group()
