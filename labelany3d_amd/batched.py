@@ -53,6 +53,16 @@ def _stream(stream=None):
     return C.c_void_p(s.cuda_stream)
 
 
+def _record(stream, *tensors):
+    """Temporaries allocated on the current stream but consumed by kernels on ``stream``: tell the caching allocator, so the
+    blocks are not handed out again while those kernels still read them."""
+    if stream is None or stream == torch.cuda.current_stream():
+        return
+    for t in tensors:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            t.record_stream(stream)
+
+
 def unpack_boxes(rec):
     """(B,39) record -> dict of center_cam (B,3), dimensions (B,3) = [dz,dy,dx], R_cam (B,3,3),
     bbox3D_cam (B,8,3): the four return values of the reference's estimate_bbox and the keys of its
@@ -170,7 +180,9 @@ def fit_instances(depth, masks, K, ground=None, sample_idx=None, image_index=Non
             return f.boxes[0], f.status[0], f.aux[0]
         if k.shape[0] == 1 and P > 1:
             k = k.expand(P, 3, 3).contiguous()
-        return f.run(d if P > 1 else d[0], m, k, g, si, ii, stream=stream)
+        out = f.run(d if P > 1 else d[0], m, k, g, si, ii, stream=stream)
+        _record(stream, d, m, k, g, si, ii, f.workspace, f.boxes, f.status, f.aux)
+        return out
 
 
 def fit_points(clouds, ground=None, sample_idx=None, method: str = "pca", stream=None, device=None):
@@ -202,6 +214,7 @@ def fit_points(clouds, ground=None, sample_idx=None, method: str = "pca", stream
     with torch.cuda.device(dev):
         check(lib.la3d_fit_points(_ptr(pts), _ptr(off), _ptr(g), _ptr(si), meth, B, _ptr(boxes), _ptr(status),
                                   _ptr(aux), _stream(stream)), "la3d_fit_points")
+    _record(stream, pts, off, g, si, boxes, status, aux)
     return boxes, status, aux
 
 

@@ -1,7 +1,21 @@
-"""Drop-in shim: put labelany3d_amd/compat first on sys.path (the reference resolves its modules by
-bare name from cwd src/, reference src/batch_scripts/whole.py:10,15-16) and
-`from util_3dbox import ...` resolves to the MI355X implementation."""
+"""Drop-in shim for the reference's ``util_3dbox`` module.
+
+Two ways to use it:
+  * ``import labelany3d_amd.compat as c; c.install()`` right after the stage script has set up ``sys.path`` (reference
+    src/batch_scripts/whole.py:10) and BEFORE its ``from util import ...`` lines: the reference's own modules are imported
+    and only their hot-path functions are replaced, so every other helper keeps working;
+  * or put this directory first on ``sys.path``: ``from util_3dbox import ...`` then resolves here, and every name this module
+    does not define is fetched lazily from the reference's own ``util_3dbox.py`` found further down ``sys.path``
+    (module ``__getattr__``, PEP 562), so ``from util import restore_mask_from_crop, depth_to_points`` works.
+"""
 from labelany3d_amd.util_3dbox import *  # noqa: F401,F403
 from labelany3d_amd import util_3dbox as _impl
+from labelany3d_amd.compat import _reference_module
 
 globals().update({k: getattr(_impl, k) for k in dir(_impl) if k.startswith("_estimate")})
+
+
+def __getattr__(attr):
+    if attr.startswith("__"):
+        raise AttributeError(attr)
+    return getattr(_reference_module("util_3dbox"), attr)

@@ -19,6 +19,10 @@
 //   yaw      closed-form 2x2 principal axis with scikit-learn's sign rule, no trigonometry (thread 0);
 //   pass B   same walk, six extents in the yaw frame with NaN-ignoring raw v_min/v_max_f64;
 //   epilog   wave 0 writes center / dims / R_cam / fp16-quantised vertices, one lane per output group.
+#include <mutex>
+#include <utility>
+#include <vector>
+
 #include "la3d_device.hpp"
 #include "la3d_poly.hpp"
 
@@ -1508,6 +1512,20 @@ void inv3_host(const double* A, double* X) {
     }
 }
 
+// Dynamic LDS above the 64 KiB default has to be allowed per kernel AND per device (a process may drive several GPUs): one
+// hipFuncSetAttribute per (kernel, device), remembered in a small table.
+void allow_big_lds(const void* fn, int bytes = 160 * 1024) {
+  static std::mutex mu;
+  static std::vector<std::pair<const void*, int>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) (void)hipGetLastError();
+  std::lock_guard<std::mutex> g(mu);
+  for (const auto& d : done)
+    if (d.first == fn && d.second == dev) return;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) (void)hipGetLastError();
+  done.emplace_back(fn, dev);
+}
+
 constexpr int MAX_MASK_LDS = 128 * 1024;  // bit image budget; larger frames re-read the u8 mask instead
 
 // ------------------------------------------------------------------------------------------
@@ -1641,14 +1659,7 @@ inline int balance_max_rounds() {
 template <bool VEC, bool LDSMASK, bool SAMPLE, bool TILED, int SRC, int RET = 0>
 int launch_fit_inst(const FitParams& p_in, size_t lds, hipStream_t s, void* workspace) {
   auto kern = fit_instances_kernel<VEC, LDSMASK, SAMPLE, TILED, SRC, RET>;
-  static bool attr_done = false;  // one flag per instantiation
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess) {
-      (void)hipGetLastError();
-    }
-    attr_done = true;
-  }
+  allow_big_lds(reinterpret_cast<const void*>(kern));
   FitParams p = p_in;
   p.perm = nullptr;
   // size-balanced launch order: needs the 16-byte mask groups (VEC), more than one workgroup per CU, and a batch
@@ -1918,13 +1929,7 @@ int la3d_rle_decode(const int32_t* counts, const int64_t* offsets, int B, int H,
   if (B == 0) return LA3D_SUCCESS;
   const int nwords = (H * W + 31) / 32;
   const size_t lds = (size_t)nwords * 4 + 64;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(rle_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-      (void)hipGetLastError();
-    attr_done = true;
-  }
+  allow_big_lds(reinterpret_cast<const void*>(rle_decode_kernel));
   hipLaunchKernelGGL(rle_decode_kernel, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), counts,
                      reinterpret_cast<const long long*>(offsets), H, W, nwords, mask_out);
   return check_launch("rle_decode_kernel");
@@ -1940,13 +1945,7 @@ int la3d_poly_decode(const int32_t* poly_xy, const int64_t* ring_offsets, const 
   if (B == 0) return LA3D_SUCCESS;
   const int nwords = (H * W + 31) / 32;
   const size_t lds = (((size_t)nwords * 4 + 15) & ~(size_t)15) + POLY_STAGE_BYTES + 64;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(poly_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-      (void)hipGetLastError();
-    attr_done = true;
-  }
+  allow_big_lds(reinterpret_cast<const void*>(poly_decode_kernel));
   hipLaunchKernelGGL(poly_decode_kernel, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), poly_xy,
                      reinterpret_cast<const long long*>(ring_offsets), reinterpret_cast<const long long*>(inst_rings), H, W, nwords,
                      mask_out);
@@ -1967,13 +1966,7 @@ int la3d_mask_stats_poly(const int32_t* poly_xy, const int64_t* ring_offsets, co
     set_err("la3d_mask_stats_poly: frame too large for LDS");
     return LA3D_ERR_UNSUPPORTED;
   }
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mask_stats_poly_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-      (void)hipGetLastError();
-    attr_done = true;
-  }
+  allow_big_lds(reinterpret_cast<const void*>(mask_stats_poly_kernel));
   hipLaunchKernelGGL(mask_stats_poly_kernel, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), poly_xy,
                      reinterpret_cast<const long long*>(ring_offsets), reinterpret_cast<const long long*>(inst_rings), H, W, nwords,
                      boundary, stats);
@@ -1981,11 +1974,8 @@ int la3d_mask_stats_poly(const int32_t* poly_xy, const int64_t* ring_offsets, co
 }
 
 static void stats_lds_attr() {  // rows beyond 16 K need more than the default 64 KiB of dynamic LDS
-  static bool done = false;
-  if (done) return;
   for (const void* k : {reinterpret_cast<const void*>(mask_stats_rle_kernel), reinterpret_cast<const void*>(mask_stats_vec_kernel)})
-    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) (void)hipGetLastError();
-  done = true;
+    allow_big_lds(k, 160 * 1024 - 1024);
 }
 
 int la3d_mask_stats(const uint8_t* mask, int B, int H, int W, int boundary, int32_t* stats, void* stream) {
@@ -2029,13 +2019,7 @@ int la3d_masked_ratio_median(const float* num, int64_t num_plane_stride, const i
   if (B == 0) return LA3D_SUCCESS;
   const int HW = H * W, nwords = (HW + 31) / 32;
   const size_t lds = (size_t)nwords * 4 + 256 * 4 + 64;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(ratio_median_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-      (void)hipGetLastError();
-    attr_done = true;
-  }
+  allow_big_lds(reinterpret_cast<const void*>(ratio_median_kernel));
   hipLaunchKernelGGL(ratio_median_kernel, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), num,
                      (long long)num_plane_stride, image_index, den, mask_a, mask_b, HW, nwords, median, count);
   return check_launch("ratio_median_kernel");

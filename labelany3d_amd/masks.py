@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 from ._lib import AUX, REC, check, lib
-from .batched import InstanceFitter, _as_dev, _dev, _ptr, _stream
+from .batched import InstanceFitter, _as_dev, _dev, _ptr, _record, _stream
 
 
 def rle_from_string(s) -> np.ndarray:
@@ -230,6 +230,7 @@ def fit_instances_poly(depth, polys, K, ground=None, sample_idx=None, image_inde
                                          9 if k.shape[0] > 1 else 0, _ptr(g), _ptr(si), B, H, W, _ptr(f.boxes[0]),
                                          _ptr(f.status[0]), _ptr(f.aux[0]), _ptr(f.workspace[0]), _stream(stream))
         check(rc, "la3d_fit_instances_poly")
+    _record(stream, d, k, ii, g, si, xy, ro, ir, f.workspace, f.boxes, f.status, f.aux)
     return f.boxes[0], f.status[0], f.aux[0]
 
 
@@ -270,6 +271,7 @@ def fit_instances_rle(depth, rles, K, ground=None, sample_idx=None, image_index=
                                         9 if k.shape[0] > 1 else 0, _ptr(g), _ptr(si), B, H, W, _ptr(f.boxes[0]),
                                         _ptr(f.status[0]), _ptr(f.aux[0]), _ptr(f.workspace[0]), _stream(stream))
         check(rc, "la3d_fit_instances_rle")
+    _record(stream, d, k, ii, g, si, c, o, f.workspace, f.boxes, f.status, f.aux)
     return f.boxes[0], f.status[0], f.aux[0]
 
 

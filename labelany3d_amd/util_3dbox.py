@@ -72,14 +72,15 @@ def convert_box_vertices(center_x, center_y, center_z, l, w, h, yaw):
 
 
 # ---- box fit (reference :106-224) --------------------------------------------------------------
-def _fit_one(in_pc, ground_equ, method):
-    """One cloud through la3d_fit_points, with the reference's RNG side effect for N > 500."""
+def _fit_one(in_pc, ground_equ, method, subsample=True):
+    """One cloud through la3d_fit_points, with the reference's RNG side effect for N > 500 (estimate_bbox only: the yaw
+    helpers of the reference see the cloud they are given, :181-224)."""
     if method not in ("pca", "convex_hull"):
         raise ValueError(f"Unknown method: {method}. Use 'pca' or 'convex_hull'")  # reference :151
     pc = np.asarray(in_pc)
     pc = pc.reshape(-1, 3) if pc.size else np.zeros((0, 3))
     idx = None
-    if pc.shape[0] > _lib.NSAMPLE:  # reference :123-125 — global stream, with replacement
+    if subsample and pc.shape[0] > _lib.NSAMPLE:  # reference :123-125 — global stream, with replacement
         idx = np.random.randint(0, pc.shape[0], _lib.NSAMPLE).astype(np.int32)[None]
     ground = None if ground_equ is None else np.asarray(ground_equ, dtype=np.float64).reshape(-1)[:4][None]
     if ground is not None and ground.shape[1] < 4:
@@ -109,13 +110,15 @@ def estimate_bbox(in_pc, cat_name=None, ground_equ=None, method="pca"):
 
 def _estimate_yaw_pca(rotated_pc):
     """Yaw of the first principal axis of the (x,z) footprint (reference :181-186)."""
-    _, aux = _fit_one(rotated_pc, None, "pca")
+    _, aux = _fit_one(rotated_pc, None, "pca", subsample=False)   # no subsampling, no RNG draw: as the reference helper
     return np.float64(aux[0])
 
 
 def _estimate_yaw_convex_hull(rotated_pc):
     """Yaw of the minimum-area enclosing rectangle over hull edges (reference :189-224)."""
-    _, aux = _fit_one(rotated_pc, None, "convex_hull")  # PCA fallback (:222-224) happens inside the kernel
+    # PCA fallback (:222-224) happens inside the kernel; no subsampling (clouds above 512 valid points are not supported by
+    # the hull kernel - the reference only ever feeds this helper the <= 500 points estimate_bbox kept)
+    _, aux = _fit_one(rotated_pc, None, "convex_hull", subsample=False)
     return np.float64(aux[0])
 
 

@@ -126,6 +126,53 @@ def test_compat_modules_resolve_by_bare_name(monkeypatch):
         sys.modules.pop(name, None)
 
 
+def test_compat_shim_falls_back_to_the_reference_module(tmp_path, monkeypatch):
+    """The import lines of the reference's stages through the shim: `from util import restore_mask_from_crop,
+    align_to_depth_match, draw_cube` (whole.py:15) must still resolve — names the shim does not define come from the
+    reference's own util.py further down sys.path — while depth_to_points is the MI355X one.  And install() patches the
+    reference's modules in place when './' is first on sys.path (whole.py:10)."""
+    import importlib
+    import sys
+
+    ref = tmp_path / "src"
+    ref.mkdir()
+    (ref / "util.py").write_text("def depth_to_points(*a, **k):\n    return 'reference'\n\ndef restore_mask_from_crop():\n"
+                                 "    return 'ref-helper'\n\ndef draw_cube():\n    return 'ref-draw'\n")
+    (ref / "util_3dbox.py").write_text("def estimate_bbox(*a, **k):\n    return 'reference'\n\ndef normalize(v):\n    return 'ref-normalize'\n"
+                                       "def save_3d_with_ground_alignment_bbox(*a, **k):\n    return 'reference'\n"
+                                       "def _estimate_yaw_pca(*a):\n    return 0\n\ndef _estimate_yaw_convex_hull(*a):\n    return 0\n")
+    compat = os.path.join(ROOT, "labelany3d_amd", "compat")
+    import labelany3d_amd.compat as C
+
+    def fresh():
+        for name in ("util", "util_3dbox", "cam_utils"):
+            sys.modules.pop(name, None)
+        C._loaded.clear()
+
+    # (a) shim directory first on the path
+    fresh()
+    monkeypatch.setattr(sys, "path", [compat, str(ref)] + [p for p in sys.path if p not in (compat, str(ref))])
+    ns = {}
+    exec("from util import restore_mask_from_crop, draw_cube, depth_to_points", ns)
+    assert ns["restore_mask_from_crop"]() == "ref-helper" and ns["draw_cube"]() == "ref-draw"
+    import labelany3d_amd.util as impl_util
+    assert ns["depth_to_points"] is impl_util.depth_to_points
+    with pytest.raises(ImportError):
+        exec("from util import no_such_function", {})
+    # (b) the reference's own directory first ('./' in the stages): install() patches in place
+    fresh()
+    monkeypatch.setattr(sys, "path", [str(ref)] + [p for p in sys.path if p not in (compat, str(ref))])
+    patched = C.install()
+    assert "util.depth_to_points" in patched and "util_3dbox.estimate_bbox" in patched
+    ns = {}
+    exec("from util import depth_to_points, restore_mask_from_crop\nfrom util_3dbox import save_3d_with_ground_alignment_bbox, normalize", ns)
+    import labelany3d_amd.util_3dbox as impl_3d
+    assert ns["depth_to_points"] is impl_util.depth_to_points and ns["restore_mask_from_crop"]() == "ref-helper"
+    assert ns["save_3d_with_ground_alignment_bbox"] is impl_3d.save_3d_with_ground_alignment_bbox
+    assert ns["normalize"](1) == "ref-normalize"           # everything else stays the reference's
+    fresh()
+
+
 def test_draw_sample_idx_consumes_global_stream_like_reference():
     from labelany3d_amd import draw_sample_idx
 
