@@ -175,6 +175,18 @@ int la3d_masked_ratio_median(const float* num, int64_t num_plane_stride, const i
                              const uint8_t* mask_a, const uint8_t* mask_b, int B, int H, int W, float* median,
                              int32_t* count, void* stream);
 
+/* align_depth (reference src/batch_scripts/depth.py:52-92), the data-parallel parts around its scikit-learn RANSAC fit:
+ * la3d_align_select compacts, in row-major order, the pixels with ~isinf(relative) & (metric < max_valid_depth) [& mask]
+ * into relative_out / metric_out (dev f32, capacity n) — what the reference feeds regressor.fit (:69-78) — and writes
+ * their number to count (dev i64).  workspace: dev scratch of la3d_align_workspace_bytes(n) bytes.
+ * la3d_align_apply writes depth = full(fill); depth[sel] = relative[sel] * coef + intercept in float32 with
+ * sel = mask when given, else ~isinf(relative) (:82-90; fill is 10000.0 there). */
+size_t la3d_align_workspace_bytes(int64_t n);
+int la3d_align_select(const float* relative, const float* metric, const uint8_t* mask, int64_t n, float max_valid_depth,
+                      float* relative_out, float* metric_out, int64_t* count, void* workspace, void* stream);
+int la3d_align_apply(const float* relative, const uint8_t* mask, int64_t n, float coef, float intercept, float fill,
+                     float* out, void* stream);
+
 /* ---- sparse unprojection at match points -------------------------------------------------------
  * Reference src/matching/matcher.py:70-91: depth dev f32 [H][W] looked up at (int(v), int(u)) of each match
  * uv dev f64 [N][2]; matches whose depth is -1 (or that fall outside the frame) get valid = 0 and NaNs;

@@ -39,6 +39,10 @@ _SIGS = {
     "la3d_mask_stats_rle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "la3d_masked_ratio_median": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                            C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "la3d_align_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "la3d_align_select": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
+    "la3d_align_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "la3d_unproject_matches": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double,
                                          C.c_double, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                          C.c_void_p, C.c_void_p, C.c_void_p]),

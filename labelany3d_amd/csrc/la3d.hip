@@ -1363,10 +1363,14 @@ __global__ __launch_bounds__(256) void iou_matrix_kernel(const double* __restric
 }
 
 // Masked depth-ratio median — reference src/util.py:476-486 (align_to_depth_match): overlap = mask_a & mask_b,
-// scale = np.median(num[overlap] / den[overlap]) in float32.  One workgroup per instance: the overlap goes to a
-// bit image in LDS, then the k-th smallest ratio is found exactly by a 4 x 8-bit most-significant-first radix
-// select on an order-preserving key (two selections when the count is even; np.median averages the two middle
-// values in float32).  Any NaN ratio makes the result NaN, as np.median does; an empty overlap gives count 0, NaN.
+// scale = np.median(num[overlap] / den[overlap]) in float32.  One 256-thread workgroup per instance:
+//   phase 1  the two u8 masks are read once with 16-byte loads into an overlap bit image in LDS;
+//   rounds   the k-th smallest ratio is found exactly by a most-significant-first radix select on an order-preserving key,
+//            three rounds of 11 / 11 / 10 bits; a wave takes 64 consecutive pixels per step (coalesced 256-byte loads of
+//            num and den, chunks without an overlap pixel are skipped), so the ratios are re-derived from memory once per
+//            round instead of being kept.  For an even count np.median averages the two middle values (in float32): both
+//            ranks are selected in the same three rounds (two histograms once their prefixes part).
+// Any NaN ratio makes the result NaN, as np.median does; an empty overlap gives count 0, NaN.
 __device__ inline unsigned f32_key(float v) {
   const unsigned b = __float_as_uint(v);
   return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
@@ -1375,6 +1379,8 @@ __device__ inline float f32_unkey(unsigned k) {
   return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
 }
 
+constexpr int RM_BINS = 2048;
+
 __global__ __launch_bounds__(256) void ratio_median_kernel(const float* __restrict__ num, long long num_stride,
                                                            const int* __restrict__ image_index, const float* __restrict__ den,
                                                            const unsigned char* __restrict__ mask_a,
@@ -1382,79 +1388,225 @@ __global__ __launch_bounds__(256) void ratio_median_kernel(const float* __restri
                                                            float* __restrict__ median, int* __restrict__ count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned* bits = reinterpret_cast<unsigned*>(smem);
-  unsigned* hist = bits + nwords;          // 256 bins
-  unsigned* misc = hist + 256;             // [0] n, [1] nan count, [2] selected prefix, [3] remaining rank
-  const int tid = threadIdx.x, inst = blockIdx.x;
+  unsigned* hist = bits + ((nwords + 3) & ~3);   // [2][RM_BINS]
+  unsigned* part = hist + 2 * RM_BINS;           // [2][256] per-thread bin sums for the scan
+  unsigned* misc = part + 512;                   // [0] n, [1] nan count, [2..3] prefix per state, [4..5] rank per state
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, inst = blockIdx.x;
   const float* np_ = num + (long long)(image_index ? image_index[inst] : inst) * num_stride;
   const float* dp = den + (long long)inst * HW;
   const unsigned char* ma = mask_a + (long long)inst * HW;
   const unsigned char* mb = mask_b ? mask_b + (long long)inst * HW : nullptr;
-  if (tid < 4) misc[tid] = 0;
-  __syncthreads();
-  // overlap bit image + counts
-  unsigned n_local = 0, nan_local = 0;
-  for (int w = tid; w < nwords; w += 256) {
-    unsigned word = 0;
-    const int i0 = w * 32;
-    for (int k = 0; k < 32; ++k) {
-      const int i = i0 + k;
-      if (i < HW && ma[i] && (!mb || mb[i])) {
-        word |= 1u << k;
-        const float r = np_[i] / dp[i];
-        nan_local += (r != r) ? 1u : 0u;
+  if (tid < 8) misc[tid] = 0;
+  // ---- phase 1: overlap bit image ----
+  unsigned n_local = 0;
+  const bool vec = (HW % 16 == 0) && ((reinterpret_cast<uintptr_t>(ma) & 15) == 0) && (!mb || (reinterpret_cast<uintptr_t>(mb) & 15) == 0);
+  if (vec) {
+    unsigned short* b16 = reinterpret_cast<unsigned short*>(bits);
+    const u32x4* a4 = reinterpret_cast<const u32x4*>(ma);
+    const u32x4* b4 = reinterpret_cast<const u32x4*>(mb);
+    const int ngroups = HW >> 4;
+#pragma unroll 4
+    for (int g = tid; g < ngroups; g += 256) {
+      const u32x4 wa = __builtin_nontemporal_load(a4 + g);
+      unsigned pat = nz16(wa.x, wa.y, wa.z, wa.w);
+      if (mb) {
+        const u32x4 wb = __builtin_nontemporal_load(b4 + g);
+        pat &= nz16(wb.x, wb.y, wb.z, wb.w);
       }
+      b16[g] = (unsigned short)pat;
+      n_local += __popc(pat);
     }
-    bits[w] = word;
-    n_local += __popc(word);
+    if ((ngroups & 1) && tid == 0) b16[ngroups] = 0;
+  } else {
+    for (int w = tid; w < nwords; w += 256) {
+      unsigned word = 0;
+      const int i0 = w * 32;
+      for (int k = 0; k < 32; ++k) {
+        const int i = i0 + k;
+        if (i < HW && ma[i] && (!mb || mb[i])) word |= 1u << k;
+      }
+      bits[w] = word;
+      n_local += __popc(word);
+    }
   }
-  atomicAdd(&misc[0], n_local);
-  atomicAdd(&misc[1], nan_local);
+  n_local = (unsigned)wave_sum_i((int)n_local);
+  __syncthreads();                       // misc is zeroed
+  if (lane == 0) atomicAdd(&misc[0], n_local);
   __syncthreads();
   const unsigned n = misc[0];
-  if (n == 0 || misc[1] != 0) {
-    if (tid == 0) { median[inst] = NAN; count[inst] = (int)n; }
+  if (n == 0) {
+    if (tid == 0) { median[inst] = NAN; count[inst] = 0; }
     return;
   }
-  float result[2] = {0.f, 0.f};
-  const int nsel = (n & 1u) ? 1 : 2;
-  for (int sel = 0; sel < nsel; ++sel) {
-    unsigned rank = (n & 1u) ? n / 2 : n / 2 - 1 + sel;   // 0-based rank among the sorted ratios
-    unsigned prefix = 0, pmask = 0;
-    for (int shift = 24; shift >= 0; shift -= 8) {
-      hist[tid] = 0;
-      __syncthreads();
-      for (int w = tid; w < nwords; w += 256) {
-        unsigned word = bits[w];
-        while (word) {
-          const int k = __ffs((int)word) - 1;
-          word &= word - 1;
-          const int i = w * 32 + k;
-          const unsigned key = f32_key(np_[i] / dp[i]);
-          if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 0xffu], 1u);
-        }
+  const int nstate = (n & 1u) ? 1 : 2;
+  if (tid == 0) {
+    misc[4] = (n & 1u) ? n / 2 : n / 2 - 1;   // 0-based ranks among the sorted ratios
+    misc[5] = n / 2;
+  }
+  const int nchunks = (HW + 63) >> 6;
+  unsigned pmask = 0;
+  const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
+  for (int round = 0; round < 3; ++round) {
+    const int shift = shifts[round];
+    const unsigned dmask = (1u << widths[round]) - 1u;
+    for (int i = tid; i < 2 * RM_BINS; i += 256) hist[i] = 0;
+    __syncthreads();                     // also publishes misc[2..5] of the previous round
+    const unsigned p0 = misc[2], p1 = misc[3];
+    const bool split = nstate == 2 && p0 != p1;
+    unsigned nan_local = 0;
+    for (int c = wave; c < nchunks; c += 4) {
+      const unsigned w0 = bits[2 * c], w1 = (2 * c + 1 < nwords) ? bits[2 * c + 1] : 0u;
+      if ((w0 | w1) == 0) continue;      // wave-uniform
+      const unsigned on = lane < 32 ? (w0 >> lane) & 1u : (w1 >> (lane - 32)) & 1u;
+      if (on) {
+        const int i = c * 64 + lane;
+        const float r = np_[i] / dp[i];
+        if (round == 0) nan_local += (r != r) ? 1u : 0u;
+        const unsigned key = f32_key(r);
+        const unsigned d = (key >> shift) & dmask;
+        if ((key & pmask) == p0) atomicAdd(&hist[d], 1u);
+        if (split && (key & pmask) == p1) atomicAdd(&hist[RM_BINS + d], 1u);
       }
-      __syncthreads();
-      if (tid == 0) {   // the bin holding the wanted rank
-        unsigned acc = 0, b = 0;
-        for (; b < 256; ++b) {
-          if (acc + hist[b] > rank) break;
-          acc += hist[b];
-        }
-        misc[2] = prefix | (b << shift);
-        misc[3] = rank - acc;
-      }
-      __syncthreads();
-      prefix = misc[2];
-      rank = misc[3];
-      pmask |= 0xffu << shift;
-      __syncthreads();
     }
-    result[sel] = f32_unkey(prefix);
+    if (round == 0) {
+      const unsigned long long any = __ballot(nan_local != 0);
+      if (lane == 0 && any) atomicAdd(&misc[1], 1u);
+    }
+    __syncthreads();
+    if (round == 0 && misc[1] != 0) {    // uniform
+      if (tid == 0) { median[inst] = NAN; count[inst] = (int)n; }
+      return;
+    }
+    // the bin holding each wanted rank: thread t sums bins [8t, 8t+8); exclusive scan of the 256 sums by thread 0's wave
+    for (int st = 0; st < nstate; ++st) {
+      const unsigned* h = hist + ((st == 1 && split) ? RM_BINS : 0);
+      unsigned sum = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sum += h[tid * 8 + k];
+      part[st * 256 + tid] = sum;
+    }
+    __syncthreads();
+    if (tid < nstate) {
+      const int st = tid;
+      const unsigned* h = hist + ((st == 1 && split) ? RM_BINS : 0);
+      unsigned rank = misc[4 + st], acc = 0;
+      int t = 0;
+      for (; t < 256; ++t) {
+        const unsigned s = part[st * 256 + t];
+        if (acc + s > rank) break;
+        acc += s;
+      }
+      int bsel = t * 8;
+      for (; bsel < t * 8 + 8; ++bsel) {
+        if (acc + h[bsel] > rank) break;
+        acc += h[bsel];
+      }
+      misc[2 + st] = (st == 0 ? p0 : p1) | ((unsigned)bsel << shift);
+      misc[4 + st] = rank - acc;
+    }
+    pmask |= dmask << shift;
+    __syncthreads();
   }
   if (tid == 0) {
-    median[inst] = (nsel == 1) ? result[0] : (result[0] + result[1]) / 2.0f;   // float32 mean of the two middle values
+    const float v0 = f32_unkey(misc[2]);
+    median[inst] = (nstate == 1) ? v0 : (v0 + f32_unkey(misc[3])) / 2.0f;   // float32 mean of the two middle values
     count[inst] = (int)n;
   }
+}
+
+// ---- align_depth support (reference src/batch_scripts/depth.py:52-92) -----------------------------------------------
+// valid = ~isinf(relative) & (metric < max_valid) [& mask]; the regressor (scikit-learn RANSAC, third party, random) is fed
+// relative[valid], metric[valid] in row-major order, and its prediction is scattered back over a 10000.0-filled frame.
+// Order-preserving stream compaction in three small kernels: per-tile counts, scan of the counts, scatter.
+constexpr int AL_TILE = 4096;   // elements per 256-thread workgroup (16 per thread, four float4)
+
+__device__ inline bool align_valid(float rel, float met, unsigned char m, bool has_mask, float max_valid) {
+  const bool isinf_rel = (__float_as_uint(rel) & 0x7fffffffu) == 0x7f800000u;   // np.isinf: NaN is NOT excluded
+  return !isinf_rel && (met < max_valid) && (!has_mask || m != 0);
+}
+
+__global__ __launch_bounds__(256) void align_count_kernel(const float* __restrict__ rel, const float* __restrict__ met,
+                                                          const unsigned char* __restrict__ mask, long long n, float max_valid,
+                                                          long long* __restrict__ counts) {
+  __shared__ int part[4];
+  const long long base = (long long)blockIdx.x * AL_TILE;
+  int c = 0;
+  for (int k = 0; k < AL_TILE / 256; ++k) {
+    const long long i = base + k * 256 + threadIdx.x;
+    if (i < n) c += align_valid(rel[i], met[i], mask ? mask[i] : 1, mask != nullptr, max_valid) ? 1 : 0;
+  }
+  c = wave_sum_i(c);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+// exclusive scan of the tile counts in place, total appended at counts[nb]; one workgroup
+__global__ __launch_bounds__(256) void align_scan_kernel(long long* __restrict__ counts, int nb, long long* __restrict__ total) {
+  __shared__ long long carry;
+  __shared__ long long wsum[4];
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < nb; b0 += 256) {
+    const int b = b0 + threadIdx.x;
+    const long long v = b < nb ? counts[b] : 0;
+    long long incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const long long t = __shfl_up(incl, o);
+      if ((threadIdx.x & 63) >= o) incl += t;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    long long off = carry;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += wsum[w];
+    if (b < nb) counts[b] = off + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 255) carry = off + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { counts[nb] = carry; *total = carry; }
+}
+
+__global__ __launch_bounds__(256) void align_scatter_kernel(const float* __restrict__ rel, const float* __restrict__ met,
+                                                            const unsigned char* __restrict__ mask, long long n, float max_valid,
+                                                            const long long* __restrict__ offsets, float* __restrict__ rel_out,
+                                                            float* __restrict__ met_out) {
+  __shared__ int wtot[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long base = (long long)blockIdx.x * AL_TILE;
+  long long out = offsets[blockIdx.x];
+  for (int k = 0; k < AL_TILE / 256; ++k) {   // 256 consecutive elements per step: row-major order is kept
+    const long long i = base + k * 256 + threadIdx.x;
+    float r = 0.f, m = 0.f;
+    bool v = false;
+    if (i < n) { r = rel[i]; m = met[i]; v = align_valid(r, m, mask ? mask[i] : 1, mask != nullptr, max_valid); }
+    const unsigned long long bal = __ballot(v);
+    if (lane == 0) wtot[wave] = __popcll(bal);
+    __syncthreads();
+    long long pos = out;
+    for (int w = 0; w < wave; ++w) pos += wtot[w];
+    const int step_total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    if (v) {
+      pos += __popcll(bal & ((1ull << lane) - 1ull));
+      rel_out[pos] = r;
+      met_out[pos] = m;
+    }
+    out += step_total;
+    __syncthreads();
+  }
+}
+
+// depth = full(fill); depth[sel] = relative[sel] * coef + intercept, sel = mask (if given) else ~isinf(relative)  (:82-90)
+__global__ __launch_bounds__(256) void align_apply_kernel(const float* __restrict__ rel, const unsigned char* __restrict__ mask,
+                                                          long long n, float coef, float intercept, float fill,
+                                                          float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float r = rel[i];
+  const bool sel = mask ? mask[i] != 0 : (__float_as_uint(r) & 0x7fffffffu) != 0x7f800000u;
+  // LinearRegression.predict on float32: X @ coef_.T (one float32 product) + intercept_
+  out[i] = sel ? __fadd_rn(__fmul_rn(r, coef), intercept) : fill;
 }
 
 // Sparse unprojection at match points — reference src/matching/matcher.py:70-91: depth looked up at
@@ -2018,11 +2170,46 @@ int la3d_masked_ratio_median(const float* num, int64_t num_plane_stride, const i
   }
   if (B == 0) return LA3D_SUCCESS;
   const int HW = H * W, nwords = (HW + 31) / 32;
-  const size_t lds = (size_t)nwords * 4 + 256 * 4 + 64;
+  const size_t lds = (size_t)((nwords + 3) & ~3) * 4 + (2 * RM_BINS + 512 + 8) * 4;
   allow_big_lds(reinterpret_cast<const void*>(ratio_median_kernel));
   hipLaunchKernelGGL(ratio_median_kernel, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), num,
                      (long long)num_plane_stride, image_index, den, mask_a, mask_b, HW, nwords, median, count);
   return check_launch("ratio_median_kernel");
+}
+
+size_t la3d_align_workspace_bytes(int64_t n) {
+  if (n <= 0) return 8;
+  return (size_t)((n + AL_TILE - 1) / AL_TILE + 2) * 8;
+}
+
+int la3d_align_select(const float* relative, const float* metric, const uint8_t* mask, int64_t n, float max_valid_depth,
+                      float* relative_out, float* metric_out, int64_t* count, void* workspace, void* stream) {
+  if (n < 0 || !count || !workspace || (n > 0 && (!relative || !metric || !relative_out || !metric_out))) {
+    set_err("la3d_align_select: bad argument");
+    return LA3D_ERR_ARG;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  long long* counts = static_cast<long long*>(workspace);
+  const int nb = (int)((n + AL_TILE - 1) / AL_TILE);
+  if (nb > 0)
+    hipLaunchKernelGGL(align_count_kernel, dim3(nb), dim3(256), 0, s, relative, metric, mask, (long long)n, max_valid_depth, counts);
+  hipLaunchKernelGGL(align_scan_kernel, dim3(1), dim3(256), 0, s, counts, nb, reinterpret_cast<long long*>(count));
+  if (nb > 0)
+    hipLaunchKernelGGL(align_scatter_kernel, dim3(nb), dim3(256), 0, s, relative, metric, mask, (long long)n, max_valid_depth,
+                       counts, relative_out, metric_out);
+  return check_launch("align_select");
+}
+
+int la3d_align_apply(const float* relative, const uint8_t* mask, int64_t n, float coef, float intercept, float fill,
+                     float* out, void* stream) {
+  if (n < 0 || (n > 0 && (!relative || !out))) {
+    set_err("la3d_align_apply: bad argument");
+    return LA3D_ERR_ARG;
+  }
+  if (n == 0) return LA3D_SUCCESS;
+  hipLaunchKernelGGL(align_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     relative, mask, (long long)n, coef, intercept, fill, out);
+  return check_launch("align_apply_kernel");
 }
 
 int la3d_unproject_matches(const float* depth, int H, int W, const double* uv, int N, double fx, double fy, double cx,

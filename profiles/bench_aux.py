@@ -70,8 +70,41 @@ def main():
                                               note="run lengths resident on the device; equivalent u8 planes: 315 MB")
     t = timed(lambda: la.mask_counts(masks), n=20)
     out["mask_counts_1024x640x480"] = dict(s=t, bytes=Bm * H * W, GBps=Bm * H * W / t / 1e9)
-    # consumers
+    # polygons: the same rectangles as 4-vertex parts + star-shaped parts with ~60 vertices of about the same area
+    rect_segs = [[[int(b), int(a), int(b + w - 1), int(a), int(b + w - 1), int(a + h - 1), int(b), int(a + h - 1)]]
+                 for a, b, h, w in zip(r0, c0, hh, ww)]
+    star_segs = []
+    for a, b, h, w in zip(r0, c0, hh, ww):
+        ang = np.sort(rs.uniform(0, 2 * np.pi, 60))
+        rad = rs.uniform(0.7, 1.0, 60)
+        star_segs.append([np.stack([b + w / 2 + w / 2 * rad * np.cos(ang), a + h / 2 + h / 2 * rad * np.sin(ang)], 1).ravel().tolist()])
     depth = torch.rand((Bm, H, W), device="cuda") * 9.5 + 0.5
+    for name, segs in (("rect4", rect_segs), ("star60", star_segs)):
+        polys = la.pack_polygons(segs, H, W)
+        dpolys = tuple(torch.as_tensor(x, device="cuda") for x in polys[:3]) + polys[3:]
+        t = timed(lambda: la.poly_decode(dpolys), n=20)
+        out[f"poly_decode_1024x640x480_{name}"] = dict(s=t, masks_per_s=Bm / t, GBps=Bm * H * W / t / 1e9, vertices=int(len(polys[0])))
+        t = timed(lambda: la.mask_stats_poly(dpolys), n=20)
+        out[f"mask_stats_poly_1024_{name}"] = dict(s=t, masks_per_s=Bm / t)
+        t = timed(lambda: la.fit_instances_poly(depth, dpolys, K), n=20)
+        out[f"fit_instances_poly_1024_{name}"] = dict(s=t, boxes_per_s=Bm / t,
+                                                       note="polygon parts rasterised inside the fit kernel; includes output allocation")
+    # masked depth-ratio median (align_to_depth_match): two u8 masks + two f32 planes per instance
+    den = torch.rand((Bm, H, W), device="cuda") * 2.8 + 0.2
+    mb = torch.rand((Bm, H, W), device="cuda") < 0.8
+    t = timed(lambda: la.masked_ratio_median(depth, den, masks, mb), n=20)
+    ov = int((masks & mb).sum())
+    out["masked_ratio_median_1024x640x480"] = dict(s=t, instances_per_s=Bm / t, mask_bytes=2 * Bm * H * W, overlap_px=ov,
+                                                   GBps=(2 * Bm * H * W + 3 * 8 * ov) / t / 1e9,
+                                                   note="bytes = both masks once + 8 B per overlap pixel in each of the three radix rounds")
+    # align_depth selection (one 640x480 frame) and prediction scatter
+    rel, met = depth[0].clone(), den[0] * 100
+    rel[torch.rand((H, W), device="cuda") < 0.05] = float("inf")
+    t = timed(lambda: la.align_select(rel, met, None, 200.0), n=50)
+    out["align_select_640x480"] = dict(s=t, frames_per_s=1 / t, note="three small launches + one 8-byte read-back of the count")
+    t = timed(lambda: la.align_apply(rel, 2.5, 0.0), n=50)
+    out["align_apply_640x480"] = dict(s=t, frames_per_s=1 / t)
+    # consumers
     boxes, _, _ = la.fit_instances(depth, masks, K)
     t = timed(lambda: la.project_boxes(boxes, K, (W, H)))
     out["project_boxes_1024"] = dict(s=t, boxes_per_s=Bm / t)
