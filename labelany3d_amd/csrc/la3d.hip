@@ -423,6 +423,13 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : NT / 64) void fit_instance
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: lives in an SGPR
+#ifdef LA3D_TIMELINE
+  const unsigned long long t_entry = wall_clock64();   // before the first memory access of the workgroup
+#endif
+  // (measured, profiles/timeline.py: all workgroups of a launch ENTER within 0.7 us, but VMEM issue is arbitrated by age, so the
+  // youngest of the four workgroups of a CU gets its first load - this perm entry - back only when an older one has finished
+  // its mask stream, ~25 us in; warming the table through L1 does not help, and s_setprio by dispatch group only moves the
+  // starvation to the oldest group, which holds the largest instances: DESIGN.md section 5.2)
   const int inst = p.perm ? p.perm[blockIdx.x] : xcd_remap(blockIdx.x, p.B);
   const int img = p.image_index ? p.image_index[inst] : inst;
   const int HW = p.HW;
@@ -446,9 +453,9 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : NT / 64) void fit_instance
 #ifdef LA3D_TIMELINE
   // measurement build only (profiles/timeline.py): wall-clock stamps (100 MHz) per workgroup at the phase boundaries,
   // into the workspace behind the launch-order arrays
-  double* tl = p.geo + 1024 + (long long)inst * 8;
+  double* tl = p.geo + 1024 + (long long)inst * 16;
 #define LA3D_STAMP(k) do { if (tid == 0) tl[k] = (double)wall_clock64(); } while (0)
-  if (tid == 0) tl[7] = (double)blockIdx.x;
+  if (tid == 0) { tl[7] = (double)blockIdx.x; tl[8] = (double)t_entry; }
 #else
 #define LA3D_STAMP(k) do { } while (0)
 #endif
@@ -480,8 +487,9 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : NT / 64) void fit_instance
       // 16-bit pattern of a 16-byte group is four dot products (sum byte_j * 2^j) - 11 VALU instructions per group instead
       // of 27 for the general non-zero test.  Every word is ORed into `seen`; a byte above 1 anywhere in the plane sends the
       // whole workgroup through the general loop below (same bit image either way).
+      constexpr int P0U = RET > 0 ? 2 * LA3D_P0_UNROLL : LA3D_P0_UNROLL;
       unsigned seen = 0;
-#pragma unroll (RET > 0 ? 2 * LA3D_P0_UNROLL : LA3D_P0_UNROLL)
+#pragma unroll P0U
       for (int g = tid; g < ngroups; g += NT) {
 #if LA3D_P0_NT
         const u32x4 w = __builtin_nontemporal_load(m4 + g);

@@ -50,8 +50,17 @@ def one(B, sizes="bench"):
     for _ in range(5):
         f.run(depth, masks, K)
     torch.cuda.synchronize()
-    tl = f.workspace[0][8192: 8192 + B * 64].view(torch.float64).cpu().numpy().reshape(B, 8)
-    t = (tl[:, :7] - tl[:, 0].min()) / 100.0  # us
+    tl = f.workspace[0][8192: 8192 + B * 128].view(torch.float64).cpu().numpy().reshape(B, 16)
+    t0 = tl[:, 8].min()                        # the first workgroup's entry (before any memory access)
+    t = (tl[:, :7] - t0) / 100.0               # us
+    ent = (tl[:, 8] - t0) / 100.0
+    print(f"\n== B={B}: kernel entry (before the first load) min / mean / max: {ent.min():.1f} {ent.mean():.1f} {ent.max():.1f} us; "
+          f"entry -> first stamp (perm / kernarg loads): mean {np.mean(t[:, 0] - ent):.1f} max {np.max(t[:, 0] - ent):.1f} us")
+    if os.environ.get("TL_DETAIL"):
+        blk = tl[:, 7].astype(int)
+        for g in range(0, B, 256):
+            sel = (blk >= g) & (blk < g + 256)
+            print(f"   blocks {g:5d}..{g + 255:5d}: entry mean {ent[sel].mean():6.1f} max {ent[sel].max():6.1f} | first stamp mean {t[sel, 0].mean():6.1f}")
     print(f"\n== B={B} sizes={sizes}: launch-relative times in us (min / mean / max over workgroups)")
     for k, n in enumerate(names):
         print(f"  {n:18s} {t[:, k].min():7.1f} {t[:, k].mean():7.1f} {t[:, k].max():7.1f}")
@@ -77,8 +86,8 @@ if os.environ.get("TL_DETAIL"):
     for _ in range(5):
         f.run(depth, masks, K)
     torch.cuda.synchronize()
-    tl = f.workspace[0][8192: 8192 + B * 64].view(torch.float64).cpu().numpy().reshape(B, 8)
-    t = (tl[:, :7] - tl[:, 0].min()) / 100.0
+    tl = f.workspace[0][8192: 8192 + B * 128].view(torch.float64).cpu().numpy().reshape(B, 16)
+    t = (tl[:, :7] - tl[:, 8].min()) / 100.0
     blk = tl[:, 7].astype(int)
     order = np.argsort(blk)
     t = t[order]
