@@ -66,6 +66,13 @@ int la3d_unproject(const float* depth, const double* K9, const double* Rt12, int
  * counts: dev i32 [B].  The host needs it to draw np.random.randint(0, N, 500). */
 int la3d_mask_counts(const uint8_t* mask, int B, int H, int W, int32_t* counts, void* stream);
 
+/* Process-wide switch for the size-balanced launch order of la3d_fit_instances* (256 < B <= 3 resident sets): mode 1 = on,
+ * 0 = off, -1 = default (on; LA3D_BALANCE=0 in the environment turns it off).  The order assumes the call finds an idle
+ * GPU.  A caller that pipelines independent batches on several streams (batch k+1 enqueued while batch k runs) should turn
+ * it off: the batches then overlap their memory-bound and compute-bound phases by themselves (measured +20 %), and an
+ * order computed for an idle chip only gets in the way.  Records never depend on it. */
+int la3d_set_launch_order(int mode);
+
 /* Bytes of device scratch la3d_fit_instances needs for (B,H,W); may be 0. */
 size_t la3d_workspace_bytes(int B, int H, int W);
 

@@ -15,6 +15,7 @@ from .batched import (  # noqa: F401
     fit_instances,
     fit_points,
     mask_counts,
+    set_launch_order,
     unproject,
     unpack_boxes,
 )
@@ -26,5 +27,5 @@ from .masks import (filter_annotations, fit_instances_poly, fit_instances_rle, k
 
 from .depth_align import align_apply, align_depth, align_select, depth_match_transform  # noqa: E402,F401
 
-__all__ = ["align_depth", "align_select", "align_apply", "depth_match_transform", "fit_instances_poly", "pack_polygons", "poly_decode", "mask_stats_poly", "segmentations_to_masks", "unproject_matches", "masked_ratio_median", "project_boxes", "iou2d_matrix", "hungarian_matching", "fit_instances_rle", "rle_decode", "filter_annotations", "mask_stats", "mask_stats_rle", "keep_instances", "pack_rle", "rle_from_string","fit_instances", "fit_points", "mask_counts", "unproject", "draw_sample_idx", "unpack_boxes",
+__all__ = ["set_launch_order", "align_depth", "align_select", "align_apply", "depth_match_transform", "fit_instances_poly", "pack_polygons", "poly_decode", "mask_stats_poly", "segmentations_to_masks", "unproject_matches", "masked_ratio_median", "project_boxes", "iou2d_matrix", "hungarian_matching", "fit_instances_rle", "rle_decode", "filter_annotations", "mask_stats", "mask_stats_rle", "keep_instances", "pack_rle", "rle_from_string","fit_instances", "fit_points", "mask_counts", "unproject", "draw_sample_idx", "unpack_boxes",
            "InstanceFitter", "La3dError", "REC", "AUX", "NSAMPLE"]

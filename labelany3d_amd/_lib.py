@@ -15,6 +15,7 @@ ERR_UNSUPPORTED = -2
 _SIGS = {
     "la3d_version": (C.c_int, []),
     "la3d_last_error": (C.c_char_p, []),
+    "la3d_set_launch_order": (C.c_int, [C.c_int]),
     "la3d_unproject": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_int,
                                  C.c_void_p, C.c_int, C.c_void_p]),
     "la3d_mask_counts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -63,6 +63,12 @@ def _record(stream, *tensors):
             t.record_stream(stream)
 
 
+def set_launch_order(mode) -> None:
+    """Size-balanced launch order of the batched fit (see include/la3d.h): ``True`` / ``False`` / ``None`` (= default: on).
+    Turn it off when independent batches are pipelined on several streams."""
+    check(lib.la3d_set_launch_order(-1 if mode is None else int(bool(mode))), "la3d_set_launch_order")
+
+
 def unpack_boxes(rec):
     """(B,39) record -> dict of center_cam (B,3), dimensions (B,3) = [dz,dy,dx], R_cam (B,3,3),
     bbox3D_cam (B,8,3): the four return values of the reference's estimate_bbox and the keys of its

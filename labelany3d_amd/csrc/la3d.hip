@@ -19,6 +19,7 @@
 //   yaw      closed-form 2x2 principal axis with scikit-learn's sign rule, no trigonometry (thread 0);
 //   pass B   same walk, six extents in the yaw frame with NaN-ignoring raw v_min/v_max_f64;
 //   epilog   wave 0 writes center / dims / R_cam / fp16-quantised vertices, one lane per output group.
+#include <atomic>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -1805,7 +1806,11 @@ __global__ __launch_bounds__(ORDER_WAVES * 64) void launch_order_kernel(const un
   }
 }
 
+std::atomic<int> g_launch_order{-1};   // la3d_set_launch_order: -1 = default (on, unless LA3D_BALANCE=0), 0 = off, 1 = on
+
 inline bool balance_enabled() {
+  const int m = g_launch_order.load(std::memory_order_relaxed);
+  if (m >= 0) return m != 0;
   const char* e = getenv("LA3D_BALANCE");  // measurement / test switch: 0 = plain XCD-strided order
   return !(e && e[0] == '0');
 }
@@ -1881,6 +1886,15 @@ int la3d_version(void) { return LA3D_ABI_VERSION; }
 const char* la3d_last_error(void) { return g_err; }
 
 double la3d_f16_round_host(double x) { return f16_round(x); }
+
+int la3d_set_launch_order(int mode) {
+  if (mode < -1 || mode > 1) {
+    set_err("la3d_set_launch_order: mode must be -1 (default), 0 (off) or 1 (on)");
+    return LA3D_ERR_ARG;
+  }
+  g_launch_order.store(mode, std::memory_order_relaxed);
+  return LA3D_SUCCESS;
+}
 
 // Workspace layout (one per concurrently running call; contents need not be initialised or preserved):
 //   instance engine: [B] u32 sort keys, then [B] i32 block -> instance (the size-balanced launch order; 8*B bytes)
