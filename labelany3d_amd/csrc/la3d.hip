@@ -1375,10 +1375,13 @@ __global__ __launch_bounds__(256) void iou_matrix_kernel(const double* __restric
 // scale = np.median(num[overlap] / den[overlap]) in float32.  One 256-thread workgroup per instance:
 //   phase 1  the two u8 masks are read once with 16-byte loads into an overlap bit image in LDS;
 //   rounds   the k-th smallest ratio is found exactly by a most-significant-first radix select on an order-preserving key,
-//            three rounds of 11 / 11 / 10 bits; a wave takes 64 consecutive pixels per step (coalesced 256-byte loads of
-//            num and den, chunks without an overlap pixel are skipped), so the ratios are re-derived from memory once per
-//            round instead of being kept.  For an even count np.median averages the two middle values (in float32): both
-//            ranks are selected in the same three rounds (two histograms once their prefixes part).
+//            four rounds of 8 bits; a wave takes 64 consecutive pixels per step (coalesced 256-byte loads of num and den,
+//            chunks without an overlap pixel are skipped), so the ratios are re-derived from memory once per round instead of
+//            being kept.  Depth ratios share their leading bits, so a plain LDS histogram would serialise on a handful of
+//            bins: every bin has 16 copies (one per lane & 15, laid out [bin][copy] so that equal bins fall on different
+//            banks) - at most four lanes of a wave ever meet on one word.
+//   even n   np.median averages the two middle values (in float32).  The upper one equals the lower one when the lower
+//            key occurs often enough; otherwise it is the smallest key above it (one more sweep with an LDS atomicMin).
 // Any NaN ratio makes the result NaN, as np.median does; an empty overlap gives count 0, NaN.
 __device__ inline unsigned f32_key(float v) {
   const unsigned b = __float_as_uint(v);
@@ -1388,24 +1391,28 @@ __device__ inline float f32_unkey(unsigned k) {
   return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
 }
 
-constexpr int RM_BINS = 2048;
+constexpr int RM_COPIES = 16;
 
-__global__ __launch_bounds__(256) void ratio_median_kernel(const float* __restrict__ num, long long num_stride,
+constexpr int RM_NT = 512;   // threads per workgroup
+
+__global__ __launch_bounds__(RM_NT) void ratio_median_kernel(const float* __restrict__ num, long long num_stride,
                                                            const int* __restrict__ image_index, const float* __restrict__ den,
                                                            const unsigned char* __restrict__ mask_a,
                                                            const unsigned char* __restrict__ mask_b, int HW, int nwords,
                                                            float* __restrict__ median, int* __restrict__ count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned* bits = reinterpret_cast<unsigned*>(smem);
-  unsigned* hist = bits + ((nwords + 3) & ~3);   // [2][RM_BINS]
-  unsigned* part = hist + 2 * RM_BINS;           // [2][256] per-thread bin sums for the scan
-  unsigned* misc = part + 512;                   // [0] n, [1] nan count, [2..3] prefix per state, [4..5] rank per state
+  unsigned* hist = bits + ((nwords + 3) & ~3);   // [256][RM_COPIES]
+  unsigned* bsum = hist + 256 * RM_COPIES;       // [256] bin totals
+  unsigned* misc = bsum + 256;                   // [0] n, [1] nan flag, [2] prefix, [3] rank, [4] count of the selected bin, [5] min key above,
+                                                 // [6] number of active chunks
+  unsigned short* clist = reinterpret_cast<unsigned short*>(misc + 8);   // ids of the 64-pixel chunks holding an overlap pixel
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, inst = blockIdx.x;
   const float* np_ = num + (long long)(image_index ? image_index[inst] : inst) * num_stride;
   const float* dp = den + (long long)inst * HW;
   const unsigned char* ma = mask_a + (long long)inst * HW;
   const unsigned char* mb = mask_b ? mask_b + (long long)inst * HW : nullptr;
-  if (tid < 8) misc[tid] = 0;
+  if (tid < 8) misc[tid] = tid == 5 ? 0xffffffffu : 0u;
   // ---- phase 1: overlap bit image ----
   unsigned n_local = 0;
   const bool vec = (HW % 16 == 0) && ((reinterpret_cast<uintptr_t>(ma) & 15) == 0) && (!mb || (reinterpret_cast<uintptr_t>(mb) & 15) == 0);
@@ -1415,7 +1422,7 @@ __global__ __launch_bounds__(256) void ratio_median_kernel(const float* __restri
     const u32x4* b4 = reinterpret_cast<const u32x4*>(mb);
     const int ngroups = HW >> 4;
 #pragma unroll 4
-    for (int g = tid; g < ngroups; g += 256) {
+    for (int g = tid; g < ngroups; g += RM_NT) {
       const u32x4 wa = __builtin_nontemporal_load(a4 + g);
       unsigned pat = nz16(wa.x, wa.y, wa.z, wa.w);
       if (mb) {
@@ -1427,7 +1434,7 @@ __global__ __launch_bounds__(256) void ratio_median_kernel(const float* __restri
     }
     if ((ngroups & 1) && tid == 0) b16[ngroups] = 0;
   } else {
-    for (int w = tid; w < nwords; w += 256) {
+    for (int w = tid; w < nwords; w += RM_NT) {
       unsigned word = 0;
       const int i0 = w * 32;
       for (int k = 0; k < 32; ++k) {
@@ -1439,7 +1446,7 @@ __global__ __launch_bounds__(256) void ratio_median_kernel(const float* __restri
     }
   }
   n_local = (unsigned)wave_sum_i((int)n_local);
-  __syncthreads();                       // misc is zeroed
+  __syncthreads();                       // misc is initialised
   if (lane == 0) atomicAdd(&misc[0], n_local);
   __syncthreads();
   const unsigned n = misc[0];
@@ -1447,78 +1454,110 @@ __global__ __launch_bounds__(256) void ratio_median_kernel(const float* __restri
     if (tid == 0) { median[inst] = NAN; count[inst] = 0; }
     return;
   }
-  const int nstate = (n & 1u) ? 1 : 2;
-  if (tid == 0) {
-    misc[4] = (n & 1u) ? n / 2 : n / 2 - 1;   // 0-based ranks among the sorted ratios
-    misc[5] = n / 2;
-  }
+  if (tid == 0) misc[3] = (n & 1u) ? n / 2 : n / 2 - 1;   // 0-based rank of the (lower) middle value
   const int nchunks = (HW + 63) >> 6;
+  // active-chunk list (order is irrelevant): the rounds visit only chunks with an overlap pixel
+  for (int c0 = 0; c0 < nchunks; c0 += RM_NT) {
+    const int c = c0 + tid;
+    const bool act = c < nchunks && ((bits[2 * c] | ((2 * c + 1 < nwords) ? bits[2 * c + 1] : 0u)) != 0);
+    const unsigned long long bal = __ballot(act);
+    unsigned base = 0;
+    if (lane == 0 && bal) base = atomicAdd(&misc[6], (unsigned)__popcll(bal));
+    base = __shfl(base, 0);
+    if (act) clist[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)c;
+  }
+  __syncthreads();
+  const int nact = (int)misc[6];
+  const int copy = lane & (RM_COPIES - 1);
   unsigned pmask = 0;
-  const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
-  for (int round = 0; round < 3; ++round) {
-    const int shift = shifts[round];
-    const unsigned dmask = (1u << widths[round]) - 1u;
-    for (int i = tid; i < 2 * RM_BINS; i += 256) hist[i] = 0;
-    __syncthreads();                     // also publishes misc[2..5] of the previous round
-    const unsigned p0 = misc[2], p1 = misc[3];
-    const bool split = nstate == 2 && p0 != p1;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int i = tid; i < 256 * RM_COPIES; i += RM_NT) hist[i] = 0;
+    __syncthreads();                     // also publishes misc[2..3] of the previous round
+    const unsigned prefix = misc[2];
     unsigned nan_local = 0;
-    for (int c = wave; c < nchunks; c += 4) {
-      const unsigned w0 = bits[2 * c], w1 = (2 * c + 1 < nwords) ? bits[2 * c + 1] : 0u;
-      if ((w0 | w1) == 0) continue;      // wave-uniform
-      const unsigned on = lane < 32 ? (w0 >> lane) & 1u : (w1 >> (lane - 32)) & 1u;
-      if (on) {
-        const int i = c * 64 + lane;
-        const float r = np_[i] / dp[i];
-        if (round == 0) nan_local += (r != r) ? 1u : 0u;
-        const unsigned key = f32_key(r);
-        const unsigned d = (key >> shift) & dmask;
-        if ((key & pmask) == p0) atomicAdd(&hist[d], 1u);
-        if (split && (key & pmask) == p1) atomicAdd(&hist[RM_BINS + d], 1u);
+    constexpr int RM_U = 4;              // chunks in flight per wave: 2 x RM_U coalesced loads issued before any is used
+    for (int j0 = wave * RM_U; j0 < nact; j0 += (RM_NT / 64) * RM_U) {
+      float a[RM_U], d[RM_U];
+      unsigned on[RM_U];
+#pragma unroll
+      for (int u = 0; u < RM_U; ++u) {
+        on[u] = 0; a[u] = 0.f; d[u] = 1.f;
+        if (j0 + u < nact) {
+          const int c = clist[j0 + u];
+          const unsigned w0 = bits[2 * c], w1 = (2 * c + 1 < nwords) ? bits[2 * c + 1] : 0u;
+          on[u] = lane < 32 ? (w0 >> lane) & 1u : (w1 >> (lane - 32)) & 1u;
+          if (on[u]) { a[u] = np_[c * 64 + lane]; d[u] = dp[c * 64 + lane]; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < RM_U; ++u) {
+        if (on[u]) {
+          const float r = a[u] / d[u];
+          if (shift == 24) nan_local |= (r != r) ? 1u : 0u;
+          const unsigned key = f32_key(r);
+          if ((key & pmask) == prefix) atomicAdd(&hist[((key >> shift) & 0xffu) * RM_COPIES + copy], 1u);
+        }
       }
     }
-    if (round == 0) {
-      const unsigned long long any = __ballot(nan_local != 0);
-      if (lane == 0 && any) atomicAdd(&misc[1], 1u);
-    }
+    if (shift == 24 && __ballot(nan_local != 0) != 0 && lane == 0) misc[1] = 1u;
     __syncthreads();
-    if (round == 0 && misc[1] != 0) {    // uniform
+    if (shift == 24 && misc[1] != 0) {   // uniform
       if (tid == 0) { median[inst] = NAN; count[inst] = (int)n; }
       return;
     }
-    // the bin holding each wanted rank: thread t sums bins [8t, 8t+8); exclusive scan of the 256 sums by thread 0's wave
-    for (int st = 0; st < nstate; ++st) {
-      const unsigned* h = hist + ((st == 1 && split) ? RM_BINS : 0);
-      unsigned sum = 0;
+    if (tid < 256) {   // bin totals, then the bin holding the wanted rank (wave 0: four bins per lane, exclusive scan over the lanes)
+      unsigned t = 0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) sum += h[tid * 8 + k];
-      part[st * 256 + tid] = sum;
+      for (int k = 0; k < RM_COPIES; ++k) t += hist[tid * RM_COPIES + k];
+      bsum[tid] = t;
     }
     __syncthreads();
-    if (tid < nstate) {
-      const int st = tid;
-      const unsigned* h = hist + ((st == 1 && split) ? RM_BINS : 0);
-      unsigned rank = misc[4 + st], acc = 0;
-      int t = 0;
-      for (; t < 256; ++t) {
-        const unsigned s = part[st * 256 + t];
-        if (acc + s > rank) break;
-        acc += s;
+    if (wave == 0) {
+      const unsigned b0 = bsum[4 * lane], b1 = bsum[4 * lane + 1], b2 = bsum[4 * lane + 2], b3 = bsum[4 * lane + 3];
+      const unsigned mine = b0 + b1 + b2 + b3;
+      unsigned incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
       }
-      int bsel = t * 8;
-      for (; bsel < t * 8 + 8; ++bsel) {
-        if (acc + h[bsel] > rank) break;
-        acc += h[bsel];
+      const unsigned rank = misc[3], excl = incl - mine;
+      if (excl <= rank && rank < incl) {   // exactly one lane
+        unsigned acc = excl, bsel = 0, cnt = b0;
+        if (rank >= acc + b0) { acc += b0; bsel = 1; cnt = b1;
+          if (rank >= acc + b1) { acc += b1; bsel = 2; cnt = b2;
+            if (rank >= acc + b2) { acc += b2; bsel = 3; cnt = b3; } } }
+        misc[2] = prefix | ((4u * (unsigned)lane + bsel) << shift);
+        misc[3] = rank - acc;
+        misc[4] = cnt;
       }
-      misc[2 + st] = (st == 0 ? p0 : p1) | ((unsigned)bsel << shift);
-      misc[4 + st] = rank - acc;
     }
-    pmask |= dmask << shift;
+    pmask |= 0xffu << shift;
     __syncthreads();
   }
+  const unsigned key0 = misc[2];
+  unsigned key1 = key0;
+  if (!(n & 1u) && misc[3] + 1 >= misc[4]) {   // uniform: the upper middle value is the smallest key above key0
+    for (int j = wave; j < nact; j += RM_NT / 64) {
+      const int c = clist[j];
+      const unsigned w0 = bits[2 * c], w1 = (2 * c + 1 < nwords) ? bits[2 * c + 1] : 0u;
+      const unsigned on = lane < 32 ? (w0 >> lane) & 1u : (w1 >> (lane - 32)) & 1u;
+      unsigned k = 0xffffffffu;
+      if (on) {
+        const int i = c * 64 + lane;
+        const unsigned key = f32_key(np_[i] / dp[i]);
+        if (key > key0) k = key;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) k = min(k, (unsigned)__shfl_xor((int)k, o));
+      if (lane == 0 && k != 0xffffffffu) atomicMin(&misc[5], k);
+    }
+    __syncthreads();
+    key1 = misc[5];
+  }
   if (tid == 0) {
-    const float v0 = f32_unkey(misc[2]);
-    median[inst] = (nstate == 1) ? v0 : (v0 + f32_unkey(misc[3])) / 2.0f;   // float32 mean of the two middle values
+    const float v0 = f32_unkey(key0);
+    median[inst] = (n & 1u) ? v0 : (v0 + f32_unkey(key1)) / 2.0f;   // float32 mean of the two middle values
     count[inst] = (int)n;
   }
 }
@@ -2192,9 +2231,9 @@ int la3d_masked_ratio_median(const float* num, int64_t num_plane_stride, const i
   }
   if (B == 0) return LA3D_SUCCESS;
   const int HW = H * W, nwords = (HW + 31) / 32;
-  const size_t lds = (size_t)((nwords + 3) & ~3) * 4 + (2 * RM_BINS + 512 + 8) * 4;
+  const size_t lds = (size_t)((nwords + 3) & ~3) * 4 + (256 * RM_COPIES + 256 + 8) * 4 + (size_t)((HW + 63) / 64) * 2 + 16;
   allow_big_lds(reinterpret_cast<const void*>(ratio_median_kernel));
-  hipLaunchKernelGGL(ratio_median_kernel, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), num,
+  hipLaunchKernelGGL(ratio_median_kernel, dim3(B), dim3(RM_NT), lds, static_cast<hipStream_t>(stream), num,
                      (long long)num_plane_stride, image_index, den, mask_a, mask_b, HW, nwords, median, count);
   return check_launch("ratio_median_kernel");
 }
