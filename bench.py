@@ -107,19 +107,28 @@ def make_config5(B, device, seed):
     return depth, masks, K, int(masks.sum(dtype=torch.int64)), (r0, c0, hh, ww)
 
 
-def required_bytes(masks):
+def required_bytes(masks, image_index=None, num_images=0):
     """HBM bytes the path cannot avoid for these inputs: every u8 mask plane once, the 128-byte depth lines of the 32 px x
-    8 row tiles that hold a mask pixel once (a depth line with no mask pixel need not be read), one 312-byte record per
-    instance.  Computed from the masks themselves, so it is checkable from the inputs alone."""
+    8 row tiles that hold a mask pixel once (a depth line with no mask pixel need not be read; with a shared depth plane
+    per image, a tile used by several instances of the image counts once), one 312-byte record per instance.  Computed
+    from the masks themselves, so it is checkable from the inputs alone.  Returns (bytes, active tiles summed over
+    instances)."""
     B, h, w = masks.shape
-    tiles = 0
+    tiles, union = 0, None
     hp, wp = (h + 7) // 8 * 8, (w + 31) // 32 * 32
+    nt = (hp // 8) * (wp // 32)
+    if image_index is not None:
+        union = torch.zeros((num_images, nt), dtype=torch.float32, device=masks.device)
     for a in range(0, B, 512):
         m = masks[a:a + 512]
         if (hp, wp) != (h, w):
             m = torch.nn.functional.pad(m, (0, wp - w, 0, hp - h))
-        tiles += int(m.view(m.shape[0], hp // 8, 8, wp // 32, 32).amax(dim=(2, 4)).ne(0).sum())
-    return B * h * w + tiles * 1024 + B * 39 * 8, tiles
+        tm = m.view(m.shape[0], hp // 8, 8, wp // 32, 32).amax(dim=(2, 4)).ne(0).reshape(m.shape[0], nt)
+        tiles += int(tm.sum())
+        if union is not None:
+            union.index_add_(0, image_index[a:a + 512].long(), tm.float())
+    depth_tiles = tiles if union is None else int((union > 0).sum())
+    return B * h * w + depth_tiles * 1024 + B * 39 * 8, tiles
 
 
 def kernel_source_sha256():
@@ -375,7 +384,7 @@ def main():
             alg_bytes = args.config3 * H * W * 4 + B * (H * W + 39 * 8)
         # bytes this input cannot be fitted without: every mask plane once + the 128-B depth lines of the 32x8 tiles that hold
         # a mask pixel once + the records (computed from the masks; with run-length input the mask term is the run lengths)
-        req_bytes, active_tiles = required_bytes(masks)
+        req_bytes, active_tiles = required_bytes(masks, image_index, args.config3)
         if args.rle:
             req_bytes += int(rle_c.numel()) * 4 - B * H * W
         step_s = kern_ms * 1e-3
@@ -428,8 +437,8 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "required_bytes_per_launch": req_bytes,
-                "byte_model": "B*H*W mask bytes once + 1024 B x (32 px x 8 row tiles holding a mask pixel) depth once + 312 B x B "
-                              "records; computed from the generated masks in this run",
+                "byte_model": "B*H*W mask bytes once + 1024 B x (32 px x 8 row tiles holding a mask pixel; shared depth planes: "
+                              "union per image) depth once + 312 B x B records; computed from the generated masks in this run",
                 "avg_launch_ms": kern_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "algorithmic_GBps": alg_bytes / step_s / 1e9,
