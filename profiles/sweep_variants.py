@@ -85,6 +85,53 @@ def worker(args):
         out["rle1024"] = {"us": best, "Mboxes_s": B / best, "sha": h}
         del depth, masks, f
         torch.cuda.empty_cache()
+    if args.poly:
+        import ctypes as C
+
+        import numpy as np
+        from labelany3d_amd import pack_polygons
+        from labelany3d_amd._lib import check, lib
+        B = 1024
+        depth, masks, K, n_masked, rects = bench.make_inputs(B, dev, 1234)
+        r0, c0, hh, ww = rects
+        rs = np.random.RandomState(7)
+        segsets = {"rect4": [[[int(b), int(a), int(b + w - 1), int(a), int(b + w - 1), int(a + h - 1), int(b), int(a + h - 1)]]
+                             for a, b, h, w in zip(r0, c0, hh, ww)]}
+        star = []
+        for a, b, h, w in zip(r0, c0, hh, ww):
+            ang = np.sort(rs.uniform(0, 2 * np.pi, 60))
+            rad = rs.uniform(0.7, 1.0, 60)
+            star.append([np.stack([b + w / 2 + w / 2 * rad * np.cos(ang), a + h / 2 + h / 2 * rad * np.sin(ang)], 1).ravel().tolist()])
+        segsets["star60"] = star
+        kfull = K[None].expand(B, 3, 3).contiguous()
+        f = InstanceFitter(B, bench.H, bench.W, dev)
+        st = torch.cuda.current_stream()
+        for name, segs in segsets.items():
+            xy, ro, ir, _, _ = pack_polygons(segs, bench.H, bench.W)
+            xy, ro, ir = (torch.as_tensor(x, device=dev) for x in (xy, ro, ir))
+
+            def run():
+                check(lib.la3d_fit_instances_poly(C.c_void_p(depth.data_ptr()), bench.H * bench.W, None, C.c_void_p(xy.data_ptr()),
+                                                  C.c_void_p(ro.data_ptr()), C.c_void_p(ir.data_ptr()), C.c_void_p(kfull.data_ptr()), 9,
+                                                  None, None, B, bench.H, bench.W, C.c_void_p(f.boxes[0].data_ptr()),
+                                                  C.c_void_p(f.status[0].data_ptr()), C.c_void_p(f.aux[0].data_ptr()),
+                                                  C.c_void_p(f.workspace[0].data_ptr()), C.c_void_p(st.cuda_stream)), "poly")
+            for _ in range(10):
+                run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            best = 1e9
+            for rep in range(3):
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(200):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1) / 200 * 1e3)
+            h = hashlib.sha1(f.boxes[0].cpu().numpy().tobytes()).hexdigest()[:12]
+            out[f"poly_{name}"] = {"us": best, "Mboxes_s": B / best, "sha": h}
+        del depth, masks, f
+        torch.cuda.empty_cache()
     if args.config3:
         depth, masks, K, n_masked, img = bench.make_config3(args.config3, dev, 1234)
         B = masks.shape[0]
@@ -116,6 +163,7 @@ def main():
     ap.add_argument("--config3", type=int, default=0)
     ap.add_argument("--config5", action="store_true")
     ap.add_argument("--rle", action="store_true")
+    ap.add_argument("--poly", action="store_true")
     args = ap.parse_args()
     if args.worker:
         return worker(args)
@@ -137,6 +185,8 @@ def main():
             cmd += ["--config5"]
         if args.rle:
             cmd += ["--rle"]
+        if args.poly:
+            cmd += ["--poly"]
         try:
             r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
         except subprocess.TimeoutExpired:

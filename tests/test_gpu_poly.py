@@ -72,9 +72,20 @@ def _random_segmentation(rs, w, h, kind):
             pts.append((xs[k + 1], top if k % 2 == 0 else bot - 2))
         pts.append((xs[-1], bot))
         return [np.asarray(pts).ravel().tolist()]
-    if kind == 6:     # axis-aligned rectangle
+    if kind == 6:     # axis-aligned rectangle, often flush with a frame border (spans that run to the last column / row)
         x0, x1 = sorted(rs.randint(0, w, 2))
         y0, y1 = sorted(rs.randint(0, h, 2))
+        t = rs.randint(0, 6)
+        if t == 0:
+            x1 = w - 1
+        elif t == 1:
+            x0 = 0
+        elif t == 2:
+            y1 = h - 1
+        elif t == 3:
+            x0, y0, x1, y1 = 0, 0, w - 1, h - 1
+        elif t == 4:
+            x1 = w + 5          # beyond the right border: clipped side
         return [[x0, y0, x1, y0, x1, y1, x0, y1]]
     # very many vertices (more than one stage of 32 sides, long sweeps)
     return [np.clip(_star(rs, w, h, rs.randint(100, 400), jitter=0.3), 0, [w - 1, h - 1]).ravel().tolist()]
@@ -85,6 +96,14 @@ def test_poly_decode_equals_fillpoly_oracle(la, H, W, seed):
     rs = np.random.RandomState(seed)
     n = 40 if H * W > 100000 else 90          # 260 polygons over the four frames
     segs = [_random_segmentation(rs, W, H, k % 8) for k in range(n)]
+    # deterministic border cases: parts flush with / beyond every frame border, few and many sides (both rasteriser forms)
+    ring = lambda x0, y0, x1, y1, k: [np.concatenate([np.stack([np.linspace(x0, x1, k), np.full(k, y0)], 1),     # noqa: E731
+                                                      np.stack([np.full(k, x1), np.linspace(y0, y1, k)], 1),
+                                                      np.stack([np.linspace(x1, x0, k), np.full(k, y1)], 1),
+                                                      np.stack([np.full(k, x0), np.linspace(y1, y0, k)], 1)]).ravel().tolist()]
+    for k in (2, 12):
+        segs += [ring(W // 3, 2, W - 1, H // 2, k), ring(0, H // 3, W // 2, H - 1, k), ring(0, 0, W - 1, H - 1, k),
+                 ring(W // 2, -7, W + 9, H + 4, k), ring(-5, -5, 3, 3, k)]
     segs.append([])                            # an instance without parts: empty mask
     polys = la.pack_polygons(segs, H, W)
     got = np_(la.poly_decode(polys))
