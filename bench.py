@@ -135,7 +135,7 @@ def kernel_source_sha256():
     """Hash of the kernel sources: stamps the PMC traffic figure so that a stale constant is detectable."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("la3d.hip", "la3d_device.hpp", "la3d_split.hip"):
+    for f in ("la3d.hip", "la3d_device.hpp", "la3d_poly.hpp", "la3d_split.hip"):
         h.update(open(os.path.join(ROOT, "labelany3d_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 

@@ -11,7 +11,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $REPO/bench.py --steps 50 --warmup 5 --no-cpu-baseline $EXTRA"
+BENCH="python $REPO/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-pipelined $EXTRA"
 # 1) per-kernel time
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o stats -- $BENCH > $OUT/stats.log 2>&1
 # 2) HBM traffic counters, one pass each (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2); never with sys/hip traces

@@ -438,6 +438,38 @@ def test_convex_hull_method(la):
     assert np_(st).tolist() == [5, 0]
 
 
+def test_convex_hull_rectangular_footprint_ties(la):
+    """Exactly rectangular footprints: all four hull edges give the same enclosing-rectangle area, so which edge wins is
+    an implementation detail of the hull walk (Qhull's starting vertex in the reference, counter-clockwise from the
+    lexicographically smallest vertex here and in the oracle) - a documented don't-care.  Whatever edge is taken, the box
+    must be the same rectangle: equal centre, equal dy, {dx, dz} equal as a set, yaw equal modulo pi/2, and the records
+    of the yaw helpers must not consume the global RNG above 500 points (the reference's helpers see the cloud as is)."""
+    from labelany3d_amd import util_3dbox as U
+
+    rs = np.random.RandomState(8)
+    clouds = []
+    for k in range(6):
+        a, b = rs.uniform(0.5, 3), rs.uniform(0.2, 2)
+        th = [0.0, np.pi / 6, -1.0, 0.3, 2.0, np.pi / 4][k]
+        gx, gz = np.meshgrid(np.linspace(-a, a, 7), np.linspace(-b, b, 5))
+        pc = np.stack([gx.ravel(), rs.uniform(-0.4, 0.4, gx.size), gz.ravel()], 1)
+        clouds.append(pc @ O.rotate_y(th).T + [rs.uniform(-1, 1), 0.2, 6.0])
+    boxes, status, aux = la.fit_points(clouds, None, None, "convex_hull")
+    boxes, aux = np_(boxes), np_(aux)
+    assert np_(status).tolist() == [0] * 6
+    for i, c in enumerate(clouds):
+        rec, st, a = O.fit_points(c, None, False, "convex_hull")
+        assert st == 0
+        np.testing.assert_allclose(boxes[i, [0, 1, 2, 4]], rec[[0, 1, 2, 4]], rtol=0, atol=1e-9)       # centre, dy
+        np.testing.assert_allclose(sorted(boxes[i, [3, 5]]), sorted(rec[[3, 5]]), rtol=0, atol=1e-9)  # {dz, dx}
+        d = (aux[i, 0] - a["yaw"]) / (np.pi / 2)
+        assert abs(d - round(d)) < 1e-9
+    big = np.random.RandomState(1).rand(2000, 3)
+    state = np.random.get_state()[1].copy()
+    U._estimate_yaw_pca(big)                                  # N > 500: no subsampling, no RNG draw in the helper
+    assert (np.random.get_state()[1] == state).all()
+
+
 # ------------------------------------------------------------------------------------------
 # full-size, size-independent properties (B = 1024 at 640x480: BASELINE config 2)
 # ------------------------------------------------------------------------------------------
