@@ -62,6 +62,11 @@ def load() -> C.CDLL:
             f"{LIB} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(needs hipcc; cross-compiles gfx950 without a GPU). There is no CPU fallback."
         )
+    # PyTorch bundles its own libamdhip64; load it FIRST so that libla3d.so binds to the same HIP runtime instance as the
+    # tensors it is handed (loaded the other way round, the process ends up with two runtimes and the library's stream /
+    # event calls fail with "no ROCm-capable device is detected")
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)  # AttributeError if the .so is stale

@@ -28,6 +28,9 @@ def _dev(device=None) -> torch.device:
     return torch.device("cuda", torch.cuda.current_device())
 
 
+_SMALL_UPLOADS: dict = {}   # (bytes, dtype, shape, device) -> device tensor: small host arrays that callers pass again and again (K)
+
+
 def _as_dev(x, dtype, device) -> torch.Tensor:
     if isinstance(x, torch.Tensor):
         t = x
@@ -41,6 +44,15 @@ def _as_dev(x, dtype, device) -> torch.Tensor:
     a = np.asarray(x)
     if dtype == torch.uint8 and a.dtype == np.bool_:
         a = a.view(np.uint8)
+    if a.nbytes <= 1024:   # e.g. the 3x3 intrinsics: one upload per distinct value instead of one per call
+        key = (a.tobytes(), str(a.dtype), a.shape, dtype, str(device))
+        t = _SMALL_UPLOADS.get(key)
+        if t is None:
+            if len(_SMALL_UPLOADS) > 256:
+                _SMALL_UPLOADS.clear()
+            t = torch.as_tensor(np.ascontiguousarray(a), device=device).to(dtype).contiguous()
+            _SMALL_UPLOADS[key] = t
+        return t
     return torch.as_tensor(np.ascontiguousarray(a), device=device).to(dtype).contiguous()
 
 
@@ -110,12 +122,18 @@ class InstanceFitter:
         self.B, self.H, self.W = int(B), int(H), int(W)
         self.device = _dev(device)
         self.slots = slots
-        self.boxes = torch.empty((slots, B, REC), dtype=torch.float64, device=self.device)
-        self.status = torch.empty((slots, B), dtype=torch.int32, device=self.device)
-        self.aux = torch.empty((slots, B, AUX), dtype=torch.float64, device=self.device)
         nbytes = int(lib.la3d_workspace_bytes(self.B, self.H, self.W))
+        wsz = max((nbytes + 255) // 256 * 256, 256)
+        # ONE device allocation carved into the four buffers (a call through the convenience wrappers allocates once)
+        up = lambda v: (v + 255) // 256 * 256  # noqa: E731  (every region starts 256-byte aligned, like a fresh allocation)
+        nb, na, ns = slots * B * REC * 8, slots * B * AUX * 8, slots * B * 4
+        o_aux, o_st, o_ws = up(nb), up(nb) + up(na), up(nb) + up(na) + up(ns)
+        self._arena = torch.empty(o_ws + ws_slots * wsz, dtype=torch.uint8, device=self.device)
+        self.boxes = self._arena[:nb].view(torch.float64).view(slots, B, REC)
+        self.aux = self._arena[o_aux:o_aux + na].view(torch.float64).view(slots, B, AUX)
+        self.status = self._arena[o_st:o_st + ns].view(torch.int32).view(slots, B)
         # one workspace per concurrently running call (calls on different streams must not share it)
-        self.workspace = torch.empty((ws_slots, max((nbytes + 255) // 256 * 256, 256)), dtype=torch.uint8, device=self.device)
+        self.workspace = self._arena[o_ws:].view(ws_slots, wsz)
 
     def run(self, depth: torch.Tensor, masks: torch.Tensor, K: torch.Tensor, ground=None, sample_idx=None,
             image_index=None, slot: int = 0, stream=None, ws_slot: int = 0):

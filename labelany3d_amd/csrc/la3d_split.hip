@@ -517,6 +517,7 @@ struct Streams {
   hipEvent_t fork = nullptr, scan_done[MAX_SUB] = {}, join[2] = {nullptr, nullptr};
   int device = -1;
   bool ok = false;
+  hipError_t err = hipSuccess;
 };
 
 Streams& streams_for_current_device() {
@@ -525,13 +526,16 @@ Streams& streams_for_current_device() {
   (void)hipGetDevice(&dev);
   Streams& s = st[dev & 15];
   if (!s.ok || s.device != dev) {
-    bool good = true;
-    for (int i = 0; i < 2; ++i) good &= hipStreamCreateWithFlags(&s.aux[i], hipStreamNonBlocking) == hipSuccess;
-    good &= hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; i < MAX_SUB; ++i) good &= hipEventCreateWithFlags(&s.scan_done[i], hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; i < 2; ++i) good &= hipEventCreateWithFlags(&s.join[i], hipEventDisableTiming) == hipSuccess;
+    hipError_t first = hipSuccess;
+    auto chk = [&](hipError_t e) { if (e != hipSuccess && first == hipSuccess) first = e; };
+    (void)hipGetLastError();   // a stale error of an earlier, unrelated call must not be mistaken for ours
+    for (int i = 0; i < 2; ++i) chk(hipStreamCreateWithFlags(&s.aux[i], hipStreamNonBlocking));
+    chk(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
+    for (int i = 0; i < MAX_SUB; ++i) chk(hipEventCreateWithFlags(&s.scan_done[i], hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) chk(hipEventCreateWithFlags(&s.join[i], hipEventDisableTiming));
     s.device = dev;
-    s.ok = good;
+    s.ok = first == hipSuccess;
+    s.err = first;
   }
   return s;
 }
@@ -564,7 +568,7 @@ bool split_eligible(const FitParams& p, bool vec, bool ldsmask) {
 int split_fit(const FitParams& pin, void* workspace, hipStream_t s) {
   Streams& st = streams_for_current_device();
   if (!st.ok) {
-    set_err("la3d split engine: could not create internal streams/events");
+    snprintf(g_err, sizeof(g_err), "la3d split engine: could not create internal streams/events (%s)", hipGetErrorString(st.err));
     return LA3D_ERR_HIP;
   }
   const int B = pin.B;
