@@ -163,3 +163,37 @@ def test_config5_size_distribution(la, B):
     assert (rst == 0).all()
     np.testing.assert_allclose(got[:, :15], ref[:, :15], rtol=0, atol=1e-9)
     np.testing.assert_allclose(got[:, 15:], ref[:, 15:], rtol=0, atol=2e-2)
+
+
+def test_pipelined_batches_and_retaining_build_give_the_same_records(la, monkeypatch):
+    """Scheduling never shows in the records: (a) batches issued through fit_batches (two streams, launch order off) and
+    (b) the 128-VGPR retaining build (LA3D_RETAIN=1, depth tiles kept in registers / LDS between the passes) are bit-identical
+    to plain serial calls."""
+    import torch
+
+    import bench
+
+    dev = torch.device("cuda", 0)
+    monkeypatch.setenv("LA3D_ENGINE", "instance")
+    batches, want = [], []
+    for k in range(5):
+        depth, masks, K, _, _ = bench.make_inputs(700 + 100 * k, dev, 40 + k)
+        batches.append((depth, masks, K))
+        want.append(tuple(t.clone() for t in la.fit_instances(depth, masks, K)))
+    got = [tuple(t.clone() for t in r) for r in la.fit_batches(batches)]
+    assert len(got) == 5
+    for g, w in zip(got, want):
+        assert torch.equal(g[0], w[0]) and torch.equal(g[1], w[1]) and torch.equal(g[2], w[2])
+    monkeypatch.setenv("LA3D_RETAIN", "1")
+    for (depth, masks, K), w in zip(batches[:2], want[:2]):
+        b, s, a = la.fit_instances(depth, masks, K)
+        assert torch.equal(b, w[0]) and torch.equal(s, w[1]) and torch.equal(a, w[2])
+    # a batch with masks above the retained capacity (160 tiles per instance) and a non-finite depth (checked re-run)
+    depth, masks, K, _, _ = bench.make_config5(600, dev, 9)
+    depth[3, 200, 300] = float("inf")
+    masks[3, 190:260, 280:400] = 1
+    monkeypatch.delenv("LA3D_RETAIN")
+    w = la.fit_instances(depth, masks, K)
+    monkeypatch.setenv("LA3D_RETAIN", "1")
+    g = la.fit_instances(depth, masks, K)
+    assert torch.equal(g[0], w[0]) and torch.equal(g[1], w[1])
