@@ -461,6 +461,13 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : NT / 64) void fit_instance
 #define LA3D_STAMP(k) do { } while (0)
 #endif
   LA3D_STAMP(0);
+  if (RET > 0 && SRC == 0 && p.stagger_ticks > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+    // retaining build, two workgroups per CU: the second-dispatched one (block b + 256 shares CU b % 256 with block b - measured
+    // placement, speed only) holds back for about the time the first needs to stream its mask plane at full bandwidth, so that
+    // the two run half a period apart: one streams while the other is in its passes (register-resident pass B moves no bytes)
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (unsigned long long)p.stagger_ticks) __builtin_amdgcn_s_sleep(32);
+  }
   // ---- phase 0: u8 mask plane -> bit image in LDS --------------------------------------
   int nmask = 0;
   if (LDSMASK && RLE) {
@@ -1905,12 +1912,20 @@ int launch_fit(const FitParams& p, size_t lds, hipStream_t s, void* workspace = 
 #ifndef LA3D_RET
 #define LA3D_RET 4
 #endif
-inline int retain_steps() {
-  // measurement switch: LA3D_RETAIN=1 selects the 128-VGPR build that keeps up to 160 depth tiles
-  // per instance on chip between the passes.  It moves 15-20 % fewer bytes and is NOT faster (two workgroups per CU instead
-  // of four), so the default is the 64-VGPR build.
+inline int retain_steps(int B) {
+  // The 128-VGPR build keeps up to 160 depth tiles per instance on chip between the passes: two
+  // workgroups per CU instead of four, the second one of every CU staggered by the time a mask plane takes to stream.
+  // Measured (u8 planes, us per call, retaining vs plain build): config-2 masks B = 384 / 512 / 768 / 1024 / 1280: 78 / 82 / 91 /
+  // 108 / 128 vs 86 / 91 / 100 / 111 / 131; config-5 masks B = 512 / 768 / 1024 / 1280: 84 / 86 / 90 / 110 vs 95 / 101 / 110 / 116;
+  // beyond ~1.5 k instances the plain build's four workgroups per CU win (10 % at B >= 2048).  LA3D_RETAIN=0 / 1 pins the
+  // choice, LA3D_RETAIN_MAXB moves the threshold.
   const char* e = getenv("LA3D_RETAIN");
-  return (e && atoi(e) > 0) ? LA3D_RET : 0;
+  if (e) return atoi(e) > 0 ? LA3D_RET : 0;
+  // a caller that has switched the launch order off is pipelining batches on several streams (la3d_set_launch_order): that
+  // regime behaves like one large batch, where the plain build wins (81.6 vs 87.0 us per 1024-instance call)
+  if (!balance_enabled()) return 0;
+  const char* m = getenv("LA3D_RETAIN_MAXB");
+  return B <= (m ? atoi(m) : 1280) ? LA3D_RET : 0;
 }
 
 }  // namespace
@@ -2012,6 +2027,7 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   p.rcp_ntx = 1.0f;
   p.perm = nullptr;
   p.lds_keep_off = 0;
+  p.stagger_ticks = 0;
   const int bit_bytes = ((((p.HW + 15) / 16 + 1) / 2) * 4 + 15) & ~15;  // u16 per 16 px, padded to u32, 16-aligned
   const bool ldsmask = bit_bytes <= MAX_MASK_LDS;
   p.mask_lds_bytes = ldsmask ? bit_bytes : 0;
@@ -2053,7 +2069,7 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
     const long ntiles = (long)p.ntx * p.nty;
     const long want = ntiles < 256 ? ntiles : 256;
     long cap = 0;
-    const int ret = retain_steps();
+    const int ret = retain_steps(p.B);
     for (int wg_per_cu = ret > 0 ? 2 : 4; wg_per_cu >= 1 && cap < want; --wg_per_cu) {
       const long budget = (160 * 1024 / wg_per_cu) & ~15L;
       cap = (budget - (long)fixed) / 2;
@@ -2067,6 +2083,11 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
         const size_t keep_bytes = (size_t)NWAVE * LDS_KEEP_WAVE;
         const char* e = getenv("LA3D_LDSKEEP");
         if (!(e && e[0] == '0') && tot + keep_bytes <= 80 * 1024) { p.lds_keep_off = (int)tot; tot += keep_bytes; }
+        if (mask != nullptr && B > 256) {   // u8 planes: 256 workgroups stream 256 x H*W bytes at ~6 TB/s
+          double us = 0.9 * 256.0 * (double)p.HW / 6.0e6;
+          if (const char* d = getenv("LA3D_STAGGER_US")) us = atof(d);
+          p.stagger_ticks = (int)(us * 100.0);
+        }
         return launch_fit<true, true, false, true, LA3D_RET>(p, tot, s, workspace);
       }
       return launch_fit<true, true, false, true>(p, fixed + ((size_t)cap * 2 > poly_stage ? (size_t)cap * 2 : poly_stage), s, workspace);

@@ -323,6 +323,7 @@ struct FitParams {
   float rcp_ntx;       // TILED: 1 / ntx
   const int* perm;     // launch order: workgroup b fits instance perm[b] (nullptr: xcd_remap(b))
   int lds_keep_off;    // retaining build: byte offset in dynamic LDS of the per-wave kept step (0: none)
+  int stagger_ticks;   // retaining build: the second-dispatched workgroup of every CU starts this many 100 MHz ticks late (0: off)
   double* out;
   int* status;
   double* aux;

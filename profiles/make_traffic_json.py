@@ -23,7 +23,9 @@ def counter(text, kernel_prefix, name):
 
 def main(tag):
     text = open(os.path.join(ROOT, "gpurun_out", f"profile_{tag}.md")).read()
-    kern = "fit_instances_kernel<true, true, false, true, 0, 0>"
+    kern = "fit_instances_kernel<true, true, false, true, 0, 4>"   # B = 1024 takes the retaining build (RET = 4)
+    if kern not in text:
+        kern = "fit_instances_kernel<true, true, false, true, 0, 0>"
     rd, n = counter(text, kern, "TCC_EA0_RDREQ_sum")
     fs, _ = counter(text, kern, "FETCH_SIZE")
     ws, _ = counter(text, kern, "WRITE_SIZE")
@@ -31,8 +33,9 @@ def main(tag):
     avg = re.search(re.escape("| " + kern) + r" \| (\d+) \| \d+ \| (\d+) \|", text)
     read_b, write_b = int(rd * 128), int(ws * 1024)
     out = {
-        "kernel": "fit_instances_kernel<VEC=1,LDSMASK=1,SAMPLE=0,TILED=1,SRC=0,RET=0> (0/1-byte mask stream, fetch/compute tile steps, "
-                  "size-balanced launch order, optimistic passes)",
+        "kernel": kern + " = <VEC,LDSMASK,SAMPLE,TILED,SRC,RET> (0/1-byte mask stream, fetch/compute tile steps, size-balanced launch "
+                  "order, optimistic passes; RET=4: depth tiles of the first 5 steps per wave kept on chip for pass B, second workgroup "
+                  "of every CU staggered)",
         "hbm_bytes_per_launch": read_b + write_b,
         "read_bytes_per_launch": read_b,
         "write_bytes_per_launch": write_b,
