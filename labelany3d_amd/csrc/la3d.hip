@@ -468,6 +468,10 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : NT / 64) void fit_instance
     const unsigned long long t0 = wall_clock64();
     while (wall_clock64() - t0 < (unsigned long long)p.stagger_ticks) __builtin_amdgcn_s_sleep(32);
   }
+  // reference-subsample mode: this thread's drawn index, requested before the mask stream so that it is not a dependent
+  // round trip afterwards (unused when the mask turns out to have <= 500 pixels)
+  int my_draw = 0;
+  if (SAMPLE && tid < LA3D_NSAMPLE) my_draw = p.sample_idx[(long long)inst * LA3D_NSAMPLE + tid];
   // ---- phase 0: u8 mask plane -> bit image in LDS --------------------------------------
   int nmask = 0;
   if (LDSMASK && RLE) {
@@ -546,9 +550,21 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : NT / 64) void fit_instance
 #pragma unroll
   for (int i = 0; i < 9; ++i) Mg[i] = uniform_f64(sh->M[i]);
 
+  // reference-subsample mode: the reference subsamples when in_pc.shape[0] > 500 (src/util_3dbox.py:123) - needs N first.
+  // Sampled instances need no tile list (their 500 points are picked through the block prefix, which shares its LDS).
+  bool sampled = false;
+  int ntot = 0;
+  if (SAMPLE) {
+    const int wsum = wave_sum_i(nmask);
+    if (lane == 0) sh->nmask[wave] = wsum;
+    __syncthreads();
+    for (int w = 0; w < NWAVE; ++w) ntot += sh->nmask[w];
+    sampled = ntot > LA3D_NSAMPLE;
+  }
+
   // ---- active-tile list (deterministic two-pass compaction: count, prefix, write) ----------------
   int nactive = 0;
-  if (TILED) {
+  if (TILED && !sampled) {
     const int ntiles = p.ntx * p.nty, per = p.tiles_per_wave;
     const int tbeg = wave * per, tend = min(tbeg + per, ntiles);
     int base = 0;
@@ -632,47 +648,78 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : NT / 64) void fit_instance
   // sampled-point state (SAMPLE only): the point of this thread in the ground-aligned frame
   double px = 0, py = 0, pz = 0;
   bool pok = false;
-  bool sampled = false;
 
   if (SAMPLE) {
-    // the reference subsamples when in_pc.shape[0] > 500 (src/util_3dbox.py:123): needs N first
-    const int wsum = wave_sum_i(nmask);
-    if (lane == 0) sh->nmask[wave] = wsum;
-    __syncthreads();
-    int ntot = 0;
-    for (int w = 0; w < NWAVE; ++w) ntot += sh->nmask[w];
-    sampled = ntot > LA3D_NSAMPLE;
     if (sampled) {
-      // exclusive prefix of per-word popcounts: thread t owns words [t*per, t*per+per)
-      const int per = (p.nwords + NT - 1) / NT;
-      const int w0 = tid * per;
-      unsigned local = 0;
-      for (int i = 0; i < per; ++i)
-        if (w0 + i < p.nwords) local += __popc(bits[w0 + i]);
-      unsigned incl = local;
+      // exclusive prefix of the popcounts of 32-word blocks (1024 px): thread t owns block t.  One word of LDS per block
+      // keeps the workgroup at a quarter of the CU's LDS (four workgroups per CU, like the full-mask build).
+      const int nblk = (p.nwords + 31) >> 5;
+      unsigned run0 = 0;   // blocks of earlier rounds (frames above NT * 1024 px)
+      for (int b0 = 0; b0 < nblk; b0 += NT) {
+        const int blk = b0 + tid;
+        unsigned local = 0;
+        if (blk < nblk) {
+          const int w0 = blk << 5, wn = min(32, p.nwords - w0);
+          if (wn == 32) {
+            const uint4* q = reinterpret_cast<const uint4*>(bits + w0);
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const unsigned t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
+            for (int i = 0; i < 8; ++i) { const uint4 v = q[i]; local += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
+          } else {
+            for (int i = 0; i < wn; ++i) local += __popc(bits[w0 + i]);
+          }
+        }
+        unsigned incl = local;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const unsigned t = __shfl_up(incl, o);
+          if (lane >= o) incl += t;
+        }
+        if (lane == 63) sh->scan[wave] = incl;
+        __syncthreads();
+        unsigned base = run0, tot = 0;
+        for (int w = 0; w < NWAVE; ++w) { const unsigned c = sh->scan[w]; if (w < wave) base += c; tot += c; }
+        if (blk < nblk) prefix[blk] = base + incl - local;
+        run0 += tot;
+        __syncthreads();
       }
-      if (lane == 63) sh->scan[wave] = incl;
-      __syncthreads();
-      unsigned base = 0;
-      for (int w = 0; w < wave; ++w) base += sh->scan[w];
-      unsigned run = base + incl - local;
-      for (int i = 0; i < per; ++i)
-        if (w0 + i < p.nwords) { prefix[w0 + i] = run; run += __popc(bits[w0 + i]); }
-      __syncthreads();
       if (tid < LA3D_NSAMPLE) {
-        int r = p.sample_idx[(long long)inst * LA3D_NSAMPLE + tid];
+        int r = my_draw;
         r = r < 0 ? 0 : (r >= ntot ? ntot - 1 : r);
-        int lo = 0, hi = p.nwords - 1;
-        while (lo < hi) {  // last word whose exclusive prefix is <= r
+        int lo = 0, hi = nblk - 1;
+        while (lo < hi) {  // last block whose exclusive prefix is <= r
           const int mid = (lo + hi + 1) >> 1;
           if (prefix[mid] <= (unsigned)r) lo = mid; else hi = mid - 1;
         }
-        unsigned w = bits[lo];
-        for (int k = r - (int)prefix[lo]; k > 0; --k) w &= w - 1;  // drop k lowest set bits
+        int k = r - (int)prefix[lo];          // rank inside the block
+        lo <<= 5;
+        unsigned w = 0;
+        if (lo + 32 <= p.nwords) {
+          // the word of the block that holds set bit k: all 32 words read at once, then a register scan
+          uint4 q[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) q[i] = reinterpret_cast<const uint4*>(bits + lo)[i];
+          int sel = 0;
+          bool found = false;
+#pragma unroll
+          for (int i = 0; i < 32; ++i) {
+            const unsigned wi = (i & 3) == 0 ? q[i >> 2].x : (i & 3) == 1 ? q[i >> 2].y : (i & 3) == 2 ? q[i >> 2].z : q[i >> 2].w;
+            const int c = __popc(wi);
+            const bool here = !found && k < c;
+            if (here) { w = wi; sel = i; }
+            found = found || here;
+            if (!found) k -= c;
+          }
+          lo += sel;
+        } else {
+          const int wend = p.nwords - 1;
+          for (; lo < wend; ++lo) {
+            const int c = __popc(bits[lo]);
+            if (k < c) break;
+            k -= c;
+          }
+          w = bits[lo];
+        }
+        for (; k > 0; --k) w &= w - 1;  // drop k lowest set bits
         const unsigned i = (unsigned)lo * 32u + (unsigned)(__ffs((int)w) - 1);
         const float df = dpl[i];
         unsigned u, v;
@@ -2049,10 +2096,27 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
       snprintf(g_err, sizeof(g_err), "%s: reference-subsample mode needs the bit image in LDS (H*W <= 1048576)", who);
       return LA3D_ERR_UNSUPPORTED;
     }
-    lds += (size_t)p.nwords * 4 + 16 > poly_stage ? (size_t)p.nwords * 4 + 16 : poly_stage;
+    const size_t blocks = (size_t)((p.nwords + 31) / 32) * 4 + 16;   // one prefix word per 32-word block of the bit image
+    lds += blocks > poly_stage ? blocks : poly_stage;
     if (lds > 160 * 1024 - 256) {
       snprintf(g_err, sizeof(g_err), "%s: reference-subsample mode: frame too large for LDS", who);
       return LA3D_ERR_UNSUPPORTED;
+    }
+    if (vec && W % 32 == 0 && W / 32 <= 255 && (H + 7) / 8 <= 255) {
+      // masks of <= 500 px (not sampled) walk their active tiles; the list shares the LDS of the block prefix
+      p.ntx = W / 32; p.nty = (H + 7) / 8;
+      p.rcp_ntx = 1.0f / (float)p.ntx;
+      p.tiles_per_wave = (p.ntx * p.nty + NWAVE - 1) / NWAVE;
+      const size_t fixed = lds - (blocks > poly_stage ? blocks : poly_stage);
+      size_t budget = (160 * 1024 / 4) & ~(size_t)15;          // four workgroups per CU if the frame allows
+      while (budget < fixed + (blocks > 128 ? blocks : 128)) budget += 8 * 1024;
+      long cap = (long)(budget - fixed) / 2;
+      if (cap > (long)p.ntx * p.nty) cap = (long)p.ntx * p.nty;
+      if (cap >= 64 && budget <= 160 * 1024 - 256) {
+        p.list_cap = (int)cap;
+        const size_t tail = (size_t)cap * 2 > blocks ? (size_t)cap * 2 : blocks;
+        return launch_fit<true, true, true, true>(p, fixed + (tail > poly_stage ? tail : poly_stage), s);
+      }
     }
     return vec ? launch_fit<true, true, true>(p, lds, s) : launch_fit<false, true, true>(p, lds, s);
   }

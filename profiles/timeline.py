@@ -47,6 +47,12 @@ def one(B, sizes="bench"):
                                              C.c_void_p(st.cuda_stream)), "la3d_fit_instances_rle")
         f.run = run_rle
         sizes += " (run-length input)"
+    if os.environ.get("TL_SAMPLE"):  # reference-subsample mode (500 drawn points per mask above 500 px)
+        from labelany3d_amd import draw_sample_idx
+        si = torch.as_tensor(draw_sample_idx(masks.reshape(B, -1).sum(1, dtype=torch.int64), np.random.RandomState(5)), device=dev)
+        _run = f.run
+        f.run = lambda d, m, k: _run(d, m, k, sample_idx=si)
+        sizes += " (subsample mode)"
     for _ in range(5):
         f.run(depth, masks, K)
     torch.cuda.synchronize()
@@ -75,6 +81,7 @@ for B in [int(a) for a in sys.argv[1:]] or [16, 1024]:
 
 if os.environ.get("TL_DETAIL"):
     B = 1024
+    sizes = "detail"
     rs = np.random.RandomState(1234)
     depth = torch.rand((B, H, W), device=dev) * 9.5 + 0.5
     masks = torch.zeros((B, H, W), dtype=torch.uint8, device=dev)
@@ -83,6 +90,12 @@ if os.environ.get("TL_DETAIL"):
         r0, c0 = rs.randint(0, H - h + 1), rs.randint(0, W - w + 1)
         masks[i, r0:r0 + h, c0:c0 + w] = 1
     f = InstanceFitter(B, H, W, dev)
+    if os.environ.get("TL_SAMPLE"):  # reference-subsample mode (500 drawn points per mask above 500 px)
+        from labelany3d_amd import draw_sample_idx
+        si = torch.as_tensor(draw_sample_idx(masks.reshape(B, -1).sum(1, dtype=torch.int64), np.random.RandomState(5)), device=dev)
+        _run = f.run
+        f.run = lambda d, m, k: _run(d, m, k, sample_idx=si)
+        sizes += " (subsample mode)"
     for _ in range(5):
         f.run(depth, masks, K)
     torch.cuda.synchronize()

@@ -197,3 +197,62 @@ def test_pipelined_batches_and_retaining_build_give_the_same_records(la, monkeyp
     monkeypatch.setenv("LA3D_RETAIN", "1")
     g = la.fit_instances(depth, masks, K)
     assert torch.equal(g[0], w[0]) and torch.equal(g[1], w[1])
+
+
+def test_subsample_mode_on_config5_mix(la):
+    """Reference-subsample mode on the config-5 size mix: masks of <= 500 px are not sampled and walk their active tiles
+    (bit-identical to full-mask mode), larger ones pick their 500 drawn pixels through the block prefix of the bit image.
+    Also: a scattered mask with more active tiles than the list holds (dense walk), a non-finite depth under a small mask
+    (checked re-run), and a frame width that is not a multiple of 32 (the untiled instantiation)."""
+    import torch
+
+    import bench
+
+    dev = torch.device("cuda", 0)
+    B = 1024
+    depth, masks, K, _, _ = bench.make_config5(B, dev, 5)
+    masks[7] = 0
+    masks[7, ::9, ::41] = 1                      # 54 x 16 = 864 px scattered over 54 x 16 tiles -> sampled
+    masks[8] = 0
+    masks[8, 3::40, 5::64] = 1                   # 12 x 10 = 120 px, one per tile: not sampled, 120 active tiles
+    masks[9] = 0
+    masks[9, 200:210, 300:330] = 1               # 300 px with a NaN depth among them
+    depth[9, 205, 310] = float("nan")
+    counts = la.mask_counts(masks).cpu().numpy()
+    assert (counts <= 500).sum() > 200 and (counts > 500).sum() > 200
+    idx = la.draw_sample_idx(counts, np.random.RandomState(3))
+    os.environ["LA3D_ENGINE"] = "instance"
+    try:
+        bs, ss, as_ = la.fit_instances(depth, masks, K, sample_idx=idx)
+        bf, sf, af = la.fit_instances(depth, masks, K)
+    finally:
+        os.environ.pop("LA3D_ENGINE", None)
+    small = torch.as_tensor(counts <= 500, device=dev)
+    assert torch.equal(bs[small], bf[small]) and torch.equal(ss[small], sf[small]) and torch.equal(as_[small], af[small])
+    assert int((ss != 0).sum()) == 0
+    order = np.argsort(counts)
+    pick = np.unique(np.concatenate([[7, 8, 9], order[:4], order[-4:], order[:: B // 24]]))
+    d, m = depth[pick].cpu().numpy(), masks[pick].cpu().numpy().astype(bool)
+    ref, rst, _, rn = O.fit_instances(d, m, np.repeat(K640[None], len(pick), 0), sample_idx=idx[pick])
+    got = bs[pick].cpu().numpy()
+    assert (rst == 0).all()
+    np.testing.assert_allclose(got[:, :15], ref[:, :15], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(got[:, 15:], ref[:, 15:], rtol=0, atol=2e-2)
+    np.testing.assert_array_equal(as_[pick, 1].cpu().numpy(), rn)
+    # frame width 600 (not a multiple of 32): untiled sample-mode instantiation, same answer as the oracle
+    rs = np.random.RandomState(8)
+    Hs, Ws = 120, 600
+    d2 = rs.uniform(0.5, 10, (6, Hs, Ws)).astype(np.float32)
+    m2 = np.zeros((6, Hs, Ws), bool)
+    for i in range(6):
+        h, w = rs.randint(4, 100), rs.randint(4, 500)
+        r0, c0 = rs.randint(0, Hs - h + 1), rs.randint(0, Ws - w + 1)
+        m2[i, r0:r0 + h, c0:c0 + w] = True
+    m2[0] = False
+    m2[0, 10:20, 10:30] = True
+    K2 = np.array([[400.0, 0, 300], [0, 400.0, 60], [0, 0, 1]])
+    idx2 = la.draw_sample_idx(m2.reshape(6, -1).sum(1), np.random.RandomState(4))
+    b2, s2, _ = la.fit_instances(d2, m2, K2, sample_idx=idx2)
+    ref2, rst2, _, _ = O.fit_instances(d2, m2, K2, sample_idx=idx2)
+    assert (s2.cpu().numpy() == rst2).all()
+    np.testing.assert_allclose(b2.cpu().numpy()[:, :15], ref2[:, :15], rtol=0, atol=1e-9)
