@@ -477,7 +477,15 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : NT / 64) void fit_instance
   if (LDSMASK && RLE) {
     // masks arrive as COCO run lengths: decode straight into the LDS bit image — no u8 plane is ever read
     const long long o0 = p.rle_offsets[inst];
-    nmask = rle_to_bits<NT>(p.rle_counts + o0, (int)(p.rle_offsets[inst + 1] - o0), bits, p.nwords, p.H, p.W, sh->scan, tid);
+#ifdef LA3D_ABL_NO_DECODE   // measurement build: an empty bit image instead of the decode
+    for (int i = tid; i < p.nwords; i += NT) bits[i] = 0;
+    nmask = (int)(o0 & 0);
+    __syncthreads();
+#else
+    // (the block totals of the column scan borrow the LDS of the tile list, which is built afterwards)
+    nmask = rle_to_bits<NT>(p.rle_counts + o0, (int)(p.rle_offsets[inst + 1] - o0), bits, p.nwords, p.H, p.W, sh->scan, tid,
+                            reinterpret_cast<unsigned*>(smem + p.mask_lds_bytes + sizeof(Shared)), TILED ? p.list_cap / 2 : 0);
+#endif
   } else if (LDSMASK && SRC == 2) {
     // masks arrive as polygon parts (the reference's create_boolean_mask_from_polygon, src/util.py:386-400): rasterised with
     // cv2.fillPoly's rule straight into the LDS bit image; the side stage borrows the space of the tile list
@@ -1109,13 +1117,13 @@ __global__ __launch_bounds__(256) void mask_counts_kernel(const unsigned char* _
 // mask_utils.decode for a batch (reference src/util.py:367,401-402): run lengths -> u8 planes.  The runs are
 // painted into an LDS bit image (rle_to_bits) and expanded with coalesced 16-byte stores.
 __global__ __launch_bounds__(256) void rle_decode_kernel(const int* __restrict__ counts, const long long* __restrict__ offsets,
-                                                         int H, int W, int nwords, unsigned char* __restrict__ out) {
+                                                         int H, int W, int nwords, int scan_words, unsigned char* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned* bits = reinterpret_cast<unsigned*>(smem);
   unsigned* wtot = bits + nwords;
   const int tid = threadIdx.x;
   const long long o0 = offsets[blockIdx.x];
-  (void)rle_to_bits<256>(counts + o0, (int)(offsets[blockIdx.x + 1] - o0), bits, nwords, H, W, wtot, tid);
+  (void)rle_to_bits<256>(counts + o0, (int)(offsets[blockIdx.x + 1] - o0), bits, nwords, H, W, wtot, tid, wtot + 16, scan_words);
   const int HW = H * W;
   unsigned char* o = out + (long long)blockIdx.x * HW;
   const unsigned short* b16 = reinterpret_cast<const unsigned short*>(bits);
@@ -2133,7 +2141,7 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
     const long ntiles = (long)p.ntx * p.nty;
     const long want = ntiles < 256 ? ntiles : 256;
     long cap = 0;
-    const int ret = retain_steps(p.B);
+    const int ret = mask != nullptr ? retain_steps(p.B) : 0;   // u8 planes only: run-length / polygon input has no mask stream to stagger
     for (int wg_per_cu = ret > 0 ? 2 : 4; wg_per_cu >= 1 && cap < want; --wg_per_cu) {
       const long budget = (160 * 1024 / wg_per_cu) & ~15L;
       cap = (budget - (long)fixed) / 2;
@@ -2226,10 +2234,16 @@ int la3d_rle_decode(const int32_t* counts, const int64_t* offsets, int B, int H,
   }
   if (B == 0) return LA3D_SUCCESS;
   const int nwords = (H * W + 31) / 32;
-  const size_t lds = (size_t)nwords * 4 + 64;
+  // behind the bit image: 16 words of wave totals, then the block totals of the column scan (word-aligned rows)
+  const int scan_words = (W % 32 == 0) ? ((256 / (W / 32) > 2 ? 256 / (W / 32) : 2) * (W / 32)) : 0;
+  const size_t lds = (size_t)nwords * 4 + 64 + (size_t)scan_words * 4;
+  if (lds > 160 * 1024 - 256) {
+    set_err("la3d_rle_decode: frame too large for LDS");
+    return LA3D_ERR_UNSUPPORTED;
+  }
   allow_big_lds(reinterpret_cast<const void*>(rle_decode_kernel));
   hipLaunchKernelGGL(rle_decode_kernel, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), counts,
-                     reinterpret_cast<const long long*>(offsets), H, W, nwords, mask_out);
+                     reinterpret_cast<const long long*>(offsets), H, W, nwords, scan_words, mask_out);
   return check_launch("rle_decode_kernel");
 }
 

@@ -402,9 +402,43 @@ __device__ inline void quad_math(unsigned nib, const unsigned* db, double r0, do
 // other (start / length broadcast by shuffle; lanes = consecutive pixels of the run = consecutive rows =
 // distinct words of the row-major image).  wtot: LDS, NTH/64 words.  Returns (per thread) the number of
 // mask pixels it accounted for; bits must hold ceil(H*W/32) words and is zeroed here.
+// Column-wise inclusive XOR scan down the rows of a word-aligned bit image (ntx words per row): after it, bit (r, c) is the
+// parity of the toggles at rows <= r of column c.  NTH threads split every word column into RB row blocks (block totals go
+// through `scratch`, RB * ntx words); each word is read twice and written once, whatever the number of runs.
+template <int NTH>
+__device__ inline void column_xor_scan(unsigned* bits, int H, int ntx, unsigned* scratch, int scratch_words, int tid) {
+  int RB = NTH / ntx;
+  if (RB > scratch_words / ntx) RB = scratch_words / ntx;
+  if (RB < 1) RB = 1;
+  const int RPB = (H + RB - 1) / RB;
+  const int items = ntx * RB;
+  if (RB > 1) {
+    for (int it = tid; it < items; it += NTH) {
+      const int blk = it / ntx, cw = it - blk * ntx;
+      const int r1 = min(blk * RPB + RPB, H);
+      unsigned x = 0;
+      for (int r = blk * RPB; r < r1; ++r) x ^= bits[r * ntx + cw];
+      scratch[it] = x;
+    }
+    __syncthreads();
+  }
+  for (int it = tid; it < items; it += NTH) {
+    const int blk = it / ntx, cw = it - blk * ntx;
+    const int r1 = min(blk * RPB + RPB, H);
+    unsigned carry = 0;
+    for (int b2 = 0; b2 < blk; ++b2) carry ^= scratch[b2 * ntx + cw];
+    for (int r = blk * RPB; r < r1; ++r) {
+      carry ^= bits[r * ntx + cw];
+      bits[r * ntx + cw] = carry;
+    }
+  }
+}
+
+// scratch / scratch_words: LDS for the block totals of the column scan (word-aligned rows); with less than 2 * (W / 32) words
+// the runs are painted directly instead (the slower route, also taken when W % 32 != 0).
 template <int NTH>
 __device__ inline int rle_to_bits(const int* __restrict__ counts, int nr, unsigned* bits, int nwords, int H, int W,
-                                  unsigned* wtot, int tid) {
+                                  unsigned* wtot, int tid, unsigned* scratch = nullptr, int scratch_words = 0) {
   const int lane = tid & 63, wave = tid >> 6;
   constexpr int NW = NTH / 64;
   const int HW = H * W;
@@ -412,6 +446,7 @@ __device__ inline int rle_to_bits(const int* __restrict__ counts, int nr, unsign
   for (int i = tid; i < nwords; i += NTH) bits[i] = 0;
   unsigned carry = 0;
   int nm = 0;
+  const bool toggles = (W & 31) == 0 && scratch != nullptr && scratch_words >= 2 * (W >> 5);   // uniform
   for (int c0 = 0; c0 < nr; c0 += NTH) {
     const int j = c0 + tid;
     unsigned len = 0;
@@ -433,7 +468,36 @@ __device__ inline int rle_to_bits(const int* __restrict__ counts, int nr, unsign
     nm += (int)L;
     carry += total;
     unsigned long long todo = __ballot(L != 0);
-    if ((W & 31) == 0) {
+    if (toggles) {
+      // Word-aligned rows, toggle form: a run is the set of pixels between two toggles of the column-major order.  Every lane
+      // marks the start of its own run and the pixel after its end (two ds_xor per run, all runs of the wave at once); a run
+      // that crosses into further columns also toggles row 0 of each of them.  column_xor_scan() below turns the toggles
+      // into the filled image.
+      const int ntx = W >> 5;
+      unsigned long long wrap = 0;
+      unsigned c_first = 0, c_last = 0;
+      if (L != 0) {
+        unsigned col0, row0, cole, rowe;
+        pix_uv(start, H, rcpH, &row0, &col0);
+        pix_uv(start + L, H, rcpH, &rowe, &cole);   // one past the run
+        atomicXor(&bits[row0 * ntx + (col0 >> 5)], 1u << (col0 & 31));
+        if (rowe != 0) atomicXor(&bits[rowe * ntx + (cole >> 5)], 1u << (cole & 31));
+        c_first = col0 + 1;
+        c_last = rowe != 0 ? cole : cole - 1;        // column of the run's last pixel
+      }
+      wrap = __ballot(L != 0 && c_last >= c_first);
+      while (wrap) {                                 // wave-uniform, rare: runs longer than the rest of their column
+        const int src = __ffsll((long long)wrap) - 1;
+        wrap &= wrap - 1;
+        const unsigned cf = (unsigned)__builtin_amdgcn_readlane((int)c_first, src);
+        const unsigned cl = (unsigned)__builtin_amdgcn_readlane((int)c_last, src);
+        for (unsigned cw = (cf >> 5) + lane; cw <= (cl >> 5); cw += 64) {   // row 0 of columns cf..cl, one word per lane
+          const unsigned lo = cw == (cf >> 5) ? (cf & 31u) : 0u, hi = cw == (cl >> 5) ? (cl & 31u) : 31u;
+          atomicXor(&bits[cw], (0xffffffffu >> (31u - hi)) & (0xffffffffu << lo));
+        }
+      }
+      todo = 0;
+    } else if ((W & 31) == 0) {
       // Word-aligned rows: runs that stay inside one column are painted 32 columns at a time.  All runs of this wave whose
       // column falls into the same 32-px word column form a group; lanes take rows, every run of the group is broadcast
       // (v_readlane) and contributes its column bit to the rows it covers: one ds_or per 64 rows and word column instead
@@ -501,6 +565,10 @@ __device__ inline int rle_to_bits(const int* __restrict__ counts, int nr, unsign
     if (carry >= (unsigned)HW) break;      // the frame is full: later runs fall outside it (uniform)
   }
   __syncthreads();
+  if (toggles) {
+    column_xor_scan<NTH>(bits, H, W >> 5, scratch, scratch_words, tid);
+    __syncthreads();
+  }
   return nm;
 }
 
