@@ -51,7 +51,15 @@ def test_rle_decode_and_filters_vs_reference(la, golden):
 @pytest.mark.parametrize("H,W", [(480, 640), (37, 53), (64, 96)])
 def test_rle_decode_random_masks(la, H, W):
     rs = np.random.RandomState(H + W)
-    masks = np.zeros((9, H, W), bool)
+    masks = np.zeros((12, H, W), bool)
+    # runs that continue through many columns (toggle form: row 0 of every crossed column), ending mid-column / at a column end
+    masks[9, :, 3:W - 5] = True
+    masks[9, :H // 3, 3] = False
+    masks[9, H // 2:, W - 6] = False
+    masks[10, :, 1:2 + W // 3] = True
+    masks[10, H - 1, 1] = False               # a one-pixel gap at the bottom of a column: two runs meet across the column end
+    masks[11, H - 1, :] = True                # one-pixel runs at the bottom of every column
+    masks[11, 0, ::2] = True                  # ... meeting one-pixel runs at the top of every other next column
     for i in range(5):
         h, w = rs.randint(1, H + 1), rs.randint(1, W + 1)
         r0, c0 = rs.randint(0, H - h + 1), rs.randint(0, W - w + 1)
