@@ -64,6 +64,29 @@ def unproject_matches(depth, uv, fx=560.44, fy=560.44, cx=256.0, cy=256.0, flip=
     return out, valid.bool()
 
 
+def correspondences_to_world(matches_im0, matches_im1, true_shape0, true_shape1, depth, T, R, image_size: int = 512):
+    """The geometry of ``ImageMatcher.get_correspondences`` after its network calls (reference src/matching/matcher.py:37-91):
+    keep matches at least 3 px inside both views (:38-55), shift them by the crop offset of the ``image_size`` square render
+    (``cy - int(3 * halfw / 4)`` rows, :58-64), drop those whose render depth is -1 (:69-75), unproject with the flipped pinhole
+    and the hard-coded intrinsics on the GPU (:77-86) and move them to world coordinates ``R (p - T)`` (:88-90).
+    Returns ``(points_world (N,3) float64, unprocessed_matches0 (N,2))`` as NumPy arrays, like the reference."""
+    m0, m1 = np.asarray(matches_im0), np.asarray(matches_im1)
+    (H0, W0), (H1, W1) = (int(v) for v in true_shape0), (int(v) for v in true_shape1)
+    ok = ((m0[:, 0] >= 3) & (m0[:, 0] < W0 - 3) & (m0[:, 1] >= 3) & (m0[:, 1] < H0 - 3) &
+          (m1[:, 0] >= 3) & (m1[:, 0] < W1 - 3) & (m1[:, 1] >= 3) & (m1[:, 1] < H1 - 3))
+    m0, m1 = m0[ok], m1[ok]
+    cx = cy = image_size // 2
+    halfw = ((2 * cx) // 16) * 8
+    off = np.array([0, cy - int(3 * halfw / 4)])
+    u0, u1 = m0 + off, m1 + off
+    if len(u1) == 0:
+        return np.zeros((0, 3)), u0
+    pts, valid = unproject_matches(depth, u1.astype(np.float64), flip=float(image_size), cx=float(cx), cy=float(cy),
+                                   R=np.asarray(R, dtype=np.float64).reshape(3, 3), T=np.asarray(T, dtype=np.float64).reshape(3))
+    valid = valid.cpu().numpy()
+    return pts.cpu().numpy()[valid], u0[valid]
+
+
 def hungarian_matching(boxes0, boxes1):
     """Reference hungarian_matching (:127-144): IoU matrix on the GPU, assignment with SciPy as in the reference.
     Returns [(index0, index1, iou), ...]."""

@@ -210,6 +210,30 @@ def test_unproject_matches_vs_numpy(la):
     np.testing.assert_allclose(np_(pts2)[ok][:, 2], d_of[ok])
 
 
+def test_correspondences_to_world_vs_reference(la):
+    """SURVEY §8f-4 pinned: tests/golden/g11_matcher.npz holds what the reference's ImageMatcher.get_correspondences
+    (src/matching/matcher.py:12-91) returned with its network / OpenCV calls replaced by stand-ins (make_golden_matcher.py): the
+    border filter, crop offset, depth filter, flipped unprojection and world transform are the reference's own code."""
+    import os
+    import sys
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, here)
+    try:
+        from make_golden_matcher import make_depth
+    finally:
+        sys.path.remove(here)
+    g = np.load(os.path.join(here, "g11_matcher.npz"))
+    for case in ("a", "b", "none"):
+        depth = make_depth(*g[f"{case}_depth_par"])
+        pw, um0 = la.correspondences_to_world(g[f"{case}_m0"], g[f"{case}_m1"], g[f"{case}_shape0"], g[f"{case}_shape1"], depth,
+                                              g[f"{case}_T"], g[f"{case}_R"])
+        assert pw.shape == g[f"{case}_points_world"].shape and pw.dtype == np.float64
+        np.testing.assert_array_equal(um0, g[f"{case}_matches0"])
+        np.testing.assert_allclose(pw, g[f"{case}_points_world"], rtol=1e-13, atol=1e-13)
+    assert len(g["a_points_world"]) > 100 and len(g["none_points_world"]) == 0
+
+
 # ------------------------------------------------------------------------------------------
 # the instance filter without a mask plane: stats from the run lengths, and the wide-load plane kernel
 # ------------------------------------------------------------------------------------------
