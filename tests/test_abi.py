@@ -209,3 +209,16 @@ def test_rle_string_host_helper_matches_oracle(golden):
     np.testing.assert_array_equal(c, g["counts"])
     with pytest.raises(ValueError):
         rle_from_string(b"P")              # 0x50 - 48 has the continuation bit set, then the string ends
+
+
+def test_omni3d_category_table_is_data():
+    """labelany3d_amd/data/omni3d_coco_categories.json: the 80 COCO names with the ids the reference's writer uses
+    (src/tools/combine_results.py:17-101); pure data, read without the GPU library."""
+    import json
+    import os
+
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "labelany3d_amd", "data", "omni3d_coco_categories.json")
+    cats = json.load(open(p))
+    assert len(cats) == 80 and len({c["id"] for c in cats}) == 80 and len({c["name"] for c in cats}) == 80
+    by = {c["name"]: c["id"] for c in cats}
+    assert by["person"] == 7 and by["car"] == 1 and by["teddy bear"] == 151 and all(set(c) == {"supercategory", "id", "name"} for c in cats)
