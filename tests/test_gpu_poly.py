@@ -216,3 +216,43 @@ def test_polygon_argument_errors(la):
         la.pack_polygons([[[1, 2, 3, 4]]])               # frame size is required
     polys = la.pack_polygons([], 48, 64)
     assert tuple(la.poly_decode(polys).shape) == (0, 48, 64)
+
+
+def test_the_reference_converters_own_polygons(la, monkeypatch):
+    """The polygon shapes of the reference's data: binary_mask_to_polygon (src/download_coconut.py:178-199) run on 20 masks
+    (tests/golden/make_golden_polygons.py): half-pixel float vertices, up to 596 parts / 5093 points per instance.  The HIP
+    rasteriser (decode, filter statistics, and inside the fit kernel) agrees with the fillPoly restatement bit for bit."""
+    from tests.test_oracle_poly import _converter_cases
+
+    by_size = {}
+    for H, W, mask, polys in _converter_cases():
+        by_size.setdefault((H, W), []).append(polys)
+    assert len(by_size) == 4
+    rs = np.random.RandomState(1)
+    for (H, W), segs in by_size.items():
+        packed = la.pack_polygons(segs, H, W)
+        got = np_(la.poly_decode(packed))
+        stats = np_(la.mask_stats_poly(packed))
+        want = []
+        for i, seg in enumerate(segs):
+            w, height = P.create_boolean_mask_from_polygon((W, H), seg)
+            want.append(w)
+            assert np.array_equal(got[i], w), (H, W, i, np.argwhere(got[i] != w)[:5])
+            assert tuple(stats[i]) == O.mask_stats(w) and stats[i][2] == height
+        depth = rs.uniform(0.5, 10, (len(segs), H, W)).astype(np.float32)
+        K = np.array([[0.8 * W, 0, W / 2], [0, 0.8 * W, H / 2], [0, 0, 1]])
+        b1, s1, a1 = la.fit_instances_poly(depth, packed, K)
+        # polygon input takes the plain build; pin it for the planes too: the 107 k-px blob has more active tiles (> 912) than the
+        # plain build's list holds and is walked densely there, which groups the partial sums differently from the retaining
+        # build's longer list (last-ulp differences; checked to rounding below)
+        monkeypatch.setenv("LA3D_RETAIN", "0")
+        with _instance_engine():
+            b2, s2, a2 = la.fit_instances(depth, np.stack(want), K)
+        monkeypatch.delenv("LA3D_RETAIN")
+        with _instance_engine():
+            b3, s3, _ = la.fit_instances(depth, np.stack(want), K)
+        np.testing.assert_array_equal(np_(s1), np_(s2))
+        np.testing.assert_array_equal(np_(b1), np_(b2))
+        np.testing.assert_array_equal(np_(a1)[:, 2], [w.sum() for w in want])
+        np.testing.assert_array_equal(np_(s1), np_(s3))
+        np.testing.assert_allclose(np_(b3)[:, :15], np_(b1)[:, :15], rtol=1e-12, atol=1e-12)

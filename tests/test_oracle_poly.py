@@ -149,3 +149,42 @@ def test_reference_truncation_of_float_vertices():
     assert (mask == ref).all() and height == 6
     with pytest.raises(ValueError):
         P.create_boolean_mask_from_polygon((64, 48), [[1, 2, 3]])   # odd number of coordinates: reshape fails
+
+
+def _converter_cases():
+    """tests/golden/g13_polygons.json.gz: masks + the polygons the reference's own converter (binary_mask_to_polygon,
+    src/download_coconut.py:178-199, run with scikit-image by make_golden_polygons.py) writes for them"""
+    import gzip
+    import json
+    import os
+
+    g = json.load(gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g13_polygons.json.gz"), "rt"))
+    for c in g["cases"]:
+        H, W = c["size"]
+        flat = np.zeros(H * W, bool)
+        pos = 0
+        for i, n in enumerate(c["counts"]):
+            if i & 1:
+                flat[pos:pos + n] = True
+            pos += n
+        yield H, W, flat.reshape(W, H).T, c["polygons"]
+
+
+def test_round_trip_through_the_reference_converter():
+    """mask -> the reference converter's polygons -> fillPoly restatement: the result stays within 3 px of the (hole-filled:
+    every part is filled with 1, so holes close, as in the reference) mask on both sides, and overlaps it like a tolerance-2
+    simplification should.  A wrong fill rule (shifted by a pixel, missing outline, inverted pairing) breaks these bounds."""
+    from scipy import ndimage
+
+    n = 0
+    for H, W, mask, polys in _converter_cases():
+        got, _ = P.create_boolean_mask_from_polygon((W, H), polys)
+        filled = ndimage.binary_fill_holes(mask)
+        core = ndimage.binary_erosion(filled, iterations=3)
+        halo = ndimage.binary_dilation(filled, iterations=3)
+        assert not (got & ~halo).any()
+        assert (core & ~got).sum() <= 0.002 * filled.sum()          # (parts of < 3 vertices are dropped by the converter)
+        iou = (got & filled).sum() / (got | filled).sum()
+        assert iou > (0.98 if len(polys) == 1 and filled.sum() > 10000 else 0.8), (H, W, len(polys), iou)   # thin / ragged shapes lose more
+        n += 1
+    assert n == 20
