@@ -247,6 +247,10 @@ def main():
     ap.add_argument("--rle", action="store_true",
                     help="feed the masks as COCO run lengths (la3d_fit_instances_rle) instead of u8 planes; NOT the "
                          "BASELINE config-2 input format, reported for the mask-ingestion row only")
+    ap.add_argument("--poly", action="store_true",
+                    help="feed the masks as polygon parts (la3d_fit_instances_poly: the reference's COCONut annotation format, "
+                         "rasterised with cv2.fillPoly's rule inside the fit kernel) instead of u8 planes: the rectangles as 4-vertex "
+                         "rings; NOT the BASELINE config-2 input format, reported for the mask-ingestion row only")
     ap.add_argument("--subsample", action="store_true",
                     help="secondary mode: the reference's own semantics for masks above 500 px - 500 points drawn with replacement "
                          "(np.random.randint, src/util_3dbox.py:123-125; indices drawn once outside the timed region, as the "
@@ -321,6 +325,30 @@ def main():
                                              C.c_void_p(st.cuda_stream)), "la3d_fit_instances_rle")
 
         fitter.run = lambda d, m, k, slot=0, stream=None, ws_slot=0: run_rle(slot, stream, ws_slot)
+
+    if args.poly:
+        import ctypes as C
+
+        if rects is None:
+            raise SystemExit("--poly needs the rectangle masks of the default workload (not --config3 / --config5)")
+        from labelany3d_amd import pack_polygons
+        from labelany3d_amd._lib import check, lib
+        r0_, c0_, hh_, ww_ = rects
+        segs = [[[int(b), int(a), int(b + w - 1), int(a), int(b + w - 1), int(a + h - 1), int(b), int(a + h - 1)]]
+                for a, b, h, w in zip(r0_, c0_, hh_, ww_)]
+        pxy, pro, pir, _, _ = pack_polygons(segs, H, W)
+        pxy, pro, pir = (torch.as_tensor(x, device=device) for x in (pxy, pro, pir))
+        kfull = K[None].expand(B, 3, 3).contiguous()
+
+        def run_poly(slot, st, ws_slot=0):
+            check(lib.la3d_fit_instances_poly(C.c_void_p(depth.data_ptr()), H * W, None, C.c_void_p(pxy.data_ptr()),
+                                              C.c_void_p(pro.data_ptr()), C.c_void_p(pir.data_ptr()), C.c_void_p(kfull.data_ptr()), 9,
+                                              None, None, B, H, W, C.c_void_p(fitter.boxes[slot].data_ptr()),
+                                              C.c_void_p(fitter.status[slot].data_ptr()), C.c_void_p(fitter.aux[slot].data_ptr()),
+                                              C.c_void_p(fitter.workspace[ws_slot].data_ptr()), C.c_void_p(st.cuda_stream)),
+                  "la3d_fit_instances_poly")
+
+        fitter.run = lambda d, m, k, slot=0, stream=None, ws_slot=0: run_poly(slot, stream, ws_slot)
 
     def barrier():
         torch.cuda.synchronize()
@@ -399,6 +427,8 @@ def main():
         req_bytes, active_tiles = required_bytes(masks, image_index, args.config3)
         if args.rle:
             req_bytes += int(rle_c.numel()) * 4 - B * H * W
+        if args.poly:
+            req_bytes += int(pxy.numel()) * 4 + int(pro.numel() + pir.numel()) * 8 - B * H * W
         if args.subsample:   # mask planes + one 64-B sector per drawn point (masks of <= 500 px: their tiles, as above) + records
             cnt = masks.reshape(B, -1).sum(1, dtype=torch.int64)
             big = cnt > 500
@@ -408,7 +438,7 @@ def main():
         achieved = req_bytes / step_s / 1e9
         traffic, traffic_src, traffic_stale = None, None, None
         tp = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
-        if os.path.exists(tp) and not (args.config3 or args.config5 or args.rle) and B == 1024:
+        if os.path.exists(tp) and not (args.config3 or args.config5 or args.rle or args.poly or args.subsample) and B == 1024:
             tj = json.load(open(tp))
             traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
             traffic_stale = tj.get("kernel_source_sha256") != kernel_source_sha256()
@@ -445,7 +475,8 @@ def main():
                 "mean_mask_occupancy": n_masked / (B * H * W),
                 "active_tiles_per_instance": active_tiles / B,
                 "sharding": "instances sharded per rank, one final RCCL gather of box records" if world > 1 else "single GPU",
-                "mask_input": "COCO run lengths (la3d_fit_instances_rle) — not the config-2 format" if args.rle else "u8 planes",
+                "mask_input": ("COCO run lengths (la3d_fit_instances_rle) — not the config-2 format" if args.rle else
+                               "polygon parts (la3d_fit_instances_poly), 4-vertex rings — not the config-2 format" if args.poly else "u8 planes"),
                 "streams": len(streams),
                 "default_steps": "1000 timed steps / 50 warm-up (0.11 s timed region); any --steps works",
             },
