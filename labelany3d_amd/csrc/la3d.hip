@@ -312,19 +312,20 @@ __device__ inline void stage_moments_to_axis(Shared* sh, const FitParams& p, int
     }
   }
   __syncthreads();
+  LA3D_SUBSTAMP(sh, 9);
   if (wave == 0) {
     // the NWAVE partials: one per lane, then a fixed xor tree over those lanes (bit-reproducible)
     double s[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) s[k] = lane < NWAVE ? sh->part[lane][k] : 0.0;
     int n = lane < NWAVE ? sh->cnt[lane] : 0, nm = lane < NWAVE ? sh->nmask[lane] : 0;
+    static_assert(NWAVE == 8, "the tree below combines lanes 0..7");
 #pragma unroll
-    for (int o = 1; o < NWAVE; o <<= 1) {
-#pragma unroll
-      for (int k = 0; k < 5; ++k) s[k] += __shfl_xor(s[k], o);
-      n += __shfl_xor(n, o);
-      nm += __shfl_xor(nm, o);
+    for (int k = 0; k < 5; ++k) {   // xor 1, xor 2, then the other quad of the first eight lanes: DPP moves, no LDS round trips
+      s[k] += dpp_f64<DPP_XOR1>(s[k]); s[k] += dpp_f64<DPP_XOR2>(s[k]); s[k] += dpp_f64<DPP_HALF_MIRROR>(s[k]);
     }
+    n += dpp_i32<DPP_XOR1>(n); n += dpp_i32<DPP_XOR2>(n); n += dpp_i32<DPP_HALF_MIRROR>(n);
+    nm += dpp_i32<DPP_XOR1>(nm); nm += dpp_i32<DPP_XOR2>(nm); nm += dpp_i32<DPP_HALF_MIRROR>(nm);
     if (lane == 0) {
     double gap = NAN;
     int st = LA3D_BOX_OK;
@@ -342,6 +343,7 @@ __device__ inline void stage_moments_to_axis(Shared* sh, const FitParams& p, int
     sh->nm = nm;
     }
   }
+  LA3D_SUBSTAMP(sh, 10);
   __syncthreads();
   if (sh->redo) return;  // uniform
   if (tid == 0 && sh->st != LA3D_BOX_OK) {  // rejected instance: the workgroup returns right after this call
@@ -377,6 +379,7 @@ __device__ inline void stage_extents_to_box(Shared* sh, const FitParams& p, int 
     }
   }
   __syncthreads();
+  LA3D_SUBSTAMP(sh, 11);
   if (wave == 0) {
     double lo[3], hi[3];
 #pragma unroll
@@ -385,17 +388,18 @@ __device__ inline void stage_extents_to_box(Shared* sh, const FitParams& p, int 
       hi[k] = lane < NWAVE ? sh->part[lane][2 * k + 1] : -INFINITY;
     }
 #pragma unroll
-    for (int o = 1; o < NWAVE; o <<= 1) {   // only the first NWAVE lanes hold data
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { lo[k] = fmin(lo[k], __shfl_xor(lo[k], o)); hi[k] = fmax(hi[k], __shfl_xor(hi[k], o)); }
+    for (int k = 0; k < 3; ++k) {   // only the first NWAVE (8) lanes hold data: xor 1, xor 2, other quad - DPP moves
+      lo[k] = fmin(lo[k], dpp_f64<DPP_XOR1>(lo[k])); lo[k] = fmin(lo[k], dpp_f64<DPP_XOR2>(lo[k])); lo[k] = fmin(lo[k], dpp_f64<DPP_HALF_MIRROR>(lo[k]));
+      hi[k] = fmax(hi[k], dpp_f64<DPP_XOR1>(hi[k])); hi[k] = fmax(hi[k], dpp_f64<DPP_XOR2>(hi[k])); hi[k] = fmax(hi[k], dpp_f64<DPP_HALF_MIRROR>(hi[k]));
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { lo[k] = __shfl(lo[k], 0); hi[k] = __shfl(hi[k], 0); }   // write_box_wave wants them in every lane
+    for (int k = 0; k < 3; ++k) { lo[k] = readlane_f64(lo[k], 0); hi[k] = readlane_f64(hi[k], 0); }   // write_box_wave wants them in every lane
     double Rg[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) Rg[i] = sh->Rg[i];
     write_box_wave(p.out + (long long)inst * LA3D_REC, Rg, sh->cyaw, sh->syaw, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], lane);
   }
+  LA3D_SUBSTAMP(sh, 12);
 }
 
 // rows 0 and 2 of rotate_y(yaw) @ M (reference :154) as wave-uniform SGPR values; row 1 is M's row 1
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : NT / 64) void fit_instance
   // into the workspace behind the launch-order arrays
   double* tl = p.geo + 1024 + (long long)inst * 16;
 #define LA3D_STAMP(k) do { if (tid == 0) tl[k] = (double)wall_clock64(); } while (0)
-  if (tid == 0) { tl[7] = (double)blockIdx.x; tl[8] = (double)t_entry; }
+  if (tid == 0) { tl[7] = (double)blockIdx.x; tl[8] = (double)t_entry; sh->tl = tl; }
 #else
 #define LA3D_STAMP(k) do { } while (0)
 #endif

@@ -225,25 +225,49 @@ __device__ inline void write_nan_box(double* out) {
 // ------------------------------------------------------------------------------------------
 // wave64 reductions (fixed butterfly order -> deterministic)
 // ------------------------------------------------------------------------------------------
+// Cross-lane steps are DPP moves (quad_perm xor 1 / xor 2, row_half_mirror, row_mirror: after them every lane of a 16-lane row holds
+// the row's result), the four rows are combined through v_readlane.  The same reductions written with __shfl_xor compile to
+// ds_bpermute_b32 chains the scheduler barely overlaps: 72 LDS round trips = 1.7 us per reduction stage of the fit kernel,
+// twice per instance (profiles/timeline.py, round 2).  All 64 lanes must be active.
+template <int CTRL>
+__device__ inline int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ inline double dpp_f64(double v) {
+  return __hiloint2double(dpp_i32<CTRL>(__double2hiint(v)), dpp_i32<CTRL>(__double2loint(v)));
+}
+__device__ inline double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+
 __device__ inline double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dpp_f64<DPP_XOR1>(v);
+  v += dpp_f64<DPP_XOR2>(v);
+  v += dpp_f64<DPP_HALF_MIRROR>(v);
+  v += dpp_f64<DPP_MIRROR>(v);
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 __device__ inline double wave_min(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
-  return v;
+  v = fmin(v, dpp_f64<DPP_XOR1>(v));
+  v = fmin(v, dpp_f64<DPP_XOR2>(v));
+  v = fmin(v, dpp_f64<DPP_HALF_MIRROR>(v));
+  v = fmin(v, dpp_f64<DPP_MIRROR>(v));
+  return fmin(fmin(readlane_f64(v, 0), readlane_f64(v, 16)), fmin(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 __device__ inline double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-  return v;
+  v = fmax(v, dpp_f64<DPP_XOR1>(v));
+  v = fmax(v, dpp_f64<DPP_XOR2>(v));
+  v = fmax(v, dpp_f64<DPP_HALF_MIRROR>(v));
+  v = fmax(v, dpp_f64<DPP_MIRROR>(v));
+  return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 __device__ inline int wave_sum_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dpp_i32<DPP_XOR1>(v);
+  v += dpp_i32<DPP_XOR2>(v);
+  v += dpp_i32<DPP_HALF_MIRROR>(v);
+  v += dpp_i32<DPP_MIRROR>(v);
+  return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) +
+         (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 }
 
 // wave-uniform double -> SGPR pair (the value is identical in every lane by construction)
@@ -348,7 +372,15 @@ struct alignas(16) Shared {
   double gap;      // relative eigenvalue gap (aux[3]), kept for the deferred aux write
   int nm;          // mask pixels (aux[2])
   int pad;
+#ifdef LA3D_TIMELINE
+  double* tl;      // measurement build: this workgroup's stamp row (profiles/timeline.py)
+#endif
 };
+#ifdef LA3D_TIMELINE
+#define LA3D_SUBSTAMP(sh, k) do { if (threadIdx.x == 0 && (sh)->tl) (sh)->tl[k] = (double)wall_clock64(); } while (0)
+#else
+#define LA3D_SUBSTAMP(sh, k) do { } while (0)
+#endif
 
 __device__ inline void pix_uv(unsigned i, int W, float rcpW, unsigned* u, unsigned* v) {
   unsigned vv = (unsigned)((float)i * rcpW);

@@ -47,6 +47,30 @@ def one(B, sizes="bench"):
                                              C.c_void_p(st.cuda_stream)), "la3d_fit_instances_rle")
         f.run = run_rle
         sizes += " (run-length input)"
+    if os.environ.get("TL_POLY"):  # same rectangles as 4-vertex polygon rings (la3d_fit_instances_poly)
+        import ctypes as C
+
+        from labelany3d_amd import pack_polygons
+        from labelany3d_amd._lib import check, lib
+        rs2 = np.random.RandomState(1234)
+        segs = []
+        for i in range(B):
+            h, w = (rs2.randint(8, 301), rs2.randint(8, 331)) if sizes == "bench" else (154, 169)
+            r0, c0 = rs2.randint(0, H - h + 1), rs2.randint(0, W - w + 1)
+            segs.append([[int(c0), int(r0), int(c0 + w - 1), int(r0), int(c0 + w - 1), int(r0 + h - 1), int(c0), int(r0 + h - 1)]])
+        pxy, pro, pir, _, _ = pack_polygons(segs, H, W)
+        pxy, pro, pir = (torch.as_tensor(x, device=dev) for x in (pxy, pro, pir))
+        kf = K[None].expand(B, 3, 3).contiguous()
+        st = torch.cuda.current_stream()
+
+        def run_poly(*_):
+            check(lib.la3d_fit_instances_poly(C.c_void_p(depth.data_ptr()), H * W, None, C.c_void_p(pxy.data_ptr()), C.c_void_p(pro.data_ptr()),
+                                              C.c_void_p(pir.data_ptr()), C.c_void_p(kf.data_ptr()), 9, None, None, B, H, W,
+                                              C.c_void_p(f.boxes[0].data_ptr()), C.c_void_p(f.status[0].data_ptr()),
+                                              C.c_void_p(f.aux[0].data_ptr()), C.c_void_p(f.workspace[0].data_ptr()),
+                                              C.c_void_p(st.cuda_stream)), "la3d_fit_instances_poly")
+        f.run = run_poly
+        sizes += " (polygon input)"
     if os.environ.get("TL_SAMPLE"):  # reference-subsample mode (500 drawn points per mask above 500 px)
         from labelany3d_amd import draw_sample_idx
         si = torch.as_tensor(draw_sample_idx(masks.reshape(B, -1).sum(1, dtype=torch.int64), np.random.RandomState(5)), device=dev)
@@ -70,6 +94,11 @@ def one(B, sizes="bench"):
     print(f"\n== B={B} sizes={sizes}: launch-relative times in us (min / mean / max over workgroups)")
     for k, n in enumerate(names):
         print(f"  {n:18s} {t[:, k].min():7.1f} {t[:, k].mean():7.1f} {t[:, k].max():7.1f}")
+    sub = (tl[:, 9:13] - t0) / 100.0           # finer stamps inside the two reduction stages (thread 0)
+    print("  reduction stages, mean us: pass A end (wave 0) -> all waves in %.2f -> axis computed %.2f -> released %.2f | "
+          "pass B end (wave 0) -> all waves in %.2f -> box written %.2f -> end %.2f" %
+          (np.mean(sub[:, 0] - t[:, 3]), np.mean(sub[:, 1] - sub[:, 0]), np.mean(t[:, 4] - sub[:, 1]),
+           np.mean(sub[:, 2] - t[:, 5]), np.mean(sub[:, 3] - sub[:, 2]), np.mean(t[:, 6] - sub[:, 3])))
     d = np.diff(t, axis=1)
     print("  durations: " + "  ".join(f"{n}={d[:, k].mean():.1f} (max {d[:, k].max():.1f})"
                                       for k, n in enumerate(["stream", "list", "passA", "axis", "passB", "box"])))
