@@ -271,8 +271,15 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # LA3D_BENCH_BACKEND=gloo: functional dry run of the multi-rank path with several ranks on ONE GPU (RCCL refuses that);
+        # the ranks then share device 0 and the three timing reductions go through the host.  Never a performance figure.
+        backend = os.environ.get("LA3D_BENCH_BACKEND", "nccl")
+        local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -280,6 +287,7 @@ def main():
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     device = torch.device("cuda", torch.cuda.current_device())
+    red_dev = device if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")   # where the timing scalars are reduced
 
     from labelany3d_amd import InstanceFitter
     from labelany3d_amd.shard import gather_boxes
@@ -399,15 +407,15 @@ def main():
                 fitter.run(depth, masks, K, slot=k, stream=s2[k % 2], ws_slot=k % 2)
             stream.wait_stream(s2[1])
             barrier()
-            pel = torch.tensor([time.perf_counter() - p0], dtype=torch.float64, device=device)
+            pel = torch.tensor([time.perf_counter() - p0], dtype=torch.float64, device=red_dev)
             if dist is not None:
                 dist.all_reduce(pel, op=dist.ReduceOp.MAX)
             pipelined = float(pel)
         finally:
             set_launch_order(None)
 
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device)
-    kern_ms = torch.tensor([ev0.elapsed_time(ev1) / steps], dtype=torch.float64, device=device)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=red_dev)
+    kern_ms = torch.tensor([ev0.elapsed_time(ev1) / steps], dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
         dist.all_reduce(kern_ms, op=dist.ReduceOp.MAX)
@@ -474,7 +482,9 @@ def main():
                 "frame": [H, W],
                 "mean_mask_occupancy": n_masked / (B * H * W),
                 "active_tiles_per_instance": active_tiles / B,
-                "sharding": "instances sharded per rank, one final RCCL gather of box records" if world > 1 else "single GPU",
+                "sharding": ("single GPU" if world == 1 else "instances sharded per rank, one final RCCL gather of box records"
+                             if dist.get_backend() == "nccl" else
+                             f"DRY RUN: {world} ranks sharing one GPU through {dist.get_backend()} (functional check of the multi-rank path, not a measurement)"),
                 "mask_input": ("COCO run lengths (la3d_fit_instances_rle) — not the config-2 format" if args.rle else
                                "polygon parts (la3d_fit_instances_poly), 4-vertex rings — not the config-2 format" if args.poly else "u8 planes"),
                 "streams": len(streams),

@@ -256,3 +256,30 @@ def test_subsample_mode_on_config5_mix(la):
     ref2, rst2, _, _ = O.fit_instances(d2, m2, K2, sample_idx=idx2)
     assert (s2.cpu().numpy() == rst2).all()
     np.testing.assert_allclose(b2.cpu().numpy()[:, :15], ref2[:, :15], rtol=0, atol=1e-9)
+
+
+def test_bench_multi_rank_path_two_ranks_one_gpu():
+    """bench.py's N > 1 path (barriers, max-over-ranks timing, the final gather of records, n_gpus / value aggregation), run as
+    the driver runs it (torch.distributed.run, one process per rank) with two ranks on this box's single GPU through gloo
+    (LA3D_BENCH_BACKEND=gloo; RCCL refuses two ranks on one device).  A functional check, not a measurement."""
+    import json
+    import subprocess
+    import sys
+
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LA3D_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--batch", "512", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["config"]["instances_per_gpu"] == 512
+    assert abs(d["value"] - 2 * 6 * 512 / (d["ms_per_step"] * 1e-3 * 6)) < 1e-6 * d["value"]     # whole-job aggregate over both ranks
+    assert "DRY RUN" in d["config"]["sharding"] and "cpu_baseline" not in d
+    assert 0 < d["roofline"]["frac"] < 1
