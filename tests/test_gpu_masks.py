@@ -48,7 +48,7 @@ def test_rle_decode_and_filters_vs_reference(la, golden):
     np.testing.assert_array_equal(st2, st)
 
 
-@pytest.mark.parametrize("H,W", [(480, 640), (37, 53), (64, 96)])
+@pytest.mark.parametrize("H,W", [(480, 640), (37, 53), (64, 96), (9, 4096), (270, 960), (1000, 1024)])
 def test_rle_decode_random_masks(la, H, W):
     rs = np.random.RandomState(H + W)
     masks = np.zeros((12, H, W), bool)
