@@ -10,13 +10,14 @@
 // DESIGN.md.  This file holds the INSTANCE ENGINE of la3d_fit_instances (one workgroup per instance; used for
 // B > 336, for run-length masks, for reference-subsample mode and for frames the split engine does not take —
 // la3d_split.hip is the other engine) and every other kernel of the C-ABI.  `fit_instances_kernel` in short:
-//   one 512-thread workgroup (8 wave64) per instance, 64 VGPRs / 40 KB LDS -> 4 workgroups per CU;
-//   phase 0  streams the u8 mask plane once with 16-byte non-temporal loads (or decodes COCO run lengths) into a
-//            1-bit-per-pixel image in LDS (38.4 KB for 640x480); meanwhile one lane computes K^-1, Rg, M;
+//   one 512-thread workgroup (8 wave64) per instance, 64 VGPRs / 40 KB LDS -> 4 workgroups per CU (the "retaining" build for
+//            u8 planes up to 1280 instances: 128 VGPRs, 2 workgroups per CU, depth tiles kept on chip between the passes);
+//   phase 0  streams the u8 mask plane once with 16-byte non-temporal loads (or decodes COCO run lengths / rasterises polygon
+//            parts) into a 1-bit-per-pixel image in LDS (38.4 KB for 640x480); meanwhile one lane computes K^-1, Rg, M;
 //   list     deterministic compaction of the 32 px x 8 row tiles that contain a set bit;
 //   pass A   4 listed tiles per wave-step, their float4 depth loads issued back to back; branch-free fp64
-//            accumulation of n, Sx, Sz, Sxx, Sxz, Szz -> wave butterfly -> LDS -> thread 0 (fixed order);
-//   yaw      closed-form 2x2 principal axis with scikit-learn's sign rule, no trigonometry (thread 0);
+//            accumulation of Sx, Sz, Sxx, Sxz, Szz -> DPP wave reduction -> LDS -> wave 0 (fixed order);
+//   yaw      closed-form 2x2 principal axis with scikit-learn's sign rule, no trigonometry (one lane);
 //   pass B   same walk, six extents in the yaw frame with NaN-ignoring raw v_min/v_max_f64;
 //   epilog   wave 0 writes center / dims / R_cam / fp16-quantised vertices, one lane per output group.
 #include <atomic>

@@ -430,10 +430,10 @@ __device__ inline void quad_math(unsigned nib, const unsigned* db, double r0, do
 // COCO run lengths -> row-major 1-bit-per-pixel image in LDS (the decode step of pycocotools' rleDecode,
 // called by the reference at src/util.py:367,401-402).  Runs are over the (H, W) mask in COLUMN-major order,
 // alternating zeros / ones, zeros first.  NTH threads take NTH runs per step: a workgroup scan of the run
-// lengths gives every run its start; then each wave paints the ones-runs of its own 64 lanes one after the
-// other (start / length broadcast by shuffle; lanes = consecutive pixels of the run = consecutive rows =
-// distinct words of the row-major image).  wtot: LDS, NTH/64 words.  Returns (per thread) the number of
-// mask pixels it accounted for; bits must hold ceil(H*W/32) words and is zeroed here.
+// lengths gives every run its start.  Word-aligned rows (W % 32 == 0, scratch given): toggle form - two ds_xor per run, then
+// one column-wise XOR scan of the image (column_xor_scan).  Otherwise each wave paints the ones-runs of its 64 lanes one
+// after the other, pixel by pixel (lanes = consecutive pixels of the run = consecutive rows).  wtot: LDS, NTH/64 words.
+// Returns (per thread) the number of mask pixels it accounted for; bits must hold ceil(H*W/32) words and is zeroed here.
 // Column-wise inclusive XOR scan down the rows of a word-aligned bit image (ntx words per row): after it, bit (r, c) is the
 // parity of the toggles at rows <= r of column c.  NTH threads split every word column into RB row blocks (block totals go
 // through `scratch`, RB * ntx words); each word is read twice and written once, whatever the number of runs.
@@ -529,49 +529,6 @@ __device__ inline int rle_to_bits(const int* __restrict__ counts, int nr, unsign
         }
       }
       todo = 0;
-    } else if ((W & 31) == 0) {
-      // Word-aligned rows: runs that stay inside one column are painted 32 columns at a time.  All runs of this wave whose
-      // column falls into the same 32-px word column form a group; lanes take rows, every run of the group is broadcast
-      // (v_readlane) and contributes its column bit to the rows it covers: one ds_or per 64 rows and word column instead
-      // of one per pixel.
-      const int ntx = W >> 5;
-      unsigned col0, row0;
-      pix_uv(start, H, rcpH, &row0, &col0);
-      const bool single = L != 0 && row0 + L <= (unsigned)H;
-      unsigned long long left = __ballot(single);
-      todo &= ~left;
-      while (left) {                       // wave-uniform loop over word columns
-        const int src = __ffsll((long long)left) - 1;
-        const int cw = (int)((unsigned)__builtin_amdgcn_readlane((int)col0, src) >> 5);
-        const unsigned long long grp = __ballot(single && (int)(col0 >> 5) == cw);
-        left &= ~grp;
-        int rmin = H, rmax = 0;
-        for (unsigned long long m = grp; m; m &= m - 1) {
-          const int k = __ffsll((long long)m) - 1;
-          const int a = __builtin_amdgcn_readlane((int)row0, k), b = a + __builtin_amdgcn_readlane((int)L, k);
-          rmin = min(rmin, a); rmax = max(rmax, b);
-        }
-        for (int wb = rmin; wb < rmax; wb += 512) {   // windows of 8 x 64 rows
-          const int nch = min(8, (rmax - wb + 63) >> 6);
-          unsigned wd[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-          for (unsigned long long m = grp; m; m &= m - 1) {
-            const int k = __ffsll((long long)m) - 1;
-            const int a = __builtin_amdgcn_readlane((int)row0, k), b = a + __builtin_amdgcn_readlane((int)L, k);
-            const unsigned bit = 1u << ((unsigned)__builtin_amdgcn_readlane((int)col0, k) & 31u);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-              if (c < nch) {                 // wave-uniform
-                const int row = wb + c * 64 + lane;
-                wd[c] |= (row >= a && row < b) ? bit : 0u;
-              }
-            }
-          }
-#pragma unroll
-          for (int c = 0; c < 8; ++c) {
-            if (c < nch && wd[c]) atomicOr(&bits[(wb + c * 64 + lane) * ntx + cw], wd[c]);
-          }
-        }
-      }
     }
     while (todo) {                         // wave-uniform loop over the remaining ones-runs (they wrap columns, or W % 32 != 0)
       const int src = __ffsll((long long)todo) - 1;
