@@ -45,6 +45,7 @@ extern "C" {
 #define LA3D_BOX_TOO_FEW 3    /* one valid point: scikit-learn PCA(2) ValueError (:183-184)              */
 #define LA3D_BOX_NONFINITE 4  /* +-inf coordinate reaches PCA: scikit-learn ValueError (:183-184)        */
 #define LA3D_BOX_UNSUPPORTED 5 /* convex_hull on more than 512 valid points (the reference feeds it <= 500)  */
+#define LA3D_BOX_FILTERED 6   /* dropped by the instance filter of the *_filtered entry points (src/util.py:375)        */
 
 /* yaw method (reference src/util_3dbox.py:146-151) */
 #define LA3D_METHOD_PCA 0
@@ -145,6 +146,24 @@ int la3d_fit_instances_poly(const float* depth, int64_t depth_plane_stride, cons
                             const int32_t* poly_xy, const int64_t* ring_offsets, const int64_t* inst_rings,
                             const double* K, int32_t k_stride, const double* ground, const int32_t* sample_idx,
                             int B, int H, int W, double* out, int32_t* status, double* aux, void* workspace, void* stream);
+
+/* ---- instance filter fused into the fit (reference read_bounding_boxes_segmentations, src/util.py:336-383) ----------
+ * The reference keeps an annotation when  height / H > 0.0625  and fewer than `max_edge` (10) mask pixels lie in the
+ * `boundary`-px (10) border strips  and  area >= `min_area` (100)  (:375; analyze_mask :291-326), with height = rows
+ * holding a pixel for RLE annotations (:368-369) and last row - first row + 1 for polygons (get_maximum_height,
+ * :328-335).  These entry points evaluate that rule on the bit image the fit kernel has just built - no second decode /
+ * rasterisation pass - write the four statistics (area, rows, span, edge; as la3d_mask_stats*) to stats (dev i32 [B][4],
+ * may be NULL) and fit only the kept instances; a dropped instance gets status LA3D_BOX_FILTERED and a NaN record. */
+int la3d_fit_instances_rle_filtered(const float* depth, int64_t depth_plane_stride, const int32_t* image_index,
+                                    const int32_t* rle_counts, const int64_t* rle_offsets, const double* K, int32_t k_stride,
+                                    const double* ground, const int32_t* sample_idx, int B, int H, int W, int boundary,
+                                    int min_area, int max_edge, double* out, int32_t* status, double* aux, int32_t* stats,
+                                    void* workspace, void* stream);
+int la3d_fit_instances_poly_filtered(const float* depth, int64_t depth_plane_stride, const int32_t* image_index,
+                                     const int32_t* poly_xy, const int64_t* ring_offsets, const int64_t* inst_rings,
+                                     const double* K, int32_t k_stride, const double* ground, const int32_t* sample_idx, int B,
+                                     int H, int W, int boundary, int min_area, int max_edge, double* out, int32_t* status,
+                                     double* aux, int32_t* stats, void* workspace, void* stream);
 
 /* create_boolean_mask_from_polygon for a batch: polygon parts -> u8 planes mask_out dev [B][H*W] (0/1). */
 int la3d_poly_decode(const int32_t* poly_xy, const int64_t* ring_offsets, const int64_t* inst_rings, int B, int H, int W,

@@ -559,6 +559,25 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : NT / 64) void fit_instance
   }
   __syncthreads();
   LA3D_STAMP(1);
+  if (SRC != 0 && LDSMASK && p.filter_boundary >= 0) {   // uniform
+    // the reference's instance filter (src/util.py:375) on the bit image just built: a dropped instance costs no passes
+    int st4[4];
+    bits_filter_stats<NT>(bits, p.H, p.W, p.filter_boundary, reinterpret_cast<int*>(sh->part), tid, st4);
+    if (p.filter_stats && tid < 4) p.filter_stats[(long long)inst * 4 + tid] = st4[tid];
+    const int height = SRC == 1 ? st4[1] : st4[2];   // run lengths: rows holding a pixel (:368-369); polygons: last - first + 1 (:328-335)
+    const bool keep = 16 * height > p.H && st4[3] < p.filter_max_edge && st4[0] >= p.filter_min_area;   // height / H > 0.0625
+    if (!keep) {
+      if (tid == 0) {
+        if (p.aux) {
+          double* a = p.aux + (long long)inst * LA3D_AUX;
+          a[0] = NAN; a[1] = 0.0; a[2] = (double)st4[0]; a[3] = NAN;
+        }
+        p.status[inst] = LA3D_BOX_FILTERED;
+        write_nan_box(p.out + (long long)inst * LA3D_REC);
+      }
+      return;
+    }
+  }
   double Mg[9];   // wave-uniform: moved to SGPRs
 #pragma unroll
   for (int i = 0; i < 9; ++i) Mg[i] = uniform_f64(sh->M[i]);
@@ -2052,12 +2071,13 @@ int la3d_mask_counts(const uint8_t* mask, int B, int H, int W, int32_t* counts, 
 }
 
 struct PolyArgs { const int32_t* xy; const int64_t* ring_off; const int64_t* inst_rings; };
+struct FilterArgs { int boundary, min_area, max_edge; int32_t* stats; };
 
 static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const int32_t* image_index, const uint8_t* mask,
                         const int32_t* rle_counts, const int64_t* rle_offsets, const double* K, int32_t k_stride,
                         const double* ground, const int32_t* sample_idx, int B, int H, int W, double* out,
                         int32_t* status, double* aux, void* workspace, void* stream, const char* who,
-                        const PolyArgs* poly = nullptr) {
+                        const PolyArgs* poly = nullptr, const FilterArgs* filter = nullptr) {
   const bool rle = rle_counts != nullptr || poly != nullptr;   // "no u8 plane": the mask is decoded into the LDS bit image
   if (!depth || (!mask && !rle) || (rle_counts && !rle_offsets) || (poly && (!poly->ring_off || !poly->inst_rings)) || !K ||
       !out || !status || B < 0 || H <= 0 || W <= 0 ||
@@ -2088,6 +2108,15 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   p.perm = nullptr;
   p.lds_keep_off = 0;
   p.stagger_ticks = 0;
+  p.filter_boundary = -1; p.filter_min_area = 0; p.filter_max_edge = 0; p.filter_stats = nullptr;
+  if (filter) {
+    if (!rle || filter->boundary < 0) {
+      snprintf(g_err, sizeof(g_err), "%s: the fused filter needs run-length or polygon masks and boundary >= 0", who);
+      return LA3D_ERR_ARG;
+    }
+    p.filter_boundary = filter->boundary; p.filter_min_area = filter->min_area; p.filter_max_edge = filter->max_edge;
+    p.filter_stats = filter->stats;
+  }
   const int bit_bytes = ((((p.HW + 15) / 16 + 1) / 2) * 4 + 15) & ~15;  // u16 per 16 px, padded to u32, 16-aligned
   const bool ldsmask = bit_bytes <= MAX_MASK_LDS;
   p.mask_lds_bytes = ldsmask ? bit_bytes : 0;
@@ -2206,6 +2235,35 @@ int la3d_fit_instances_poly(const float* depth, int64_t depth_plane_stride, cons
   const PolyArgs pa{poly_xy, ring_offsets, inst_rings};
   return fit_dispatch(depth, depth_plane_stride, image_index, nullptr, nullptr, nullptr, K, k_stride, ground, sample_idx, B, H, W,
                       out, status, aux, workspace, stream, "la3d_fit_instances_poly", &pa);
+}
+
+int la3d_fit_instances_rle_filtered(const float* depth, int64_t depth_plane_stride, const int32_t* image_index,
+                                    const int32_t* rle_counts, const int64_t* rle_offsets, const double* K, int32_t k_stride,
+                                    const double* ground, const int32_t* sample_idx, int B, int H, int W, int boundary,
+                                    int min_area, int max_edge, double* out, int32_t* status, double* aux, int32_t* stats,
+                                    void* workspace, void* stream) {
+  if (!rle_counts && B > 0) {
+    set_err("la3d_fit_instances_rle_filtered: bad argument");
+    return LA3D_ERR_ARG;
+  }
+  const FilterArgs fa{boundary, min_area, max_edge, stats};
+  return fit_dispatch(depth, depth_plane_stride, image_index, nullptr, rle_counts, rle_offsets, K, k_stride, ground, sample_idx, B,
+                      H, W, out, status, aux, workspace, stream, "la3d_fit_instances_rle_filtered", nullptr, &fa);
+}
+
+int la3d_fit_instances_poly_filtered(const float* depth, int64_t depth_plane_stride, const int32_t* image_index,
+                                     const int32_t* poly_xy, const int64_t* ring_offsets, const int64_t* inst_rings,
+                                     const double* K, int32_t k_stride, const double* ground, const int32_t* sample_idx, int B,
+                                     int H, int W, int boundary, int min_area, int max_edge, double* out, int32_t* status,
+                                     double* aux, int32_t* stats, void* workspace, void* stream) {
+  if ((!poly_xy || !ring_offsets || !inst_rings) && B > 0) {
+    set_err("la3d_fit_instances_poly_filtered: bad argument");
+    return LA3D_ERR_ARG;
+  }
+  const PolyArgs pa{poly_xy, ring_offsets, inst_rings};
+  const FilterArgs fa{boundary, min_area, max_edge, stats};
+  return fit_dispatch(depth, depth_plane_stride, image_index, nullptr, nullptr, nullptr, K, k_stride, ground, sample_idx, B, H, W,
+                      out, status, aux, workspace, stream, "la3d_fit_instances_poly_filtered", &pa, &fa);
 }
 
 int la3d_rle_from_string_host(const char* s, int64_t len, int32_t* counts, int cap) {

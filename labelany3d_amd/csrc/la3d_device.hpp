@@ -270,6 +270,53 @@ __device__ inline int wave_sum_i(int v) {
          (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 }
 
+__device__ inline int wave_min_i(int v) {
+  v = min(v, dpp_i32<DPP_XOR1>(v)); v = min(v, dpp_i32<DPP_XOR2>(v)); v = min(v, dpp_i32<DPP_HALF_MIRROR>(v)); v = min(v, dpp_i32<DPP_MIRROR>(v));
+  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ inline int wave_max_i(int v) {
+  v = max(v, dpp_i32<DPP_XOR1>(v)); v = max(v, dpp_i32<DPP_XOR2>(v)); v = max(v, dpp_i32<DPP_HALF_MIRROR>(v)); v = max(v, dpp_i32<DPP_MIRROR>(v));
+  return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+// The four quantities of the reference's instance filter (analyze_mask / get_maximum_height, src/util.py:291-335) from a
+// row-major bit image in LDS, by all NTH threads of the workgroup (threads over rows): out4 = area, rows holding a pixel,
+// last - first + 1, pixels inside the `boundary`-px border strips (a pixel in a corner counts twice, as the reference's
+// four slice sums do).  red: LDS, 5 * NTH/64 ints.  The result is valid in every thread; ends with a barrier.
+template <int NTH>
+__device__ inline void bits_filter_stats(const unsigned* bits, int H, int W, int boundary, int* red, int tid, int* out4) {
+  const int lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = NTH / 64;
+  const int bc = min(boundary, W), br = min(boundary, H);
+  int area = 0, edge = 0, rows = 0, first = H, last = -1;
+  for (int r = tid; r < H; r += NTH) {
+    int cnt = 0, e = 0;
+    const unsigned base = (unsigned)r * (unsigned)W;
+    for (int c0 = 0; c0 < W; c0 += 32) {       // 32 columns at a time (unaligned rows: the word is assembled from two)
+      const unsigned i = base + c0, wi = i >> 5, sh = i & 31;
+      unsigned w = bits[wi] >> sh;
+      if (sh && c0 + (32 - (int)sh) < W) w |= bits[wi + 1] << (32 - sh);
+      const int valid = min(32, W - c0);
+      if (valid < 32) w &= (1u << valid) - 1u;
+      cnt += __popc(w);
+      const int nlo = min(max(bc - c0, 0), 32), fhi = min(max(W - bc - c0, 0), 32);
+      e += __popc(nlo >= 32 ? w : (w & ((1u << nlo) - 1u))) + __popc(fhi >= 32 ? 0u : (w & ~((1u << fhi) - 1u)));
+    }
+    area += cnt;
+    edge += e + cnt * ((r < br ? 1 : 0) + (r >= H - br ? 1 : 0));
+    if (cnt != 0) { rows += 1; first = min(first, r); last = max(last, r); }
+  }
+  area = wave_sum_i(area); edge = wave_sum_i(edge); rows = wave_sum_i(rows);
+  first = wave_min_i(first); last = wave_max_i(last);
+  if (lane == 0) { red[wave] = area; red[NW + wave] = edge; red[2 * NW + wave] = rows; red[3 * NW + wave] = first; red[4 * NW + wave] = last; }
+  __syncthreads();
+  int a = 0, ed = 0, rw = 0, f = H, l = -1;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) { a += red[w]; ed += red[NW + w]; rw += red[2 * NW + w]; f = min(f, red[3 * NW + w]); l = max(l, red[4 * NW + w]); }
+  out4[0] = a; out4[1] = rw; out4[2] = (l >= f) ? l - f + 1 : 0; out4[3] = ed;
+  __syncthreads();
+}
+
 // wave-uniform double -> SGPR pair (the value is identical in every lane by construction)
 __device__ inline double uniform_f64(double v) {
   const unsigned lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
@@ -348,6 +395,9 @@ struct FitParams {
   const int* perm;     // launch order: workgroup b fits instance perm[b] (nullptr: xcd_remap(b))
   int lds_keep_off;    // retaining build: byte offset in dynamic LDS of the per-wave kept step (0: none)
   int stagger_ticks;   // retaining build: the second-dispatched workgroup of every CU starts this many 100 MHz ticks late (0: off)
+  // instance filter fused into the fit (run-length / polygon input): boundary < 0 = off
+  int filter_boundary, filter_min_area, filter_max_edge;
+  int* filter_stats;   // [B][4] area, rows, span, edge (may be null)
   double* out;
   int* status;
   double* aux;

@@ -200,6 +200,50 @@ def filter_annotations(annotations, image_size, boundary_threshold: int = 10, sc
             [annotations[i]["category_id"] for i in kept])
 
 
+def fit_annotations(annotations, image_size, depth, K, ground=None, boundary_threshold: int = 10, scale_threshold: int = 100,
+                    image_index=None, device=None):
+    """``read_bounding_boxes_segmentations`` (reference src/util.py:336-383) and the box fit in ONE pass over the annotations:
+    crowd annotations are skipped (:355-357); every other annotation's segmentation is decoded / rasterised once, inside the
+    fit launch, which also evaluates the keep rule (:375) on the bit image and fits only the kept instances (``filter=`` of
+    ``fit_instances_rle`` / ``fit_instances_poly``).  One launch per segmentation kind present.
+
+    depth / K / image_index as in ``fit_instances`` (image_index per ANNOTATION when depth holds several planes); ground: None
+    or (len(annotations), 4).  Returns ``(bboxes, kept_index, category_ids, boxes (n,39) f64, status (n,) i32)`` for the kept
+    annotations in annotation order, the last two on the GPU."""
+    W_img, H_img = int(image_size[0]), int(image_size[1])
+    dev = _dev(device)
+    groups = {"rle": ([], []), "poly": ([], [])}
+    for i, a in enumerate(annotations):
+        if a.get("iscrowd") or "segmentation" not in a:
+            continue
+        seg = a["segmentation"]
+        kind = "rle" if isinstance(seg, dict) and "counts" in seg else "poly"
+        groups[kind][0].append(i)
+        groups[kind][1].append({"size": seg["size"], "counts": seg["counts"]} if kind == "rle" else seg)
+    flt = {"boundary_threshold": boundary_threshold, "scale_threshold": scale_threshold}
+    idx_all, box_all, st_all = [], [], []
+    for kind, (idx, segs) in groups.items():
+        if not idx:
+            continue
+        sel = np.asarray(idx, np.int64)
+        g = None if ground is None else np.asarray(ground, dtype=np.float64)[sel]
+        ii = None if image_index is None else np.asarray(image_index)[sel]
+        if kind == "rle":
+            b, s, _, _ = fit_instances_rle(depth, segs, K, ground=g, image_index=ii, device=dev, filter=flt)
+        else:
+            b, s, _, _ = fit_instances_poly(depth, pack_polygons(segs, H_img, W_img), K, ground=g, image_index=ii, device=dev, filter=flt)
+        keep = (s != 6).cpu().numpy()
+        idx_all.append(sel[keep]); box_all.append(b[torch.as_tensor(keep, device=b.device)]); st_all.append(s[torch.as_tensor(keep, device=s.device)])
+    if not idx_all:
+        return [], np.zeros(0, np.int64), [], torch.zeros((0, 39), dtype=torch.float64, device=dev), torch.zeros(0, dtype=torch.int32, device=dev)
+    kept = np.concatenate(idx_all)
+    order = np.argsort(kept, kind="stable")
+    ot = torch.as_tensor(order, device=dev)
+    boxes, status = torch.cat(box_all)[ot], torch.cat(st_all)[ot]
+    kept = kept[order]
+    return ([annotations[i]["bbox"] for i in kept], kept, [annotations[i]["category_id"] for i in kept], boxes, status)
+
+
 def segmentations_to_masks(segmentations, H: int, W: int, device=None) -> torch.Tensor:
     """A list mixing RLE dicts and polygon part lists (what ``filter_annotations`` returns) -> (B,H,W) bool masks on the
     GPU in list order: the reference's ``np.array(segmentation_mask)`` (src/util.py:382)."""
@@ -214,24 +258,48 @@ def segmentations_to_masks(segmentations, H: int, W: int, device=None) -> torch.
     return out
 
 
-def fit_instances_poly(depth, polys, K, ground=None, sample_idx=None, image_index=None, stream=None, device=None):
+def _filter_args(filter):
+    """``filter`` of fit_instances_rle / fit_instances_poly: True or a dict with the reference's three thresholds
+    (src/util.py:291-326, :375): boundary strip width (10), minimum area (100), boundary pixels that make a mask "truncated" (10)."""
+    f = {} if filter is True else dict(filter)
+    unknown = set(f) - {"boundary_threshold", "scale_threshold", "truncation_pixels"}
+    if unknown:
+        raise ValueError(f"unknown filter keys: {sorted(unknown)}")
+    return int(f.get("boundary_threshold", 10)), int(f.get("scale_threshold", 100)), int(f.get("truncation_pixels", 10))
+
+
+def fit_instances_poly(depth, polys, K, ground=None, sample_idx=None, image_index=None, stream=None, device=None, filter=None):
     """fit_instances with polygon masks: the parts are rasterised inside the fit kernel, straight into its LDS bit image
     (cv2.fillPoly semantics, reference src/util.py:386-400).  Arguments and returns as ``labelany3d_amd.fit_instances``;
-    ``polys`` is the tuple from ``pack_polygons``."""
+    ``polys`` is the tuple from ``pack_polygons``.
+
+    ``filter=True`` (or a dict of thresholds, see ``_filter_args``) fuses the reference's instance filter (src/util.py:375, polygon
+    branch: height = last row - first row + 1) into the same launch: dropped instances get status 6 and a NaN record and cost no
+    passes; a fourth return value holds the (B,4) statistics (area, rows, span, edge pixels) as ``mask_stats_poly`` gives them."""
     dev = _dev(device)
     xy, ro, ir, H, W = _poly_dev(polys, dev)
     B = ir.numel() - 1
     d, k, P, ii, g, si = _fit_common(depth, K, H, W, B, ground, sample_idx, image_index, dev, "polygon")
+    stats = None
     with torch.cuda.device(dev):
         f = InstanceFitter(B, H, W, dev)
+        if filter:
+            stats = torch.zeros((B, 4), dtype=torch.int32, device=dev)
         if B == 0:
-            return f.boxes[0], f.status[0], f.aux[0]
-        rc = lib.la3d_fit_instances_poly(_ptr(d), H * W if P > 1 else 0, _ptr(ii), _ptr(xy), _ptr(ro), _ptr(ir), _ptr(k),
-                                         9 if k.shape[0] > 1 else 0, _ptr(g), _ptr(si), B, H, W, _ptr(f.boxes[0]),
-                                         _ptr(f.status[0]), _ptr(f.aux[0]), _ptr(f.workspace[0]), _stream(stream))
+            return (f.boxes[0], f.status[0], f.aux[0]) + ((stats,) if filter else ())
+        if filter:
+            b, a, e = _filter_args(filter)
+            rc = lib.la3d_fit_instances_poly_filtered(_ptr(d), H * W if P > 1 else 0, _ptr(ii), _ptr(xy), _ptr(ro), _ptr(ir), _ptr(k),
+                                                      9 if k.shape[0] > 1 else 0, _ptr(g), _ptr(si), B, H, W, b, a, e,
+                                                      _ptr(f.boxes[0]), _ptr(f.status[0]), _ptr(f.aux[0]), _ptr(stats),
+                                                      _ptr(f.workspace[0]), _stream(stream))
+        else:
+            rc = lib.la3d_fit_instances_poly(_ptr(d), H * W if P > 1 else 0, _ptr(ii), _ptr(xy), _ptr(ro), _ptr(ir), _ptr(k),
+                                             9 if k.shape[0] > 1 else 0, _ptr(g), _ptr(si), B, H, W, _ptr(f.boxes[0]),
+                                             _ptr(f.status[0]), _ptr(f.aux[0]), _ptr(f.workspace[0]), _stream(stream))
         check(rc, "la3d_fit_instances_poly")
-    _record(stream, d, k, ii, g, si, xy, ro, ir, f.workspace, f.boxes, f.status, f.aux)
-    return f.boxes[0], f.status[0], f.aux[0]
+    _record(stream, d, k, ii, g, si, xy, ro, ir, stats, f.workspace, f.boxes, f.status, f.aux)
+    return (f.boxes[0], f.status[0], f.aux[0]) + ((stats,) if filter else ())
 
 
 def _fit_common(depth, K, H, W, B, ground, sample_idx, image_index, dev, what):
@@ -254,25 +322,35 @@ def _fit_common(depth, K, H, W, B, ground, sample_idx, image_index, dev, what):
     return d, k, P, ii, g, si
 
 
-def fit_instances_rle(depth, rles, K, ground=None, sample_idx=None, image_index=None, stream=None, device=None):
+def fit_instances_rle(depth, rles, K, ground=None, sample_idx=None, image_index=None, stream=None, device=None, filter=None):
     """fit_instances with run-length masks: the runs are decoded inside the fit kernel, straight into its LDS
     bit image.  Arguments and returns as ``labelany3d_amd.fit_instances``; ``rles`` is a list of COCO RLE
-    objects or the tuple from ``pack_rle``."""
+    objects or the tuple from ``pack_rle``.  ``filter``: as in ``fit_instances_poly`` (RLE branch of the rule: height = rows
+    holding a pixel, src/util.py:368-369)."""
     counts, offsets, H, W = pack_rle(rles)
     dev = _dev(device)
     c, o = _as_dev(counts, torch.int32, dev), _as_dev(offsets, torch.int64, dev)
     B = o.numel() - 1
     d, k, P, ii, g, si = _fit_common(depth, K, H, W, B, ground, sample_idx, image_index, dev, "RLE")
+    stats = None
     with torch.cuda.device(dev):
         f = InstanceFitter(B, H, W, dev)
+        if filter:
+            stats = torch.zeros((B, 4), dtype=torch.int32, device=dev)
         if B == 0:
-            return f.boxes[0], f.status[0], f.aux[0]
-        rc = lib.la3d_fit_instances_rle(_ptr(d), H * W if P > 1 else 0, _ptr(ii), _ptr(c), _ptr(o), _ptr(k),
-                                        9 if k.shape[0] > 1 else 0, _ptr(g), _ptr(si), B, H, W, _ptr(f.boxes[0]),
-                                        _ptr(f.status[0]), _ptr(f.aux[0]), _ptr(f.workspace[0]), _stream(stream))
+            return (f.boxes[0], f.status[0], f.aux[0]) + ((stats,) if filter else ())
+        if filter:
+            b, a, e = _filter_args(filter)
+            rc = lib.la3d_fit_instances_rle_filtered(_ptr(d), H * W if P > 1 else 0, _ptr(ii), _ptr(c), _ptr(o), _ptr(k),
+                                                     9 if k.shape[0] > 1 else 0, _ptr(g), _ptr(si), B, H, W, b, a, e, _ptr(f.boxes[0]),
+                                                     _ptr(f.status[0]), _ptr(f.aux[0]), _ptr(stats), _ptr(f.workspace[0]), _stream(stream))
+        else:
+            rc = lib.la3d_fit_instances_rle(_ptr(d), H * W if P > 1 else 0, _ptr(ii), _ptr(c), _ptr(o), _ptr(k),
+                                            9 if k.shape[0] > 1 else 0, _ptr(g), _ptr(si), B, H, W, _ptr(f.boxes[0]),
+                                            _ptr(f.status[0]), _ptr(f.aux[0]), _ptr(f.workspace[0]), _stream(stream))
         check(rc, "la3d_fit_instances_rle")
-    _record(stream, d, k, ii, g, si, c, o, f.workspace, f.boxes, f.status, f.aux)
-    return f.boxes[0], f.status[0], f.aux[0]
+    _record(stream, d, k, ii, g, si, c, o, stats, f.workspace, f.boxes, f.status, f.aux)
+    return (f.boxes[0], f.status[0], f.aux[0]) + ((stats,) if filter else ())
 
 
 def masked_ratio_median(depth_map, depth_render, mask, render_mask=None, image_index=None, stream=None):

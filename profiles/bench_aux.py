@@ -89,6 +89,12 @@ def main():
         t = timed(lambda: la.fit_instances_poly(depth, dpolys, K), n=20)
         out[f"fit_instances_poly_1024_{name}"] = dict(s=t, boxes_per_s=Bm / t,
                                                        note="polygon parts rasterised inside the fit kernel; includes output allocation")
+        t = timed(lambda: la.fit_instances_poly(depth, dpolys, K, filter=True), n=20)
+        kept = int((la.fit_instances_poly(depth, dpolys, K, filter=True)[1] != 6).sum())
+        out[f"fit_instances_poly_filtered_1024_{name}"] = dict(
+            s=t, annotations_per_s=Bm / t, kept=kept,
+            note="the reference's instance filter (src/util.py:375) evaluated inside the fit launch; compare with "
+                 "mask_stats_poly + fit_instances_poly as two launches over the polygons")
     # masked depth-ratio median (align_to_depth_match): two u8 masks + two f32 planes per instance
     den = torch.rand((Bm, H, W), device="cuda") * 2.8 + 0.2
     mb = torch.rand((Bm, H, W), device="cuda") < 0.8

@@ -256,3 +256,91 @@ def test_the_reference_converters_own_polygons(la, monkeypatch):
         np.testing.assert_array_equal(np_(a1)[:, 2], [w.sum() for w in want])
         np.testing.assert_array_equal(np_(s1), np_(s3))
         np.testing.assert_allclose(np_(b3)[:, :15], np_(b1)[:, :15], rtol=1e-12, atol=1e-12)
+
+
+def test_fused_instance_filter_polygons_and_run_lengths(la):
+    """*_filtered entry points: the reference's keep rule (src/util.py:375) evaluated inside the fit launch on the bit image it has
+    just built.  The statistics equal mask_stats_poly / mask_stats_rle, the decisions equal the oracle's keep_instance (polygon
+    branch: span; RLE branch: rows), kept instances carry exactly the records of the unfiltered call, dropped ones status 6."""
+    rs = np.random.RandomState(21)
+    H, W = 480, 640
+    K = np.array([[500.0, 0, 320], [0, 500.0, 240], [0, 0, 1]])
+    segs = [_random_segmentation(rs, W, H, k % 8) for k in range(60)]
+    segs += [[[5, 5, 300, 5, 300, 200, 5, 200]],                   # touches the 10-px border strips: truncated
+             [[100, 100, 104, 100, 104, 400, 100, 400]],             # 5 px wide, tall: kept (area 1505)
+             [[100, 100, 400, 100, 400, 120, 100, 120]],             # 21 rows: 21 / 480 < 0.0625 -> dropped
+             [[100, 100, 400, 100, 400, 130, 100, 130]],             # 31 rows: kept
+             [[200, 200, 205, 200, 205, 205, 200, 205]],             # 36 px: below the area threshold
+             []]
+    B = len(segs)
+    depth = rs.uniform(0.5, 10, (B, H, W)).astype(np.float32)
+    polys = la.pack_polygons(segs, H, W)
+    b0, s0, a0 = la.fit_instances_poly(depth, polys, K)
+    b1, s1, a1, st = la.fit_instances_poly(depth, polys, K, filter=True)
+    want_stats = np_(la.mask_stats_poly(polys))
+    np.testing.assert_array_equal(np_(st), want_stats)
+    keep = np.array([O.keep_instance(tuple(r), H, False) for r in want_stats])
+    assert keep.sum() > 10 and (~keep).sum() > 10
+    assert keep[-5] and not keep[-4] and keep[-3] and not keep[-2] and not keep[-1] and not keep[-6]
+    np.testing.assert_array_equal(np_(s1)[keep], np_(s0)[keep])
+    np.testing.assert_array_equal(np_(b1)[keep], np_(b0)[keep])
+    np.testing.assert_array_equal(np_(a1)[keep], np_(a0)[keep])
+    assert (np_(s1)[~keep] == 6).all() and np.isnan(np_(b1)[~keep]).all()
+    np.testing.assert_array_equal(np_(a1)[~keep, 2], want_stats[~keep, 0])
+    # other thresholds
+    _, s2, _, _ = la.fit_instances_poly(depth, polys, K, filter={"scale_threshold": 2000, "truncation_pixels": 1, "boundary_threshold": 30})
+    st30 = np_(la.mask_stats_poly(polys, 30))
+    keep2 = (16 * st30[:, 2] > H) & (st30[:, 3] < 1) & (st30[:, 0] >= 2000)
+    np.testing.assert_array_equal(np_(s2) != 6, keep2)
+    with pytest.raises(ValueError, match="unknown filter keys"):
+        la.fit_instances_poly(depth, polys, K, filter={"area": 3})
+    # run lengths: same masks, RLE branch of the rule (rows holding a pixel)
+    masks = np_(la.poly_decode(polys))
+    rles = [O.rle_encode(m) for m in masks]
+    r0 = la.fit_instances_rle(depth, rles, K)
+    r1 = la.fit_instances_rle(depth, rles, K, filter=True)
+    want_r = np_(la.mask_stats_rle(rles))
+    np.testing.assert_array_equal(np_(r1[3]), want_r)
+    keep_r = np.array([O.keep_instance(tuple(r), H, True) for r in want_r])
+    np.testing.assert_array_equal(np_(r1[1]) != 6, keep_r)
+    np.testing.assert_array_equal(np_(r1[0])[keep_r], np_(r0[0])[keep_r])
+    # a frame whose rows are not word aligned
+    Hs, Ws = 120, 200
+    segs2 = [_random_segmentation(rs, Ws, Hs, k % 8) for k in range(24)]
+    p2 = la.pack_polygons(segs2, Hs, Ws)
+    d2 = rs.uniform(0.5, 10, (24, Hs, Ws)).astype(np.float32)
+    K2 = np.array([[150.0, 0, 100], [0, 150.0, 60], [0, 0, 1]])
+    _, s3, _, st3 = la.fit_instances_poly(d2, p2, K2, filter=True)
+    w3 = np_(la.mask_stats_poly(p2))
+    np.testing.assert_array_equal(np_(st3), w3)
+    np.testing.assert_array_equal(np_(s3) != 6, [O.keep_instance(tuple(r), Hs, False) for r in w3])
+
+
+def test_fit_annotations_one_pass(la):
+    """fit_annotations = filter_annotations + fit of the kept segmentations, with one decode per annotation (the filter is
+    evaluated inside the fit launch): same kept set, boxes, categories and records as the two-step route."""
+    rs = np.random.RandomState(33)
+    H, W = 240, 320
+    anns = []
+    for i in range(40):
+        seg = _random_segmentation(rs, W, H, i % 8)
+        a = {"iscrowd": int(i % 11 == 0), "bbox": [float(i), 1.0, 2.0, 3.0], "category_id": 1 + i % 5, "segmentation": seg}
+        if i % 3 == 0:      # every third annotation as an RLE of the same shape
+            m, _ = P.create_boolean_mask_from_polygon((W, H), seg)
+            a["segmentation"] = O.rle_encode(m)
+        anns.append(a)
+    anns.append({"iscrowd": 0, "bbox": [0, 0, 1, 1], "category_id": 9})     # no segmentation: skipped
+    depth = rs.uniform(0.5, 10, (H, W)).astype(np.float32)
+    K = np.array([[250.0, 0, 160], [0, 250.0, 120], [0, 0, 1]])
+    ground = np.array([[0.02, -0.97, 0.1, 1.0]] * len(anns)) + 0.02 * rs.randn(len(anns), 4)
+    bb, kept, cats, boxes, status = la.fit_annotations(anns, (W, H), depth, K, ground=ground)
+    bb0, segs0, kept0, cats0 = la.filter_annotations(anns, (W, H))
+    np.testing.assert_array_equal(kept, kept0)
+    assert bb == bb0 and cats == cats0 and len(kept) > 5
+    masks = la.segmentations_to_masks(segs0, H, W)
+    with _instance_engine():
+        b0, s0, _ = la.fit_instances(depth, masks, K, ground=ground[kept0])
+    np.testing.assert_array_equal(np_(status), np_(s0))
+    np.testing.assert_array_equal(np_(boxes), np_(b0))
+    out = la.fit_annotations([], (W, H), depth, K)
+    assert out[0] == [] and out[3].shape == (0, 39)
