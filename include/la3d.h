@@ -165,6 +165,30 @@ int la3d_fit_instances_poly_filtered(const float* depth, int64_t depth_plane_str
                                      int H, int W, int boundary, int min_area, int max_edge, double* out, int32_t* status,
                                      double* aux, int32_t* stats, void* workspace, void* stream);
 
+/* ---- one extensible entry: every option of the fit calls above, plus the 2-D boxes of the records -----------------
+ * Exactly one of mask / rle_counts(+rle_offsets) / poly_xy(+ring_offsets, inst_rings) gives the masks.  filter_boundary >= 0
+ * switches the fused instance filter on (run-length / polygon masks; see the *_filtered entry points).  proj != NULL adds
+ * la3d_project_boxes' output for every record - bbox2D_proj (4) and bbox2D_trunc (4), reference
+ * src/tools/combine_results.py:105-108, :238-252 - written by the same epilogue that writes the record (rejected / dropped
+ * instances: 8 NaNs); image_width / image_height are the clamp limits.  struct_size = sizeof(la3d_fit_args) of the caller:
+ * fields beyond it are taken as zero, so the struct can grow. */
+typedef struct la3d_fit_args {
+  int32_t struct_size;
+  int32_t B, H, W;
+  const float* depth; int64_t depth_plane_stride; const int32_t* image_index;
+  const uint8_t* mask;
+  const int32_t* rle_counts; const int64_t* rle_offsets;
+  const int32_t* poly_xy; const int64_t* ring_offsets; const int64_t* inst_rings;
+  const double* K; int32_t k_stride;
+  int32_t filter_boundary, filter_min_area, filter_max_edge;   /* filter_boundary < 0: no filter */
+  const double* ground; const int32_t* sample_idx;
+  int32_t* stats;                                              /* [B][4] | NULL (filter) */
+  double* proj; double image_width, image_height;              /* [B][8] | NULL */
+  double* out; int32_t* status; double* aux;
+  void* workspace; void* stream;
+} la3d_fit_args;
+int la3d_fit_instances_ex(const la3d_fit_args* args);
+
 /* create_boolean_mask_from_polygon for a batch: polygon parts -> u8 planes mask_out dev [B][H*W] (0/1). */
 int la3d_poly_decode(const int32_t* poly_xy, const int64_t* ring_offsets, const int64_t* inst_rings, int B, int H, int W,
                      uint8_t* mask_out, void* stream);

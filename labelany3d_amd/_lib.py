@@ -8,11 +8,28 @@ import os
 from ._build import HERE, INCLUDE, LIB, ROOT, SRC, build  # noqa: F401
 
 REC, AUX, NSAMPLE = 39, 4, 500
-BOX_OK, BOX_EMPTY, BOX_BAD_GROUND, BOX_TOO_FEW, BOX_NONFINITE, BOX_UNSUPPORTED = 0, 1, 2, 3, 4, 5
+BOX_OK, BOX_EMPTY, BOX_BAD_GROUND, BOX_TOO_FEW, BOX_NONFINITE, BOX_UNSUPPORTED, BOX_FILTERED = 0, 1, 2, 3, 4, 5, 6
 METHOD_PCA, METHOD_CONVEX_HULL = 0, 1
 ERR_UNSUPPORTED = -2
 
+class FitArgs(C.Structure):
+    """``la3d_fit_args`` of include/la3d.h (argument block of la3d_fit_instances_ex); field order is the header's."""
+    _fields_ = [("struct_size", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("depth", C.c_void_p), ("depth_plane_stride", C.c_int64), ("image_index", C.c_void_p),
+                ("mask", C.c_void_p),
+                ("rle_counts", C.c_void_p), ("rle_offsets", C.c_void_p),
+                ("poly_xy", C.c_void_p), ("ring_offsets", C.c_void_p), ("inst_rings", C.c_void_p),
+                ("K", C.c_void_p), ("k_stride", C.c_int32),
+                ("filter_boundary", C.c_int32), ("filter_min_area", C.c_int32), ("filter_max_edge", C.c_int32),
+                ("ground", C.c_void_p), ("sample_idx", C.c_void_p),
+                ("stats", C.c_void_p),
+                ("proj", C.c_void_p), ("image_width", C.c_double), ("image_height", C.c_double),
+                ("out", C.c_void_p), ("status", C.c_void_p), ("aux", C.c_void_p),
+                ("workspace", C.c_void_p), ("stream", C.c_void_p)]
+
+
 _SIGS = {
+    "la3d_fit_instances_ex": (C.c_int, [C.POINTER(FitArgs)]),
     "la3d_version": (C.c_int, []),
     "la3d_last_error": (C.c_char_p, []),
     "la3d_set_launch_order": (C.c_int, [C.c_int]),

@@ -21,6 +21,7 @@
 //   pass B   same walk, six extents in the yaw frame with NaN-ignoring raw v_min/v_max_f64;
 //   epilog   wave 0 writes center / dims / R_cam / fp16-quantised vertices, one lane per output group.
 #include <atomic>
+#include <cstddef>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -354,6 +355,7 @@ __device__ inline void stage_moments_to_axis(Shared* sh, const FitParams& p, int
     }
     p.status[inst] = sh->st;
     write_nan_box(p.out + (long long)inst * LA3D_REC);
+    if (p.proj) { for (int j = 0; j < 8; ++j) p.proj[(long long)inst * 8 + j] = NAN; }
   }
 }
 
@@ -398,7 +400,13 @@ __device__ inline void stage_extents_to_box(Shared* sh, const FitParams& p, int 
     double Rg[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) Rg[i] = sh->Rg[i];
-    write_box_wave(p.out + (long long)inst * LA3D_REC, Rg, sh->cyaw, sh->syaw, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], lane);
+    if (p.proj) {   // uniform: the 2-D boxes of the record in the same epilogue (la3d_fit_instances_ex)
+      const int img = p.image_index ? p.image_index[inst] : inst;
+      write_box_wave(p.out + (long long)inst * LA3D_REC, Rg, sh->cyaw, sh->syaw, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], lane,
+                     p.proj + (long long)inst * 8, p.K + (long long)img * p.k_stride, p.proj_w, p.proj_h);
+    } else {
+      write_box_wave(p.out + (long long)inst * LA3D_REC, Rg, sh->cyaw, sh->syaw, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], lane);
+    }
   }
   LA3D_SUBSTAMP(sh, 12);
 }
@@ -574,6 +582,7 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : NT / 64) void fit_instance
         }
         p.status[inst] = LA3D_BOX_FILTERED;
         write_nan_box(p.out + (long long)inst * LA3D_REC);
+        if (p.proj) { for (int j = 0; j < 8; ++j) p.proj[(long long)inst * 8 + j] = NAN; }
       }
       return;
     }
@@ -1431,9 +1440,8 @@ __global__ __launch_bounds__(128) void project_boxes_kernel(const double* __rest
   double lo[2] = {INFINITY, INFINITY}, hi[2] = {-INFINITY, -INFINITY};
   bool bad = false;
   for (int v = 0; v < 8; ++v) {
-    const double x = c[v * 3], y = c[v * 3 + 1], z = c[v * 3 + 2];
-    const double hx = k[0] * x + k[1] * y + k[2] * z, hy = k[3] * x + k[4] * y + k[5] * z, hz = k[6] * x + k[7] * y + k[8] * z;
-    const double px = hx / hz, py = hy / hz;            // (K @ P)[:2] / (K @ P)[2]
+    double px, py;
+    project_corner(k, c[v * 3], c[v * 3 + 1], c[v * 3 + 2], &px, &py);   // (K @ P)[:2] / (K @ P)[2]
     if (px != px || py != py) bad = true;              // Python's min()/max() over NaN are order dependent: report NaN
     lo[0] = fmin(lo[0], px); hi[0] = fmax(hi[0], px);
     lo[1] = fmin(lo[1], py); hi[1] = fmax(hi[1], py);
@@ -2072,12 +2080,13 @@ int la3d_mask_counts(const uint8_t* mask, int B, int H, int W, int32_t* counts, 
 
 struct PolyArgs { const int32_t* xy; const int64_t* ring_off; const int64_t* inst_rings; };
 struct FilterArgs { int boundary, min_area, max_edge; int32_t* stats; };
+struct ProjArgs { double* out; double width, height; };
 
 static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const int32_t* image_index, const uint8_t* mask,
                         const int32_t* rle_counts, const int64_t* rle_offsets, const double* K, int32_t k_stride,
                         const double* ground, const int32_t* sample_idx, int B, int H, int W, double* out,
                         int32_t* status, double* aux, void* workspace, void* stream, const char* who,
-                        const PolyArgs* poly = nullptr, const FilterArgs* filter = nullptr) {
+                        const PolyArgs* poly = nullptr, const FilterArgs* filter = nullptr, const ProjArgs* proj = nullptr) {
   const bool rle = rle_counts != nullptr || poly != nullptr;   // "no u8 plane": the mask is decoded into the LDS bit image
   if (!depth || (!mask && !rle) || (rle_counts && !rle_offsets) || (poly && (!poly->ring_off || !poly->inst_rings)) || !K ||
       !out || !status || B < 0 || H <= 0 || W <= 0 ||
@@ -2109,6 +2118,7 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   p.lds_keep_off = 0;
   p.stagger_ticks = 0;
   p.filter_boundary = -1; p.filter_min_area = 0; p.filter_max_edge = 0; p.filter_stats = nullptr;
+  p.proj = proj ? proj->out : nullptr; p.proj_w = proj ? proj->width : 0; p.proj_h = proj ? proj->height : 0;
   if (filter) {
     if (!rle || filter->boundary < 0) {
       snprintf(g_err, sizeof(g_err), "%s: the fused filter needs run-length or polygon masks and boundary >= 0", who);
@@ -2132,7 +2142,13 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   // polygons: the side stage sits behind Shared, where the tile list / rank prefix go later (disjoint in time)
   const size_t poly_stage = poly ? (size_t)POLY_STAGE_BYTES : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (!rle && split_eligible(p, vec, ldsmask)) return split_fit(p, workspace, s);
+  if (!rle && split_eligible(p, vec, ldsmask)) {
+    const int rc = split_fit(p, workspace, s);   // (the split engine's final kernel does not project: one small follow-up launch)
+    if (rc != LA3D_SUCCESS || !p.proj) return rc;
+    hipLaunchKernelGGL(project_boxes_kernel, dim3((B + 127) / 128), dim3(128), 0, s, out, K, k_stride, image_index, B, p.proj_w, p.proj_h,
+                       p.proj);
+    return check_launch("project_boxes_kernel");
+  }
   if (sample) {
     if (!ldsmask) {
       snprintf(g_err, sizeof(g_err), "%s: reference-subsample mode needs the bit image in LDS (H*W <= 1048576)", who);
@@ -2264,6 +2280,33 @@ int la3d_fit_instances_poly_filtered(const float* depth, int64_t depth_plane_str
   const FilterArgs fa{boundary, min_area, max_edge, stats};
   return fit_dispatch(depth, depth_plane_stride, image_index, nullptr, nullptr, nullptr, K, k_stride, ground, sample_idx, B, H, W,
                       out, status, aux, workspace, stream, "la3d_fit_instances_poly_filtered", &pa, &fa);
+}
+
+int la3d_fit_instances_ex(const la3d_fit_args* args) {
+  if (!args || args->struct_size < (int32_t)sizeof(la3d_fit_args)) {   // (a longer struct from a newer caller is fine)
+    set_err("la3d_fit_instances_ex: bad struct_size");
+    return LA3D_ERR_ARG;
+  }
+  const la3d_fit_args& a = *args;
+  const int kinds = (a.mask ? 1 : 0) + (a.rle_counts ? 1 : 0) + (a.poly_xy ? 1 : 0);
+  if (kinds != 1 && a.B > 0) {
+    set_err("la3d_fit_instances_ex: give exactly one of mask / rle_counts / poly_xy");
+    return LA3D_ERR_ARG;
+  }
+  if (a.poly_xy && (!a.ring_offsets || !a.inst_rings)) {
+    set_err("la3d_fit_instances_ex: polygon masks need ring_offsets and inst_rings");
+    return LA3D_ERR_ARG;
+  }
+  if (a.proj && !(a.image_width > 0 && a.image_height > 0)) {
+    set_err("la3d_fit_instances_ex: proj needs image_width / image_height > 0");
+    return LA3D_ERR_ARG;
+  }
+  const PolyArgs pa{a.poly_xy, a.ring_offsets, a.inst_rings};
+  const FilterArgs fa{a.filter_boundary, a.filter_min_area, a.filter_max_edge, a.stats};
+  const ProjArgs pr{a.proj, a.image_width, a.image_height};
+  return fit_dispatch(a.depth, a.depth_plane_stride, a.image_index, a.mask, a.rle_counts, a.rle_offsets, a.K, a.k_stride, a.ground,
+                      a.sample_idx, a.B, a.H, a.W, a.out, a.status, a.aux, a.workspace, a.stream, "la3d_fit_instances_ex",
+                      a.poly_xy ? &pa : nullptr, a.filter_boundary >= 0 ? &fa : nullptr, a.proj ? &pr : nullptr);
 }
 
 int la3d_rle_from_string_host(const char* s, int64_t len, int32_t* counts, int cap) {

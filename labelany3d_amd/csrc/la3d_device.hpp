@@ -189,8 +189,31 @@ __device__ inline void write_box(double* out, const double* Rg, double cyaw, dou
 // Same record, written by one wave: lanes 0..7 take one corner each, lane 8 center + dims, lanes 9..11 one
 // R_cam row each (the single-thread version is ~3000 dependent fp64 instructions, i.e. ~10 us of pure
 // latency when a whole kernel consists of it).  Bit-identical to write_box.
+// DPP cross-lane moves (see the wave reductions below)
+template <int CTRL>
+__device__ inline int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ inline double dpp_f64(double v) {
+  return __hiloint2double(dpp_i32<CTRL>(__double2hiint(v)), dpp_i32<CTRL>(__double2loint(v)));
+}
+__device__ inline double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+
+// one corner through the image's K: (K @ P)[:2] / (K @ P)[2]  (project_to_2d, reference src/tools/combine_results.py:105-108)
+__device__ inline void project_corner(const double* k, double x, double y, double z, double* px, double* py) {
+  const double hx = k[0] * x + k[1] * y + k[2] * z, hy = k[3] * x + k[4] * y + k[5] * z, hz = k[6] * x + k[7] * y + k[8] * z;
+  *px = hx / hz; *py = hy / hz;
+}
+
+// proj (optional, with the image's K and size): the record's 2-D boxes as la3d_project_boxes writes them - bbox2D_proj (4) and its
+// clamp to the frame (4) - from the corners this call has in registers (lanes 0..7; an 8-lane DPP min / max)
 __device__ inline void write_box_wave(double* out, const double* Rg, double cyaw, double syaw, double xmin, double xmax,
-                                      double ymin, double ymax, double zmin, double zmax, int lane) {
+                                      double ymin, double ymax, double zmin, double zmax, int lane,
+                                      double* proj = nullptr, const double* Kp = nullptr, double Wd = 0, double Hd = 0) {
+  double cpx = INFINITY, cpy = INFINITY, cqx = -INFINITY, cqy = -INFINITY;   // this lane's corner, projected
+  int cbad = 0;
   const double dx = xmax - xmin, dy = ymax - ymin, dz = zmax - zmin;
   const double c[3] = {(xmin + xmax) / 2, (ymin + ymax) / 2, (zmin + zmax) / 2};
   const double h[3] = {dx / 2, dy / 2, dz / 2};
@@ -202,7 +225,14 @@ __device__ inline void write_box_wave(double* out, const double* Rg, double cyaw
     double g[3], r[3];
     g[0] = f16_round(sx * h[0] + c[0]); g[1] = f16_round(sy * h[1] + c[1]); g[2] = f16_round(sz * h[2] + c[2]);
     for (int i = 0; i < 3; ++i) r[i] = Ry[i * 3] * g[0] + Ry[i * 3 + 1] * g[1] + Ry[i * 3 + 2] * g[2];
-    for (int i = 0; i < 3; ++i) out[15 + lane * 3 + i] = r[0] * Rg[i * 3] + r[1] * Rg[i * 3 + 1] + r[2] * Rg[i * 3 + 2];
+    double cv[3];
+    for (int i = 0; i < 3; ++i) { cv[i] = r[0] * Rg[i * 3] + r[1] * Rg[i * 3 + 1] + r[2] * Rg[i * 3 + 2]; out[15 + lane * 3 + i] = cv[i]; }
+    if (proj) {
+      double px, py;
+      project_corner(Kp, cv[0], cv[1], cv[2], &px, &py);
+      cbad = (px != px || py != py) ? 1 : 0;
+      cpx = cqx = px; cpy = cqy = py;
+    }
   } else if (lane == 8) {
     double w[3];
     for (int i = 0; i < 3; ++i) w[i] = Ry[i * 3] * c[0] + Ry[i * 3 + 1] * c[1] + Ry[i * 3 + 2] * c[2];
@@ -215,6 +245,20 @@ __device__ inline void write_box_wave(double* out, const double* Rg, double cyaw
 #pragma unroll
         for (int j = 0; j < 3; ++j) out[6 + i * 3 + j] = Rg[i] * Ry[j] + Rg[3 + i] * Ry[3 + j] + Rg[6 + i] * Ry[6 + j];
       }
+  }
+  if (proj) {   // uniform
+    cpx = fmin(cpx, dpp_f64<DPP_XOR1>(cpx)); cpx = fmin(cpx, dpp_f64<DPP_XOR2>(cpx)); cpx = fmin(cpx, dpp_f64<DPP_HALF_MIRROR>(cpx));
+    cpy = fmin(cpy, dpp_f64<DPP_XOR1>(cpy)); cpy = fmin(cpy, dpp_f64<DPP_XOR2>(cpy)); cpy = fmin(cpy, dpp_f64<DPP_HALF_MIRROR>(cpy));
+    cqx = fmax(cqx, dpp_f64<DPP_XOR1>(cqx)); cqx = fmax(cqx, dpp_f64<DPP_XOR2>(cqx)); cqx = fmax(cqx, dpp_f64<DPP_HALF_MIRROR>(cqx));
+    cqy = fmax(cqy, dpp_f64<DPP_XOR1>(cqy)); cqy = fmax(cqy, dpp_f64<DPP_XOR2>(cqy)); cqy = fmax(cqy, dpp_f64<DPP_HALF_MIRROR>(cqy));
+    cbad |= dpp_i32<DPP_XOR1>(cbad); cbad |= dpp_i32<DPP_XOR2>(cbad); cbad |= dpp_i32<DPP_HALF_MIRROR>(cbad);
+    if (lane == 0) {
+      if (cbad) { for (int j = 0; j < 8; ++j) proj[j] = NAN; }   // Python's min() / max() over NaN are order dependent: report NaN
+      else {
+        proj[0] = cpx; proj[1] = cpy; proj[2] = cqx; proj[3] = cqy;
+        proj[4] = fmax(0.0, cpx); proj[5] = fmax(0.0, cpy); proj[6] = fmin(Wd, cqx); proj[7] = fmin(Hd, cqy);
+      }
+    }
   }
 }
 
@@ -229,16 +273,6 @@ __device__ inline void write_nan_box(double* out) {
 // the row's result), the four rows are combined through v_readlane.  The same reductions written with __shfl_xor compile to
 // ds_bpermute_b32 chains the scheduler barely overlaps: 72 LDS round trips = 1.7 us per reduction stage of the fit kernel,
 // twice per instance (profiles/timeline.py, round 2).  All 64 lanes must be active.
-template <int CTRL>
-__device__ inline int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
-template <int CTRL>
-__device__ inline double dpp_f64(double v) {
-  return __hiloint2double(dpp_i32<CTRL>(__double2hiint(v)), dpp_i32<CTRL>(__double2loint(v)));
-}
-__device__ inline double readlane_f64(double v, int l) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
 
 __device__ inline double wave_sum(double v) {
   v += dpp_f64<DPP_XOR1>(v);
@@ -398,6 +432,9 @@ struct FitParams {
   // instance filter fused into the fit (run-length / polygon input): boundary < 0 = off
   int filter_boundary, filter_min_area, filter_max_edge;
   int* filter_stats;   // [B][4] area, rows, span, edge (may be null)
+  // optional epilogue: bbox2D_proj | bbox2D_trunc of every record ([B][8], la3d_project_boxes' layout), frame size proj_w x proj_h
+  double* proj;
+  double proj_w, proj_h;
   double* out;
   int* status;
   double* aux;

@@ -200,6 +200,69 @@ def filter_annotations(annotations, image_size, boundary_threshold: int = 10, sc
             [annotations[i]["category_id"] for i in kept])
 
 
+def fit_instances_ex(depth, K, masks=None, rles=None, polys=None, ground=None, sample_idx=None, image_index=None, filter=None,
+                     image_size=None, stream=None, device=None):
+    """Every option of the fit in one call (C-ABI ``la3d_fit_instances_ex``): exactly one of ``masks`` (B,H,W) u8 / bool,
+    ``rles`` (COCO RLE list or ``pack_rle`` tuple), ``polys`` (``pack_polygons`` tuple) gives the masks; ``filter`` as in
+    ``fit_instances_poly`` (run-length / polygon masks only); ``image_size=(width, height)`` adds the 2-D boxes the reference's
+    Omni3D writer derives from every record - ``bbox2D_proj | bbox2D_trunc`` (B,8), src/tools/combine_results.py:105-108, :238-252 -
+    written by the same kernel epilogue that writes the record.  Returns a dict: boxes, status, aux, and stats / boxes2d when asked."""
+    import ctypes as C
+
+    from ._lib import FitArgs
+
+    dev = _dev(device)
+    if (masks is not None) + (rles is not None) + (polys is not None) != 1:
+        raise ValueError("give exactly one of masks / rles / polys")
+    a = FitArgs()
+    keep = []
+    if masks is not None:
+        m = _as_dev(masks, torch.uint8, dev)
+        B, H, W = m.shape
+        a.mask = _ptr(m); keep.append(m)
+        what = "mask"
+    elif rles is not None:
+        counts, offsets, H, W = pack_rle(rles)
+        c, o = _as_dev(counts, torch.int32, dev), _as_dev(offsets, torch.int64, dev)
+        B = o.numel() - 1
+        a.rle_counts, a.rle_offsets = _ptr(c), _ptr(o); keep += [c, o]
+        what = "RLE"
+    else:
+        xy, ro, ir, H, W = _poly_dev(polys, dev)
+        B = ir.numel() - 1
+        a.poly_xy, a.ring_offsets, a.inst_rings = _ptr(xy), _ptr(ro), _ptr(ir); keep += [xy, ro, ir]
+        what = "polygon"
+    if filter and masks is not None:
+        raise ValueError("the fused filter needs run-length or polygon masks")
+    d, k, P, ii, g, si = _fit_common(depth, K, H, W, B, ground, sample_idx, image_index, dev, what)
+    out = {}
+    with torch.cuda.device(dev):
+        f = InstanceFitter(B, H, W, dev)
+        out.update(boxes=f.boxes[0], status=f.status[0], aux=f.aux[0])
+        if filter:
+            out["stats"] = torch.zeros((B, 4), dtype=torch.int32, device=dev)
+        if image_size is not None:
+            out["boxes2d"] = torch.full((B, 8), float("nan"), dtype=torch.float64, device=dev)
+        if B == 0:
+            return out
+        a.struct_size = C.sizeof(FitArgs)
+        a.B, a.H, a.W = B, H, W
+        a.depth, a.depth_plane_stride, a.image_index = _ptr(d), (H * W if P > 1 else 0), _ptr(ii)
+        a.K, a.k_stride = _ptr(k), (9 if k.shape[0] > 1 else 0)
+        a.ground, a.sample_idx = _ptr(g), _ptr(si)
+        a.filter_boundary = -1
+        if filter:
+            a.filter_boundary, a.filter_min_area, a.filter_max_edge = _filter_args(filter)
+            a.stats = _ptr(out["stats"])
+        if image_size is not None:
+            a.proj, a.image_width, a.image_height = _ptr(out["boxes2d"]), float(image_size[0]), float(image_size[1])
+        a.out, a.status, a.aux = _ptr(f.boxes[0]), _ptr(f.status[0]), _ptr(f.aux[0])
+        a.workspace, a.stream = _ptr(f.workspace[0]), _stream(stream)
+        check(lib.la3d_fit_instances_ex(C.byref(a)), "la3d_fit_instances_ex")
+    _record(stream, d, k, ii, g, si, *keep, f.workspace, *out.values())
+    return out
+
+
 def fit_annotations(annotations, image_size, depth, K, ground=None, boundary_threshold: int = 10, scale_threshold: int = 100,
                     image_index=None, device=None):
     """``read_bounding_boxes_segmentations`` (reference src/util.py:336-383) and the box fit in ONE pass over the annotations:

@@ -344,3 +344,50 @@ def test_fit_annotations_one_pass(la):
     np.testing.assert_array_equal(np_(boxes), np_(b0))
     out = la.fit_annotations([], (W, H), depth, K)
     assert out[0] == [] and out[3].shape == (0, 39)
+
+
+def test_fit_instances_ex_projection_in_the_epilogue(la, monkeypatch):
+    """la3d_fit_instances_ex: the records' 2-D boxes (bbox2D_proj | bbox2D_trunc, reference src/tools/combine_results.py:105-108,
+    :238-252) written by the epilogue that writes the record must equal la3d_project_boxes on the finished records - for u8 planes
+    (instance engine, and the split engine with its follow-up launch), run lengths, polygons with the fused filter - and the records
+    must be those of the plain entry points."""
+    rs = np.random.RandomState(8)
+    B, H, W = 48, 480, 640
+    P_img = 5
+    depth = rs.uniform(0.5, 10, (P_img, H, W)).astype(np.float32)
+    img = np.sort(rs.randint(0, P_img, B)).astype(np.int32)
+    Ks = np.stack([np.array([[500.0 + 20 * i, 0, 320 + i], [0, 480.0 + 10 * i, 240 - i], [0, 0, 1]]) for i in range(P_img)])
+    segs = [_random_segmentation(rs, W, H, k % 8) for k in range(B - 2)] + [[], [[10, 10, 14, 10, 14, 14, 10, 14]]]
+    polys = la.pack_polygons(segs, H, W)
+    masks = np_(la.poly_decode(polys))
+    ground = np.array([[0.03, -0.97, 0.1, 1.1]] * B) + 0.02 * rs.randn(B, 4)
+    ground[5] = [0.0, -1.0, 0.0, 0.0]                               # degenerate ground: rejected -> 8 NaNs
+    size = (W, H)
+
+    def check(res, ref_boxes, ref_status):
+        np.testing.assert_array_equal(np_(res["status"]), np_(ref_status))
+        np.testing.assert_array_equal(np_(res["boxes"]), np_(ref_boxes))
+        want = np_(la.project_boxes(res["boxes"], Ks, size, image_index=img))
+        np.testing.assert_array_equal(np_(res["boxes2d"]), want)
+        bad = np_(res["status"]) != 0
+        assert bad.any() and np.isnan(np_(res["boxes2d"])[bad]).all() and np.isfinite(np_(res["boxes2d"])[~bad]).all()
+
+    monkeypatch.setenv("LA3D_ENGINE", "instance")
+    b0, s0, _ = la.fit_instances(depth, masks, Ks, ground=ground, image_index=img)
+    check(la.fit_instances_ex(depth, Ks, masks=masks, ground=ground, image_index=img, image_size=size), b0, s0)
+    monkeypatch.setenv("LA3D_ENGINE", "split")
+    b1, s1, _ = la.fit_instances(depth, masks, Ks, ground=ground, image_index=img)
+    check(la.fit_instances_ex(depth, Ks, masks=masks, ground=ground, image_index=img, image_size=size), b1, s1)
+    monkeypatch.delenv("LA3D_ENGINE")
+    rles = [O.rle_encode(m) for m in masks]
+    b2, s2, _ = la.fit_instances_rle(depth, rles, Ks, ground=ground, image_index=img)
+    check(la.fit_instances_ex(depth, Ks, rles=rles, ground=ground, image_index=img, image_size=size), b2, s2)
+    b3, s3, _, st3 = la.fit_instances_poly(depth, polys, Ks, ground=ground, image_index=img, filter=True)
+    res = la.fit_instances_ex(depth, Ks, polys=polys, ground=ground, image_index=img, image_size=size, filter=True)
+    check(res, b3, s3)
+    np.testing.assert_array_equal(np_(res["stats"]), np_(st3))
+    assert (np_(res["status"]) == 6).any()
+    with pytest.raises(ValueError, match="exactly one"):
+        la.fit_instances_ex(depth, Ks, masks=masks, rles=rles)
+    with pytest.raises(ValueError, match="fused filter"):
+        la.fit_instances_ex(depth, Ks, masks=masks, filter=True)
