@@ -3,11 +3,13 @@
 //   labelany3d_amd/lib/fit_from_c <B> <H> <W> <seed>
 // Builds B synthetic instances (private depth planes, one rectangle each, a ground plane per instance) with a small
 // LCG, runs la3d_fit_instances on HIP buffers and prints status + the 39 doubles of every record in hex-exact form
-// ("%a").  tests/test_gpu_cabi.py regenerates the same inputs in NumPy and checks the printed records against the oracle.
+// ("%a"), then repeats the fit through la3d_fit_instances_ex (C struct argument block) with the 2-D boxes of the records ("P"
+// lines).  tests/test_gpu_cabi.py regenerates the same inputs in NumPy and checks the printed records against the oracle.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <vector>
 
@@ -61,6 +63,35 @@ int main(int argc, char** argv) {
     printf("%d", status[i]);
     for (int k = 0; k < LA3D_REC; ++k) printf(" %a", out[(size_t)i * LA3D_REC + k]);
     printf("\n");
+  }
+  // the same fit through the extensible entry point, with the records' 2-D boxes from the same epilogue: the records must be
+  // identical, and the boxes those of la3d_project_boxes on the finished records ("P" lines)
+  {
+    double *d_out2, *d_proj, *d_proj2;
+    HIPCHK(hipMalloc(&d_out2, (size_t)B * LA3D_REC * 8)); HIPCHK(hipMalloc(&d_proj, (size_t)B * 64)); HIPCHK(hipMalloc(&d_proj2, (size_t)B * 64));
+    la3d_fit_args a = {};
+    a.struct_size = (int32_t)sizeof(a);
+    a.B = B; a.H = H; a.W = W;
+    a.depth = d_depth; a.depth_plane_stride = (int64_t)HW; a.mask = d_mask; a.K = d_K; a.k_stride = 0; a.ground = d_ground;
+    a.filter_boundary = -1;
+    a.proj = d_proj; a.image_width = W; a.image_height = H;
+    a.out = d_out2; a.status = d_status; a.aux = d_aux; a.workspace = d_ws; a.stream = stream;
+    if (la3d_fit_instances_ex(&a) != LA3D_SUCCESS) { fprintf(stderr, "la3d_fit_instances_ex: %s\n", la3d_last_error()); return 6; }
+    if (la3d_project_boxes(d_out2, d_K, 0, nullptr, B, (double)W, (double)H, d_proj2, stream) != LA3D_SUCCESS) return 7;
+    HIPCHK(hipStreamSynchronize(stream));
+    std::vector<double> out2(out.size()), pr((size_t)B * 8), pr2((size_t)B * 8);
+    HIPCHK(hipMemcpy(out2.data(), d_out2, out2.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(pr.data(), d_proj, pr.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(pr2.data(), d_proj2, pr2.size() * 8, hipMemcpyDeviceToHost));
+    if (memcmp(out.data(), out2.data(), out.size() * 8) != 0) { fprintf(stderr, "la3d_fit_instances_ex: records differ\n"); return 8; }
+    if (memcmp(pr.data(), pr2.data(), pr.size() * 8) != 0) { fprintf(stderr, "la3d_fit_instances_ex: 2-D boxes differ from la3d_project_boxes\n"); return 9; }
+    for (int i = 0; i < B; ++i) {
+      printf("P");
+      for (int k = 0; k < 8; ++k) printf(" %a", pr[(size_t)i * 8 + k]);
+      printf("\n");
+    }
+    a.struct_size = 8;   // a truncated argument block is an error, not a crash
+    if (la3d_fit_instances_ex(&a) != LA3D_ERR_ARG) { fprintf(stderr, "expected LA3D_ERR_ARG for a short struct\n"); return 10; }
   }
   // a bad call must come back as an error code, not a crash
   if (la3d_fit_instances(nullptr, (int64_t)HW, nullptr, d_mask, d_K, 0, nullptr, nullptr, B, H, W, d_out, d_status, nullptr,

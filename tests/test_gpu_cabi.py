@@ -50,8 +50,10 @@ def test_plain_host_program_matches_oracle(B, H, W, seed):
     assert os.path.exists(BIN), "run __graft_entry__.build() first (labelany3d_amd/lib/fit_from_c)"
     out = subprocess.run([BIN, str(B), str(H), str(W), str(seed)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
-    rows = [l.split() for l in out.stdout.strip().splitlines()]
-    assert len(rows) == B
+    lines = out.stdout.strip().splitlines()
+    rows = [l.split() for l in lines if not l.startswith("P")]
+    prows = [l.split()[1:] for l in lines if l.startswith("P")]     # la3d_fit_instances_ex: bbox2D_proj | bbox2D_trunc per record
+    assert len(rows) == B and len(prows) == B
     status = np.array([int(r[0]) for r in rows])
     rec = np.array([[float.fromhex(x) if x not in ("nan", "-nan") else np.nan for x in r[1:]] for r in rows])
     depth, masks, K, ground = make_inputs(B, H, W, seed)
@@ -64,3 +66,11 @@ def test_plain_host_program_matches_oracle(B, H, W, seed):
         scale = max(1.0, np.abs(r[:6]).max())
         np.testing.assert_allclose(rec[i, :15], r[:15], rtol=0, atol=1e-9 * scale, err_msg=f"instance {i}")
         np.testing.assert_allclose(rec[i, 15:], r[15:], rtol=0, atol=max(np.abs(r[15:]).max(), 1.0) * 2.0 ** -10)
+    # the 2-D boxes against the reference's arithmetic on the oracle's corners (src/tools/combine_results.py:105-108, :238-252)
+    p2 = np.array([[float.fromhex(x) if x not in ("nan", "-nan") else np.nan for x in r] for r in prows])
+    for i, (r, st, aux) in enumerate(ref):
+        if st:
+            assert np.isnan(p2[i]).all()
+            continue
+        want = O.project_boxes(rec[i][None], K, (W, H))[0]
+        np.testing.assert_allclose(p2[i], want, rtol=1e-12, atol=1e-9)
