@@ -114,6 +114,10 @@ def main():
     boxes, _, _ = la.fit_instances(depth, masks, K)
     t = timed(lambda: la.project_boxes(boxes, K, (W, H)))
     out["project_boxes_1024"] = dict(s=t, boxes_per_s=Bm / t)
+    t0 = timed(lambda: la.fit_instances_ex(depth, K, masks=masks), n=20)
+    t1 = timed(lambda: la.fit_instances_ex(depth, K, masks=masks, image_size=(W, H)), n=20)
+    out["fit_instances_ex_1024"] = dict(s=t0, s_with_boxes2d=t1,
+                                        note="u8 planes through the Python wrapper; with image_size the records' 2-D boxes come from the same epilogue")
     print(json.dumps(out, indent=1))
 
 
