@@ -314,3 +314,42 @@ def test_filter_annotations_matches_the_reference_rule(la):
     # a polygon annotation takes the polygon branch (tests/test_gpu_poly.py); this small triangle fails the height / area rules
     out = la.filter_annotations([{"iscrowd": 0, "bbox": [0, 0, 1, 1], "category_id": 1, "segmentation": [[0, 0, 5, 0, 5, 5]]}], (W, H))
     assert out[0] == [] and out[1] == [] and out[2].tolist() == [] and out[3] == []
+
+
+@pytest.mark.parametrize("H,W", [(48, 64), (30, 96), (37, 53), (480, 640)])
+def test_rle_decode_fuzzed_run_lengths(la, H, W):
+    """Run-length lists that no encoder would write: zero-length runs anywhere (ones-runs that touch, empty ones-runs), totals short of
+    the frame (the rest is background) or beyond it (clipped, later runs ignored), very long runs crossing many columns, a single
+    count, thousands of one-pixel runs - against pycocotools' rleDecode as restated in the oracle.  Word-aligned widths take the
+    toggle decode, the others the per-pixel painter; the fit kernel's decode (same function) is checked through its pixel count."""
+    rs = np.random.RandomState(H * 7 + W)
+    cases = []
+    for k in range(48 if H * W < 10000 else 12):
+        n = int(rs.randint(1, 60 if k % 3 else 1500))
+        kind = k % 6
+        if kind == 0:
+            c = rs.randint(0, 4, n)                                   # many zero-length runs
+        elif kind == 1:
+            c = rs.randint(0, 2 * H, n)                               # runs around one column long
+        elif kind == 2:
+            c = rs.randint(0, 5 * H, n)                               # runs over several columns
+        elif kind == 3:
+            c = np.where(rs.rand(n) < 0.3, 0, rs.randint(1, H * W // max(n, 1) + 2, n))
+        elif kind == 4:
+            c = rs.randint(0, H * W // 2, min(n, 6))                  # overshoots the frame quickly
+        else:
+            c = np.ones(n, np.int64)
+        cases.append({"size": [H, W], "counts": [int(v) for v in c]})
+    cases.append({"size": [H, W], "counts": [0, H * W]})
+    cases.append({"size": [H, W], "counts": [H * W]})
+    cases.append({"size": [H, W], "counts": [3, 2 * H * W]})
+    cases.append({"size": [H, W], "counts": [H - 1, 1, 0, 1, H - 1, H + 1]})      # runs meeting across a column end
+    want = np.stack([O.rle_decode(c["counts"], H, W) for c in cases])
+    got = np_(la.rle_decode(cases))
+    bad = [i for i in range(len(cases)) if not np.array_equal(got[i], want[i])]
+    assert not bad, (bad[:5], cases[bad[0]]["counts"][:20])
+    depth = np.full((H, W), 2.0, np.float32)
+    K = np.array([[0.8 * W, 0, W / 2], [0, 0.8 * W, H / 2], [0, 0, 1]])
+    _, _, aux = la.fit_instances_rle(depth, cases, K)
+    np.testing.assert_array_equal(np_(aux)[:, 2], want.reshape(len(cases), -1).sum(1))
+    np.testing.assert_array_equal(np_(la.mask_stats_rle(cases))[:, 0], want.reshape(len(cases), -1).sum(1))
