@@ -29,7 +29,9 @@ struct alignas(8) PolySide {
 
 constexpr int POLY_XY_SHIFT = 16;
 constexpr int POLY_CHUNK = 32;                                   // sides staged per step
-constexpr int POLY_STAGE_BYTES = POLY_CHUNK * (int)sizeof(PolySide);
+constexpr int POLY_MAX_JOINT = 8;                                // parts of one instance that may share the fast pass (see poly_to_bits)
+constexpr int POLY_META_INTS = 48;                               // ring bounds (POLY_MAX_JOINT + 1), bounding boxes (4 each), verdict
+constexpr int POLY_STAGE_BYTES = POLY_CHUNK * (int)sizeof(PolySide) + POLY_META_INTS * 4;
 constexpr int POLY_KEEP = 8;                                     // crossings a scanline keeps per sweep (more: another sweep)
 
 // cv::clipLine(Size2l, Point2l&, Point2l&): end points are updated in place even when the line misses the image
@@ -144,9 +146,12 @@ __device__ inline void poly_fill_span(unsigned* bits, int W, int y, int x1, int 
 // scanline) crossing is handled on its own: pass 0 XORs a toggle at column f + 1 (clamped to >= 0; >= W falls outside), an
 // inclusive prefix-XOR along every row turns the toggles into the parity term, pass 1 ORs in the f == c term and the
 // Bresenham outline.  Work: O(crossings + H*W/32) instead of O(sides x scanlines).
+// rb / nrb: the part boundaries inside the n points starting at p0 (rb[0] = 0 < rb[1] < ... rb[nrb] = n, in LDS): several parts
+// whose bounding boxes are pairwise disjoint go through ONE pass - on every scanline their crossings then lie in disjoint column
+// ranges, each with even parity, so the parity fill of all crossings together is the union of the parts' fills.
 template <int NTH>
-__device__ __forceinline__ void poly_ring_fast(const int* __restrict__ xy, long long p0, int n, PolySide* stage, int* box, unsigned* bits,
-                                      int H, int W, int tid) {
+__device__ __forceinline__ void poly_ring_fast(const int* __restrict__ xy, long long p0, int n, const int* rb, int nrb, PolySide* stage,
+                                      int* box, unsigned* bits, int H, int W, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
   constexpr int NW = NTH / 64;
   const int ntxw = W >> 5;
@@ -157,7 +162,11 @@ __device__ __forceinline__ void poly_ring_fast(const int* __restrict__ xy, long 
       if (pass == 0 || n > POLY_CHUNK) {                          // a single chunk stays in the stage for the second pass
         __syncthreads();                                          // the stage is free; the previous phase is complete
         if (tid < m) {
-          const int i = c0 + tid, ip = (i == 0) ? n - 1 : i - 1;
+          const int i = c0 + tid;
+          int lo = 0, hi = n;                                     // the part this point belongs to: the side closes inside it
+          for (int j = 0; j < nrb; ++j)
+            if (i >= rb[j] && i < rb[j + 1]) { lo = rb[j]; hi = rb[j + 1]; }
+          const int ip = (i == lo) ? hi - 1 : i - 1;
           const PolySide sd = poly_side(xy[2 * (p0 + ip)], xy[2 * (p0 + ip) + 1], xy[2 * (p0 + i)], xy[2 * (p0 + i) + 1], W, H);
           stage[tid] = sd;
           if (pass == 0 && sd.e.y0 < sd.e.y1) {                   // bounding rows / words of the toggles of this side
@@ -297,14 +306,59 @@ template <int NTH>
 __device__ __forceinline__ int poly_to_bits(const int* __restrict__ xy, const long long* __restrict__ ring_off, long long r0, long long r1,
                                    PolySide* stage, unsigned* flags, unsigned* bits, int nwords, int H, int W, int tid) {
   for (int i = tid; i < nwords; i += NTH) bits[i] = 0;
-  for (long long r = r0; r < r1; ++r) {
+  int* meta = reinterpret_cast<int*>(stage + POLY_CHUNK);   // [0..8] part bounds, [9 + 4 j ..] bounding box of part j, [41] verdict
+  const int nr = (int)(r1 - r0);
+  long long r = r0;
+  if (nr >= 1 && (W & 31) == 0) {
+    // The fast form wants an empty image, so it can take only the first part - unless the parts cannot interact: up to
+    // POLY_MAX_JOINT parts with pairwise disjoint vertex bounding boxes (the usual case of an object seen in several pieces) are
+    // filled in one pass.  Measured, 1024 instances of 2 / 3 / 5 parts: 117 / 148 / 225 us per launch with the extra parts in the
+    // general form (profiles/exp_poly_rings.py).
+    int joint = 1;
+    if (nr >= 2 && nr <= POLY_MAX_JOINT) {
+      const int lane = tid & 63, wave = tid >> 6;
+      const long long pf = ring_off[r0];
+      for (int j = wave; j < nr; j += NTH / 64) {             // one wave per part: bounding box of its vertices
+        const long long a = ring_off[r0 + j], b = ring_off[r0 + j + 1];
+        int x0 = 0x7fffffff, x1 = -0x7fffffff - 1, y0 = 0x7fffffff, y1 = -0x7fffffff - 1;
+        for (long long q = a + lane; q < b; q += 64) {
+          const int x = xy[2 * q], y = xy[2 * q + 1];
+          x0 = min(x0, x); x1 = max(x1, x); y0 = min(y0, y); y1 = max(y1, y);
+        }
+        x0 = wave_min_i(x0); x1 = wave_max_i(x1); y0 = wave_min_i(y0); y1 = wave_max_i(y1);
+        if (lane == 0) { meta[9 + 4 * j] = x0; meta[10 + 4 * j] = x1; meta[11 + 4 * j] = y0; meta[12 + 4 * j] = y1; meta[j] = (int)(a - pf); }
+      }
+      if (tid == 0) meta[nr] = (int)(ring_off[r1] - pf);
+      __syncthreads();
+      if (tid == 0) {
+        int ok = 1;
+        for (int i = 0; i < nr; ++i)
+          for (int j = i + 1; j < nr; ++j) {
+            const bool apart = meta[10 + 4 * i] < meta[9 + 4 * j] || meta[10 + 4 * j] < meta[9 + 4 * i] ||
+                               meta[12 + 4 * i] < meta[11 + 4 * j] || meta[12 + 4 * j] < meta[11 + 4 * i];   // (an empty part is apart from all)
+            if (!apart) ok = 0;
+          }
+        meta[41] = ok;
+      }
+      __syncthreads();
+      if (meta[41]) joint = nr;   // uniform
+    }
+    const long long p0 = ring_off[r0];
+    const int n = (int)(ring_off[r0 + joint] - p0);
+    if (joint == 1) {
+      if (tid == 0) { meta[0] = 0; meta[1] = n; }
+      __syncthreads();
+    }
+    // (cost of the fast form: independent of the number of crossings, no per-scanline state: measured on 1024 instances of
+    // 640x480 with 60 / 120-vertex non-convex parts 142 / 273 us -> 95 / 119 us per launch; convex parts of 4..31 vertices 3-6 us
+    // slower than the general form)
+    poly_ring_fast<NTH>(xy, p0, n, meta, joint, stage, reinterpret_cast<int*>(flags), bits, H, W, tid);
+    r = r0 + joint;
+  }
+  for (; r < r1; ++r) {   // whatever is left is OR-ed in by the general form
     const long long p0 = ring_off[r];
     const int n = (int)(ring_off[r + 1] - p0);
-    // the first part of an instance takes the fast form (cost independent of the number of crossings, no per-scanline
-    // state: measured on 1024 instances of 640x480 with 60 / 120-vertex non-convex parts 142 / 273 us -> 95 / 119 us per
-    // launch; convex parts of 4..31 vertices 3-6 us slower than the general form); further parts are OR-ed in by the general form
-    if (r == r0 && (W & 31) == 0) poly_ring_fast<NTH>(xy, p0, n, stage, reinterpret_cast<int*>(flags), bits, H, W, tid);
-    else poly_ring_general<NTH>(xy, p0, n, stage, flags, bits, H, W, tid);
+    poly_ring_general<NTH>(xy, p0, n, stage, flags, bits, H, W, tid);
   }
   __syncthreads();
   int nm = 0;

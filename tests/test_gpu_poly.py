@@ -391,3 +391,43 @@ def test_fit_instances_ex_projection_in_the_epilogue(la, monkeypatch):
         la.fit_instances_ex(depth, Ks, masks=masks, rles=rles)
     with pytest.raises(ValueError, match="fused filter"):
         la.fit_instances_ex(depth, Ks, masks=masks, filter=True)
+
+
+def test_parts_with_disjoint_bounding_boxes_share_one_pass(la):
+    """Instances of 2..8 parts whose vertex bounding boxes are pairwise disjoint take ONE fast pass (poly_to_bits): side-by-side and
+    stacked parts, boxes that touch (adjacent columns / rows), parts partly outside the frame, a degenerate 2-point part among
+    them, and the cases that must NOT join: 9 parts, overlapping boxes, a hole contour inside its outer contour.  All against the
+    fillPoly restatement, decode and fit."""
+    rs = np.random.RandomState(77)
+    H, W = 240, 320
+
+    def blob(x0, y0, x1, y1, n):
+        ang = np.sort(rs.uniform(0, 2 * np.pi, n))
+        rad = rs.uniform(0.55, 1.0, n)
+        cx, cy, rx, ry = (x0 + x1) / 2, (y0 + y1) / 2, (x1 - x0) / 2, (y1 - y0) / 2
+        return np.clip(np.stack([cx + rx * rad * np.cos(ang), cy + ry * rad * np.sin(ang)], 1), [x0, y0], [x1, y1]).ravel().tolist()
+
+    segs = []
+    for nparts in range(2, 10):                                   # side by side, touching boxes (x1 of one = x0 - 1 of the next)
+        xs = np.linspace(5, W - 5, nparts + 1).astype(int)
+        segs.append([blob(xs[i], 20 + 7 * i, xs[i + 1] - 1, 200 - 5 * i, rs.randint(3, 40)) for i in range(nparts)])
+    for nparts in (2, 3, 5, 8):                                   # stacked in y, touching rows
+        ys = np.linspace(3, H - 3, nparts + 1).astype(int)
+        segs.append([blob(30 + 5 * i, ys[i], 290 - 9 * i, ys[i + 1] - 1, rs.randint(3, 70)) for i in range(nparts)])
+    segs.append([blob(-40, -30, 100, 90, 25), blob(150, 100, W + 60, H + 50, 31), [200, 10, 230, 40]])   # outside the frame + a 2-point part
+    segs.append([blob(10, 10, 150, 200, 20), blob(140, 50, 300, 220, 20)])                               # overlapping boxes: not joint
+    segs.append([blob(20, 20, 300, 220, 40), [100, 80, 220, 80, 220, 160, 100, 160]])                    # a "hole" contour: filled, not joint
+    segs.append([[10, 10, 60, 10, 60, 60, 10, 60], [61, 10, 120, 10, 120, 60, 61, 60], [10, 61, 60, 61, 60, 120, 10, 120]])   # rectangles that touch
+    polys = la.pack_polygons(segs, H, W)
+    got = np_(la.poly_decode(polys))
+    for i, seg in enumerate(segs):
+        want, _ = P.create_boolean_mask_from_polygon((W, H), seg)
+        assert np.array_equal(got[i], want), (i, len(seg), np.argwhere(got[i] != want)[:5])
+    depth = rs.uniform(0.5, 10, (len(segs), H, W)).astype(np.float32)
+    K = np.array([[250.0, 0, 160], [0, 250.0, 120], [0, 0, 1]])
+    b1, s1, a1 = la.fit_instances_poly(depth, polys, K)
+    with _instance_engine():
+        b2, s2, a2 = la.fit_instances(depth, got, K)
+    np.testing.assert_array_equal(np_(s1), np_(s2))
+    np.testing.assert_array_equal(np_(b1), np_(b2))
+    np.testing.assert_array_equal(np_(la.mask_stats_poly(polys))[:, 0], got.reshape(len(segs), -1).sum(1))
