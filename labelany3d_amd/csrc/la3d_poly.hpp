@@ -8,8 +8,8 @@
 //
 // GPU form (poly_to_bits): the sides of a ring go through LDS 32 at a time — one thread computes a side (clipLine, scan edge),
 // one wave paints its Bresenham pixels lane-parallel from the closed form  minor(i) = floor((2 i dmin + dmaj - 1) / (2 dmaj));
-// every scanline (one thread each) keeps the 8 smallest crossings in (x, side) order in registers while the sides stream by
-// and then ORs the paired spans into the bit image word by word; a scanline with more than 8 crossings takes further sweeps.
+// every scanline (one thread each) keeps the POLY_KEEP smallest crossings in (x, side) order in registers while the sides stream by
+// and then ORs the paired spans into the bit image word by word; a scanline with more crossings takes further sweeps.
 // No global scratch, any number of sides / crossings.
 #pragma once
 #include "la3d_device.hpp"
@@ -32,7 +32,13 @@ constexpr int POLY_CHUNK = 32;                                   // sides staged
 constexpr int POLY_MAX_JOINT = 8;                                // parts of one instance that may share the fast pass (see poly_to_bits)
 constexpr int POLY_META_INTS = 48;                               // ring bounds (POLY_MAX_JOINT + 1), bounding boxes (4 each), verdict
 constexpr int POLY_STAGE_BYTES = POLY_CHUNK * (int)sizeof(PolySide) + POLY_META_INTS * 4;
-constexpr int POLY_KEEP = 8;                                     // crossings a scanline keeps per sweep (more: another sweep)
+#ifndef LA3D_POLY_KEEP
+#define LA3D_POLY_KEEP 4
+#endif
+// crossings a scanline keeps per sweep of the general form (more: another sweep).  Measured on second / third parts of 1024 instances
+// (profiles/r02_poly_parts.txt): convex parts 8 -> 4 kept: -7...-27 % per launch (the 64-VGPR kernel spills 72 -> 31 registers in
+// these loops), 20-40 % more with 2; spiky 40 / 80-vertex parts: +4...9 % with 4, +25...40 % with 2.
+constexpr int POLY_KEEP = LA3D_POLY_KEEP;
 
 // cv::clipLine(Size2l, Point2l&, Point2l&): end points are updated in place even when the line misses the image
 __device__ inline bool poly_clip_line(long long width, long long height, long long& x1, long long& y1, long long& x2, long long& y2) {

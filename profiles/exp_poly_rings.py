@@ -11,18 +11,19 @@ depth, masks, K, n_masked, rects = bench.make_inputs(B, dev, 1234)
 r0, c0, hh, ww = rects
 kfull = K[None].expand(B, 3, 3).contiguous()
 f = InstanceFitter(B, bench.H, bench.W, dev); st = torch.cuda.current_stream()
-for nr, nv in [(1, 4), (1, 20), (2, 4), (2, 20), (3, 20), (5, 20), (8, 12)]:
+for nr, nv in ([(2, 40), (3, 40), (2, 80)] if os.environ.get('STAR') else [(1, 4), (1, 20), (2, 4), (2, 20), (3, 20), (5, 20), (8, 12)]):
     rs = np.random.RandomState(7); segs = []
     for a, b, h, w in zip(r0, c0, hh, ww):
         parts = []
         for q in range(nr):
-            x0, x1 = b + w * q / nr, b + w * (q + 1) / nr - 1
+            x0, x1 = b + w * q / nr, b + w * (q + 1) / nr - 1 + (2 if os.environ.get('OVERLAP') else 0)   # OVERLAP=1: boxes overlap, the general form
             cx, cy, rx, ry = (x0 + x1) / 2, a + h / 2, max((x1 - x0) / 2, 1), max(h / 2 - 1, 1)
             if nv == 4:
                 parts.append([x0, a, x1, a, x1, a + h - 1, x0, a + h - 1])
             else:
                 ang = np.sort(rs.uniform(0, 2 * np.pi, nv))
-                parts.append(np.stack([cx + rx * np.cos(ang), cy + ry * np.sin(ang)], 1).ravel().tolist())
+                rad = rs.uniform(0.35, 1.0, nv) if os.environ.get("STAR") else 1.0     # STAR=1: non-convex parts (many crossings per row)
+                parts.append(np.stack([cx + rx * rad * np.cos(ang), cy + ry * rad * np.sin(ang)], 1).ravel().tolist())
         segs.append(parts)
     xy, ro, ir, _, _ = pack_polygons(segs, bench.H, bench.W)
     xy, ro, ir = (torch.as_tensor(x, device=dev) for x in (xy, ro, ir))
