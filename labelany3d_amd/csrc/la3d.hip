@@ -1147,55 +1147,46 @@ __global__ __launch_bounds__(256) void mask_counts_kernel(const unsigned char* _
   if (threadIdx.x == 0) counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
+constexpr int NT_DEC = 512;   // decode kernels: 8 waves per workgroup (four workgroups per CU by LDS: 32 waves keep the stores coming)
+
+// bit image in LDS -> u8 plane (0/1), coalesced 16-byte non-temporal stores where the plane allows; NTH threads.  Four bits
+// become four bytes with one multiply: bit i of the nibble lands at 8 i through the partial product shifted by 7 i (the 16 partial
+// products hit 16 different bit positions: no carries).
+template <int NTH>
+__device__ inline void bits_to_plane(const unsigned* bits, int HW, unsigned char* o, int tid) {
+  const unsigned short* b16 = reinterpret_cast<const unsigned short*>(bits);
+  if (HW % 16 == 0 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+#pragma unroll 4
+    for (int g = tid; g < HW / 16; g += NTH) {
+      const unsigned pat = b16[g];
+      u32x4 v;
+      v.x = ((pat & 0xFu) * 0x00204081u) & 0x01010101u;
+      v.y = (((pat >> 4) & 0xFu) * 0x00204081u) & 0x01010101u;
+      v.z = (((pat >> 8) & 0xFu) * 0x00204081u) & 0x01010101u;
+      v.w = (((pat >> 12) & 0xFu) * 0x00204081u) & 0x01010101u;
+      __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(o + g * 16));
+    }
+  } else {
+    for (int i = tid; i < HW; i += NTH) o[i] = (bits[i >> 5] >> (i & 31)) & 1u;
+  }
+}
+
 // mask_utils.decode for a batch (reference src/util.py:367,401-402): run lengths -> u8 planes.  The runs are
-// painted into an LDS bit image (rle_to_bits) and expanded with coalesced 16-byte stores.
-__global__ __launch_bounds__(256) void rle_decode_kernel(const int* __restrict__ counts, const long long* __restrict__ offsets,
-                                                         int H, int W, int nwords, int scan_words, unsigned char* __restrict__ out) {
+// decoded into an LDS bit image (rle_to_bits) and expanded with coalesced 16-byte stores.
+__global__ __launch_bounds__(NT_DEC) void rle_decode_kernel(const int* __restrict__ counts, const long long* __restrict__ offsets,
+                                                            int H, int W, int nwords, int scan_words, unsigned char* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned* bits = reinterpret_cast<unsigned*>(smem);
   unsigned* wtot = bits + nwords;
   const int tid = threadIdx.x;
   const long long o0 = offsets[blockIdx.x];
-  (void)rle_to_bits<256>(counts + o0, (int)(offsets[blockIdx.x + 1] - o0), bits, nwords, H, W, wtot, tid, wtot + 16, scan_words);
-  const int HW = H * W;
-  unsigned char* o = out + (long long)blockIdx.x * HW;
-  const unsigned short* b16 = reinterpret_cast<const unsigned short*>(bits);
-  if (HW % 16 == 0 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
-    for (int g = tid; g < HW / 16; g += 256) {
-      const unsigned pat = b16[g];
-      uint4 v;
-      v.x = ((pat >> 0) & 1u) | (((pat >> 1) & 1u) << 8) | (((pat >> 2) & 1u) << 16) | (((pat >> 3) & 1u) << 24);
-      v.y = ((pat >> 4) & 1u) | (((pat >> 5) & 1u) << 8) | (((pat >> 6) & 1u) << 16) | (((pat >> 7) & 1u) << 24);
-      v.z = ((pat >> 8) & 1u) | (((pat >> 9) & 1u) << 8) | (((pat >> 10) & 1u) << 16) | (((pat >> 11) & 1u) << 24);
-      v.w = ((pat >> 12) & 1u) | (((pat >> 13) & 1u) << 8) | (((pat >> 14) & 1u) << 16) | (((pat >> 15) & 1u) << 24);
-      *reinterpret_cast<uint4*>(o + g * 16) = v;
-    }
-  } else {
-    for (int i = tid; i < HW; i += 256) o[i] = (bits[i >> 5] >> (i & 31)) & 1u;
-  }
-}
-
-// bit image in LDS -> u8 plane (0/1), coalesced 16-byte stores where the plane allows; 256 threads
-__device__ inline void bits_to_plane_256(const unsigned* bits, int HW, unsigned char* o, int tid) {
-  const unsigned short* b16 = reinterpret_cast<const unsigned short*>(bits);
-  if (HW % 16 == 0 && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
-    for (int g = tid; g < HW / 16; g += 256) {
-      const unsigned pat = b16[g];
-      uint4 v;
-      v.x = ((pat >> 0) & 1u) | (((pat >> 1) & 1u) << 8) | (((pat >> 2) & 1u) << 16) | (((pat >> 3) & 1u) << 24);
-      v.y = ((pat >> 4) & 1u) | (((pat >> 5) & 1u) << 8) | (((pat >> 6) & 1u) << 16) | (((pat >> 7) & 1u) << 24);
-      v.z = ((pat >> 8) & 1u) | (((pat >> 9) & 1u) << 8) | (((pat >> 10) & 1u) << 16) | (((pat >> 11) & 1u) << 24);
-      v.w = ((pat >> 12) & 1u) | (((pat >> 13) & 1u) << 8) | (((pat >> 14) & 1u) << 16) | (((pat >> 15) & 1u) << 24);
-      *reinterpret_cast<uint4*>(o + g * 16) = v;
-    }
-  } else {
-    for (int i = tid; i < HW; i += 256) o[i] = (bits[i >> 5] >> (i & 31)) & 1u;
-  }
+  (void)rle_to_bits<NT_DEC>(counts + o0, (int)(offsets[blockIdx.x + 1] - o0), bits, nwords, H, W, wtot, tid, wtot + 16, scan_words);
+  bits_to_plane<NT_DEC>(bits, H * W, out + (long long)blockIdx.x * H * W, tid);
 }
 
 // create_boolean_mask_from_polygon for a batch (reference src/util.py:386-400): polygon parts -> u8 planes.  Dynamic LDS:
 // bit image (16-aligned), side stage, flags.
-__global__ __launch_bounds__(256) void poly_decode_kernel(const int* __restrict__ xy, const long long* __restrict__ ring_off,
+__global__ __launch_bounds__(NT_DEC) void poly_decode_kernel(const int* __restrict__ xy, const long long* __restrict__ ring_off,
                                                           const long long* __restrict__ inst_rings, int H, int W, int nwords,
                                                           unsigned char* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1204,8 +1195,8 @@ __global__ __launch_bounds__(256) void poly_decode_kernel(const int* __restrict_
   PolySide* stage = reinterpret_cast<PolySide*>(smem + bit_bytes);
   unsigned* flags = reinterpret_cast<unsigned*>(smem + bit_bytes + POLY_STAGE_BYTES);
   const int tid = threadIdx.x;
-  (void)poly_to_bits<256>(xy, ring_off, inst_rings[blockIdx.x], inst_rings[blockIdx.x + 1], stage, flags, bits, nwords, H, W, tid);
-  bits_to_plane_256(bits, H * W, out + (long long)blockIdx.x * H * W, tid);
+  (void)poly_to_bits<NT_DEC>(xy, ring_off, inst_rings[blockIdx.x], inst_rings[blockIdx.x + 1], stage, flags, bits, nwords, H, W, tid);
+  bits_to_plane<NT_DEC>(bits, H * W, out + (long long)blockIdx.x * H * W, tid);
 }
 
 // The reference's filter quantities (mask_stats) for polygon annotations without materialising a plane: rasterise into
@@ -2341,14 +2332,14 @@ int la3d_rle_decode(const int32_t* counts, const int64_t* offsets, int B, int H,
   if (B == 0) return LA3D_SUCCESS;
   const int nwords = (H * W + 31) / 32;
   // behind the bit image: 16 words of wave totals, then the block totals of the column scan (word-aligned rows)
-  const int scan_words = (W % 32 == 0) ? ((256 / (W / 32) > 2 ? 256 / (W / 32) : 2) * (W / 32)) : 0;
+  const int scan_words = (W % 32 == 0) ? ((NT_DEC / (W / 32) > 2 ? NT_DEC / (W / 32) : 2) * (W / 32)) : 0;
   const size_t lds = (size_t)nwords * 4 + 64 + (size_t)scan_words * 4;
   if (lds > 160 * 1024 - 256) {
     set_err("la3d_rle_decode: frame too large for LDS");
     return LA3D_ERR_UNSUPPORTED;
   }
   allow_big_lds(reinterpret_cast<const void*>(rle_decode_kernel));
-  hipLaunchKernelGGL(rle_decode_kernel, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), counts,
+  hipLaunchKernelGGL(rle_decode_kernel, dim3(B), dim3(NT_DEC), lds, static_cast<hipStream_t>(stream), counts,
                      reinterpret_cast<const long long*>(offsets), H, W, nwords, scan_words, mask_out);
   return check_launch("rle_decode_kernel");
 }
@@ -2364,7 +2355,7 @@ int la3d_poly_decode(const int32_t* poly_xy, const int64_t* ring_offsets, const 
   const int nwords = (H * W + 31) / 32;
   const size_t lds = (((size_t)nwords * 4 + 15) & ~(size_t)15) + POLY_STAGE_BYTES + 64;
   allow_big_lds(reinterpret_cast<const void*>(poly_decode_kernel));
-  hipLaunchKernelGGL(poly_decode_kernel, dim3(B), dim3(256), lds, static_cast<hipStream_t>(stream), poly_xy,
+  hipLaunchKernelGGL(poly_decode_kernel, dim3(B), dim3(NT_DEC), lds, static_cast<hipStream_t>(stream), poly_xy,
                      reinterpret_cast<const long long*>(ring_offsets), reinterpret_cast<const long long*>(inst_rings), H, W, nwords,
                      mask_out);
   return check_launch("poly_decode_kernel");
