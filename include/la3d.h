@@ -62,6 +62,13 @@ const char* la3d_last_error(void);
 int la3d_unproject(const float* depth, const double* K9, const double* Rt12, int H, int W,
                    void* out, int out_is_f64, void* stream);
 
+/* The same for P frames in one launch (a dataset stage unprojects every image: the reference loops over them,
+ * src/batch_scripts/depth.py:138-160).  depth: dev f32 [P][H*W]; K: DEVICE f64, 9 per frame (k_stride >= 9) or one shared
+ * matrix (k_stride 0), inverted in the kernel with the same elimination as the host routine of la3d_unproject;
+ * Rt12 as above (shared by all frames) or NULL; out: dev [P][H*W*3]. */
+int la3d_unproject_batch(const float* depth, const double* K, int32_t k_stride, const double* Rt12, int P, int H, int W,
+                         void* out, int out_is_f64, void* stream);
+
 /* Number of True pixels per mask plane: what the reference sees as in_pc.shape[0]
  * (src/util_3dbox.py:123) when fed pts[mask].  mask: dev u8 [B][H*W] (non-zero = True);
  * counts: dev i32 [B].  The host needs it to draw np.random.randint(0, N, 500). */

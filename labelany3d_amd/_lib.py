@@ -35,6 +35,8 @@ _SIGS = {
     "la3d_set_launch_order": (C.c_int, [C.c_int]),
     "la3d_unproject": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_int,
                                  C.c_void_p, C.c_int, C.c_void_p]),
+    "la3d_unproject_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_int, C.c_void_p]),
     "la3d_mask_counts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "la3d_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "la3d_fit_instances": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,

@@ -243,11 +243,27 @@ def fit_points(clouds, ground=None, sample_idx=None, method: str = "pca", stream
 
 
 def unproject(depth, K, R=None, t=None, out_dtype=torch.float64, stream=None, device=None) -> torch.Tensor:
-    """depth (H,W) float32 -> (H,W,3) points on the GPU (reference src/util.py:52-75)."""
+    """depth (H,W) float32 -> (H,W,3) points on the GPU (reference src/util.py:52-75).  depth (P,H,W) with K (3,3) or (P,3,3):
+    every frame in ONE launch -> (P,H,W,3) (``la3d_unproject_batch``; the reference's stage loops over the images)."""
     if device is None and isinstance(depth, torch.Tensor) and depth.is_cuda:
         device = depth.device
     dev = _dev(device)
     d = _as_dev(depth, torch.float32, dev)
+    if d.dim() == 3:
+        P, H, W = d.shape
+        k = _as_dev(K, torch.float64, dev).reshape(-1, 9)
+        if k.shape[0] not in (1, P):
+            raise ValueError("K must be (3,3) or (P,3,3)")
+        Rt = None
+        if R is not None or t is not None:
+            Rt = (C.c_double * 12)(*(np.eye(3) if R is None else np.asarray(R, dtype=np.float64)).ravel(),
+                                   *(np.zeros(3) if t is None else np.asarray(t, dtype=np.float64)).ravel())
+        out = torch.empty((P, H, W, 3), dtype=out_dtype, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.la3d_unproject_batch(_ptr(d), _ptr(k), 9 if k.shape[0] > 1 else 0, Rt, P, H, W, _ptr(out),
+                                           int(out_dtype == torch.float64), _stream(stream)), "la3d_unproject_batch")
+        _record(stream, d, k, out)
+        return out
     H, W = d.shape
     K9 = (C.c_double * 9)(*np.asarray(K.cpu() if isinstance(K, torch.Tensor) else K, dtype=np.float64).ravel())
     Rt = None

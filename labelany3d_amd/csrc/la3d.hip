@@ -1127,6 +1127,53 @@ __global__ __launch_bounds__(256) void unproject_kernel(const float* __restrict_
   }
 }
 
+// P frames in one launch: blockIdx.y = frame; the frame's K is inverted by one thread (device inv3 = the host routine's elimination)
+template <typename OutT>
+__global__ __launch_bounds__(256) void unproject_batch_kernel(const float* __restrict__ depth, const double* __restrict__ K,
+                                                              int k_stride, OutT* __restrict__ out, const UnprojParams p) {
+  __shared__ double kinv[9];
+  __shared__ OutT stage[4][192];   // one wave's 64 points, so that every store instruction writes whole lines (lane-contiguous)
+  if (threadIdx.x == 0) inv3(K + (long long)blockIdx.y * k_stride, kinv);
+  __syncthreads();
+  const float* dp = depth + (long long)blockIdx.y * p.HW;
+  OutT* op = out + (long long)blockIdx.y * p.HW * 3;
+  const int stride = gridDim.x * blockDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i0 = blockIdx.x * blockDim.x + wave * 64; i0 < p.HW; i0 += stride) {   // wave-uniform trip count
+    const int i = i0 + lane;
+    double w[3] = {0, 0, 0};
+    if (i < p.HW) {
+      unsigned u, v;
+      pix_uv((unsigned)i, p.W, p.rcpW, &u, &v);
+      const double d = (double)dp[i], ud = (double)u, vd = (double)v;
+      double q[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) q[r] = (d * kinv[r * 3]) * ud + (d * kinv[r * 3 + 1]) * vd + (d * kinv[r * 3 + 2]);
+      if (p.has_rt) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) w[r] = p.R[r * 3] * q[0] + p.R[r * 3 + 1] * q[1] + p.R[r * 3 + 2] * q[2] + p.t[r];
+      } else {   // the reference's identity transform, multiplied out (NaN / inf propagate as there)
+        w[0] = 1.0 * q[0] + 0.0 * q[1] + 0.0 * q[2] + 0.0;
+        w[1] = 0.0 * q[0] + 1.0 * q[1] + 0.0 * q[2] + 0.0;
+        w[2] = 0.0 * q[0] + 0.0 * q[1] + 1.0 * q[2] + 0.0;
+      }
+    }
+    OutT* sl = stage[wave];
+    sl[lane * 3] = (OutT)w[0]; sl[lane * 3 + 1] = (OutT)w[1]; sl[lane * 3 + 2] = (OutT)w[2];
+    // lanes exchange through LDS: the hardware completes a wave's LDS operations in order, but the compiler must be told that the
+    // reads below depend on OTHER lanes' writes (it can prove that 3 lane + 1 never equals 64 + lane and would hoist that read)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const long long base = (long long)i0 * 3, lim = (long long)p.HW * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (base + k * 64 + lane < lim) op[base + k * 64 + lane] = sl[k * 64 + lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
 __global__ __launch_bounds__(256) void mask_counts_kernel(const unsigned char* __restrict__ mask, int HW, int vec,
                                                           int* __restrict__ counts) {
   __shared__ int part[4];
@@ -2055,6 +2102,29 @@ int la3d_unproject(const float* depth, const double* K9, const double* Rt12, int
   if (out_is_f64) hipLaunchKernelGGL(unproject_kernel<double>, dim3(blocks), dim3(256), 0, s, depth, static_cast<double*>(out), p);
   else hipLaunchKernelGGL(unproject_kernel<float>, dim3(blocks), dim3(256), 0, s, depth, static_cast<float*>(out), p);
   return check_launch("unproject_kernel");
+}
+
+int la3d_unproject_batch(const float* depth, const double* K, int32_t k_stride, const double* Rt12, int P, int H, int W, void* out,
+                         int out_is_f64, void* stream) {
+  if (!depth || !K || !out || P < 0 || H <= 0 || W <= 0 || (long long)H * W > 0x7fffffffLL / 4 || (k_stride != 0 && k_stride < 9) ||
+      P > 65535) {
+    set_err("la3d_unproject_batch: bad argument (P <= 65535)");
+    return LA3D_ERR_ARG;
+  }
+  if (P == 0) return LA3D_SUCCESS;
+  UnprojParams p;
+  for (int i = 0; i < 9; ++i) p.Kinv[i] = 0.0;
+  p.has_rt = Rt12 != nullptr;
+  for (int i = 0; i < 9; ++i) p.R[i] = Rt12 ? Rt12[i] : ((i % 4 == 0) ? 1.0 : 0.0);
+  for (int i = 0; i < 3; ++i) p.t[i] = Rt12 ? Rt12[9 + i] : 0.0;
+  p.H = H; p.W = W; p.HW = H * W; p.rcpW = 1.0f / (float)W;
+  int bx = (p.HW + 255) / 256;
+  const int want = (8192 + P - 1) / P;   // enough workgroups over all frames to fill the chip several times
+  if (bx > want) bx = want < 1 ? 1 : want;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (out_is_f64) hipLaunchKernelGGL(unproject_batch_kernel<double>, dim3(bx, P), dim3(256), 0, s, depth, K, k_stride, static_cast<double*>(out), p);
+  else hipLaunchKernelGGL(unproject_batch_kernel<float>, dim3(bx, P), dim3(256), 0, s, depth, K, k_stride, static_cast<float*>(out), p);
+  return check_launch("unproject_batch_kernel");
 }
 
 int la3d_mask_counts(const uint8_t* mask, int B, int H, int W, int32_t* counts, void* stream) {

@@ -38,6 +38,12 @@ def main():
     d = torch.rand((H, W), device="cuda") * 9.5 + 0.5
     t = timed(lambda: la.unproject(d, K))
     out["unproject_640x480_f64"] = dict(s=t, bytes=H * W * 28, GBps=H * W * 28 / t / 1e9, frames_per_s=1 / t)
+    stack = torch.rand((256, H, W), device="cuda") * 9.5 + 0.5
+    Kst = torch.as_tensor(np.repeat(np.asarray(K)[None], 256, 0), device="cuda")
+    t = timed(lambda: la.unproject(stack, Kst), n=10)
+    out["unproject_batch_256x640x480_f64"] = dict(s=t, bytes=256 * H * W * 28, GBps=256 * H * W * 28 / t / 1e9, frames_per_s=256 / t,
+                                                  note="256 frames, one launch (la3d_unproject_batch), K per frame inverted in the kernel; includes the output allocation")
+    del stack
     big = torch.rand((2160, 3840), device="cuda") * 9.5 + 0.5
     t = timed(lambda: la.unproject(big, K), n=20)
     out["unproject_3840x2160_f64"] = dict(s=t, bytes=big.numel() * 28, GBps=big.numel() * 28 / t / 1e9)

@@ -91,6 +91,40 @@ def test_g1_depth_to_points(la, golden):
         depth_to_points(d640)
 
 
+def test_unproject_batch_many_frames_one_launch(la, golden):
+    """la3d_unproject_batch (la.unproject on a (P,H,W) stack): every frame of a stage in one launch, K per frame inverted in
+    the kernel.  Each frame against the reference fixtures G1 (same 1e-13 as the single-frame entry) and against the
+    single-frame entry itself; NaN / inf depth propagate alike; shared K, shared R / t, float32 output."""
+    import torch
+
+    g = golden("g1_depth_to_points.npz")
+    tol = dict(rtol=1e-13, atol=1e-13)
+    d = np.stack([g["b_depth"][0], g["b_depth"][0], g["g_depth"][0]])             # (3, 48, 64); the last one holds NaN / +-inf
+    Ks = np.stack([g["b_K"], g["e_K"], g["b_K"]])
+    out = la.unproject(d, Ks)
+    assert out.shape == (3, 48, 64, 3) and out.dtype == torch.float64
+    np.testing.assert_allclose(np_(out[0]), g["b_out"], **tol)
+    np.testing.assert_allclose(np_(out[1]), g["e_out"], **tol)
+    assert np.array_equal(np.isnan(np_(out[2])), np.isnan(g["g_out"]))
+    np.testing.assert_allclose(np_(out[2]), g["g_out"], **tol)
+    for i in range(3):
+        np.testing.assert_allclose(np_(out[i]), np_(la.unproject(d[i], Ks[i])), rtol=1e-14, atol=0, equal_nan=True)
+    shared = la.unproject(d[:2], g["b_K"], R=g["c_R"], t=g["c_t"])
+    np.testing.assert_allclose(np_(shared[0]), g["c_out"], **tol)
+    np.testing.assert_allclose(np_(shared[1]), g["c_out"], **tol)
+    f32 = la.unproject(d[:2], Ks[:2], out_dtype=torch.float32)
+    np.testing.assert_allclose(np_(f32), np_(out[:2]).astype(np.float32), rtol=1e-6)
+    rs = np.random.RandomState(3)
+    big = rs.uniform(0.5, 10, (37, 480, 640)).astype(np.float32)                  # 37 VGA frames, K per frame
+    Kb = np.repeat(K640[None], 37, 0) * (1 + 0.01 * np.arange(37))[:, None, None]
+    Kb[:, 2, 2] = 1
+    ob = la.unproject(big, Kb)
+    for i in (0, 17, 36):
+        np.testing.assert_allclose(np_(ob[i]), np_(la.unproject(big[i], Kb[i])), rtol=1e-14, atol=0)
+    with pytest.raises(ValueError, match="K must be"):
+        la.unproject(d, Ks[:2])
+
+
 def test_g1_torch_in_torch_out(la):
     import torch
 
