@@ -50,6 +50,10 @@ extern "C" {
 /* yaw method (reference src/util_3dbox.py:146-151) */
 #define LA3D_METHOD_PCA 0
 #define LA3D_METHOD_CONVEX_HULL 1
+/* OR-ed into `method` of la3d_fit_points: the caller promises that no cloud has more than a few thousand rows to visit (after
+ * sampling) - true for the reference's own calls (500 mesh samples per object).  PCA method: one WAVE per cloud instead of one
+ * workgroup - no LDS, no barriers, four clouds per workgroup.  Larger clouds stay correct, only slow. */
+#define LA3D_HINT_SMALL_CLOUDS 0x100
 
 int la3d_version(void);
 const char* la3d_last_error(void);

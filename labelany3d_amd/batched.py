@@ -209,18 +209,24 @@ def fit_instances(depth, masks, K, ground=None, sample_idx=None, image_index=Non
         return out
 
 
-def fit_points(clouds, ground=None, sample_idx=None, method: str = "pca", stream=None, device=None):
+def fit_points(clouds, ground=None, sample_idx=None, method: str = "pca", stream=None, device=None, small_clouds=None):
     """estimate_bbox for a list of (N_i,3) clouds in one launch (reference src/util_3dbox.py:106-178).
 
     clouds: list of arrays/tensors, or a tuple (points (T,3) f64, offsets (B+1,) i64).
+    small_clouds: True promises that no cloud has more than a few thousand rows to visit (LA3D_HINT_SMALL_CLOUDS: one wave per
+    cloud); None = decided here when the cloud sizes are known on the host (a list of clouds, or sample_idx given).
     Returns (boxes (B,39), status (B,), aux (B,4)) on the GPU.
     """
     dev = _dev(device)
     if isinstance(clouds, tuple):
         pts = _as_dev(clouds[0], torch.float64, dev)
         off = _as_dev(clouds[1], torch.int64, dev)
+        if small_clouds is None:
+            small_clouds = sample_idx is not None
     else:
         lens = [int(len(c)) for c in clouds]
+        if small_clouds is None:
+            small_clouds = sample_idx is not None or max(lens, default=0) <= 4096
         off = torch.as_tensor(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64), device=dev)
         if sum(lens):
             pts = torch.cat([_as_dev(c, torch.float64, dev).reshape(-1, 3) for c in clouds if len(c)])
@@ -236,7 +242,7 @@ def fit_points(clouds, ground=None, sample_idx=None, method: str = "pca", stream
     status = torch.empty(B, dtype=torch.int32, device=dev)
     aux = torch.empty((B, AUX), dtype=torch.float64, device=dev)
     with torch.cuda.device(dev):
-        check(lib.la3d_fit_points(_ptr(pts), _ptr(off), _ptr(g), _ptr(si), meth, B, _ptr(boxes), _ptr(status),
+        check(lib.la3d_fit_points(_ptr(pts), _ptr(off), _ptr(g), _ptr(si), meth | (_lib.HINT_SMALL_CLOUDS if small_clouds else 0), B, _ptr(boxes), _ptr(status),
                                   _ptr(aux), _stream(stream)), "la3d_fit_points")
     _record(stream, pts, off, g, si, boxes, status, aux)
     return boxes, status, aux

@@ -54,6 +54,10 @@ def main():
     for method in ("pca", "convex_hull"):
         t = timed(lambda: la.fit_points((pts, off), None, None, method), n=20)
         out[f"fit_points_500pt_{method}"] = dict(s=t, boxes_per_s=B / t, bytes=B * 500 * 24 * 2, GBps=B * 500 * 48 / t / 1e9)
+        if method == "pca":
+            t = timed(lambda: la.fit_points((pts, off), None, None, method, small_clouds=True), n=20)
+            out["fit_points_500pt_pca_wave_per_cloud"] = dict(s=t, boxes_per_s=B / t, bytes=B * 500 * 24, GBps=B * 500 * 24 / t / 1e9,
+                                                              note="LA3D_HINT_SMALL_CLOUDS: one wave per cloud (bytes: the points once; the second walk hits the cache)")
     # masks: rle decode, stats
     Bm = 1024
     hh, ww = rs.randint(8, 301, Bm), rs.randint(8, 331, Bm)

@@ -742,3 +742,46 @@ def test_randomized_differential_sweep(la, seed, monkeypatch):
         assert np_(s).tolist() == rst, f"{tag} rle status"
         np.testing.assert_allclose(np.nan_to_num(np_(b), nan=-7.0), np.nan_to_num(outs["instance"], nan=-7.0), rtol=1e-12, atol=1e-12,
                                    err_msg=f"{tag} rle vs planes")
+
+
+def test_fit_points_wave_per_cloud_equals_workgroup_per_cloud(la):
+    """LA3D_HINT_SMALL_CLOUDS (la.fit_points(..., small_clouds=True), the default when the sizes are known): one wave per cloud.
+    Same status, same records to rounding (the sums associate differently) as the workgroup-per-cloud kernel and the oracle, over
+    empty / one-point / NaN / inf clouds, degenerate grounds, the N > 500 index gather, a batch that is not a multiple of four and a
+    cloud far beyond the promise (still correct)."""
+    rs = np.random.RandomState(5)
+    clouds, grounds = [], []
+    for i in range(41):
+        n = [0, 1, 2, 3, 19, 20, 21, 64, 65, 500, 501, 777][i % 12] if i < 36 else rs.randint(2, 600)
+        c = rs.randn(n, 3) * [1.0 + i % 3, 0.5, 2.0] + [0.3 * i, -1.0, 4.0]
+        if i % 7 == 3 and n > 3:
+            c[1, 2] = np.nan
+        if i == 20:
+            c[0, 0] = np.inf
+        clouds.append(c)
+        g = np.array([0.05, -0.97, 0.1, 1.2]) + 0.05 * rs.randn(4)
+        if i == 8:
+            g = np.array([0.0, -1.0, 0.0, 0.0])            # degenerate: NaN rotation
+        if i == 9:
+            g = np.array([0.1, 0.9, 0.1, 2.0])             # flip branch
+        grounds.append(g)
+    clouds.append(rs.randn(20000, 3) * [3, 1, 2] + [0, 0, 6])   # far beyond the promise, not sampled
+    grounds.append(np.array([0.02, -0.99, 0.05, 1.0]))
+    grounds = np.stack(grounds)
+    counts = np.array([len(c) for c in clouds])
+    idx = la.draw_sample_idx(counts, np.random.RandomState(2))
+    for si in (None, idx):
+        bw, sw, aw = la.fit_points(clouds, ground=grounds, sample_idx=si, small_clouds=True)
+        bg, sg, ag = la.fit_points(clouds, ground=grounds, sample_idx=si, small_clouds=False)
+        np.testing.assert_array_equal(np_(sw), np_(sg))
+        ok = np_(sg) == 0
+        assert ok.sum() > 25 and (~ok).sum() >= 4
+        np.testing.assert_allclose(np_(bw)[ok][:, :15], np_(bg)[ok][:, :15], rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(np_(bw)[ok][:, 15:], np_(bg)[ok][:, 15:], rtol=0, atol=2e-2)     # fp16-quantised corners
+        assert np.isnan(np_(bw)[~ok]).all()
+        np.testing.assert_array_equal(np_(aw)[:, 1:3], np_(ag)[:, 1:3])
+        for i in range(len(clouds)):          # and against the oracle (status of every cloud, records of the accepted ones)
+            rec, st, _ = O.fit_points(clouds[i], grounds[i], rand_ind=(False if si is None else si[i]))
+            assert np_(sw)[i] == st, (i, np_(sw)[i], st)
+            if st == 0:
+                np.testing.assert_allclose(np_(bw)[i, :15], rec[:15], rtol=0, atol=1e-9 * max(1.0, np.abs(rec[:6]).max()))
