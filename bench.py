@@ -251,6 +251,9 @@ def main():
                     help="feed the masks as polygon parts (la3d_fit_instances_poly: the reference's COCONut annotation format, "
                          "rasterised with cv2.fillPoly's rule inside the fit kernel) instead of u8 planes: the rectangles as 4-vertex "
                          "rings; NOT the BASELINE config-2 input format, reported for the mask-ingestion row only")
+    ap.add_argument("--area-hint", action="store_true",
+                    help="secondary mode: hand the mask areas to the fit (la3d_fit_args::area_hint - what a caller holding the annotation "
+                         "metadata or a preceding filter's statistics can do): the launch order then needs no estimate pass over the masks")
     ap.add_argument("--subsample", action="store_true",
                     help="secondary mode: the reference's own semantics for masks above 500 px - 500 points drawn with replacement "
                          "(np.random.randint, src/util_3dbox.py:123-125; indices drawn once outside the timed region, as the "
@@ -306,6 +309,31 @@ def main():
     if args.config3:
         _run = fitter.run
         fitter.run = lambda d, m, k, slot=0, stream=None, ws_slot=0: _run(d, m, k, image_index=image_index, slot=0, stream=stream, ws_slot=ws_slot)
+    if args.area_hint:
+        import ctypes as C
+
+        from labelany3d_amd._lib import FitArgs, check, lib
+        if args.config3 or args.rle or args.poly or args.subsample:
+            raise SystemExit("--area-hint: u8 planes with private depth only")
+        areas = masks.reshape(B, -1).sum(1, dtype=torch.int32)
+        blocks = {}
+
+        def run_hinted(d, m, k, slot=0, stream=None, ws_slot=0):
+            key = (slot, ws_slot, stream.cuda_stream)
+            a = blocks.get(key)
+            if a is None:
+                a = FitArgs()
+                a.struct_size = C.sizeof(FitArgs)
+                a.B, a.H, a.W = B, H, W
+                a.depth, a.depth_plane_stride, a.mask = d.data_ptr(), H * W, m.data_ptr()
+                a.K, a.k_stride, a.filter_boundary = k.data_ptr(), 0, -1
+                a.area_hint = areas.data_ptr()
+                a.out, a.status, a.aux = fitter.boxes[slot].data_ptr(), fitter.status[slot].data_ptr(), fitter.aux[slot].data_ptr()
+                a.workspace, a.stream = fitter.workspace[ws_slot].data_ptr(), stream.cuda_stream
+                blocks[key] = a
+            check(lib.la3d_fit_instances_ex(C.byref(a)), "la3d_fit_instances_ex")
+
+        fitter.run = run_hinted
     sample_idx = None
     if args.subsample:
         from labelany3d_amd import draw_sample_idx
@@ -446,7 +474,7 @@ def main():
         achieved = req_bytes / step_s / 1e9
         traffic, traffic_src, traffic_stale = None, None, None
         tp = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
-        if os.path.exists(tp) and not (args.config3 or args.config5 or args.rle or args.poly or args.subsample) and B == 1024:
+        if os.path.exists(tp) and not (args.config3 or args.config5 or args.rle or args.poly or args.subsample or args.area_hint) and B == 1024:
             tj = json.load(open(tp))
             traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
             traffic_stale = tj.get("kernel_source_sha256") != kernel_source_sha256()
@@ -460,6 +488,8 @@ def main():
             workload = ("BASELINE config 2: 1024 instances per GPU per step, private 480x640 f32 depth ~U(0.5,10) "
                         "+ u8 rectangular mask per instance, K=[[500,0,320],[0,500,240],[0,0,1]], ground=None, "
                         "full-mask mode; inputs resident in HBM")
+        if args.area_hint:
+            workload += "; mask areas handed to the fit (area_hint): no estimate pass"
         if args.subsample:
             workload = workload.replace("full-mask mode", "reference-subsample mode (500 drawn points per mask above 500 px)") \
                 if "full-mask mode" in workload else workload + "; reference-subsample mode (500 drawn points per mask above 500 px)"

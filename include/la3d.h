@@ -197,6 +197,10 @@ typedef struct la3d_fit_args {
   double* proj; double image_width, image_height;              /* [B][8] | NULL */
   double* out; int32_t* status; double* aux;
   void* workspace; void* stream;
+  /* --- fields added after the first publication (struct_size tells which the caller has) --- */
+  const int32_t* area_hint;   /* dev i32 [B] | NULL: mask areas in pixels the caller already knows (annotation "area", the statistics of
+                                 a preceding filter): the size-balanced launch order then needs no estimate pass over the masks.  A
+                                 hint only orders the work - wrong values cost speed, never correctness. */
 } la3d_fit_args;
 int la3d_fit_instances_ex(const la3d_fit_args* args);
 

@@ -26,7 +26,8 @@ class FitArgs(C.Structure):
                 ("stats", C.c_void_p),
                 ("proj", C.c_void_p), ("image_width", C.c_double), ("image_height", C.c_double),
                 ("out", C.c_void_p), ("status", C.c_void_p), ("aux", C.c_void_p),
-                ("workspace", C.c_void_p), ("stream", C.c_void_p)]
+                ("workspace", C.c_void_p), ("stream", C.c_void_p),
+                ("area_hint", C.c_void_p)]
 
 
 _SIGS = {

@@ -22,6 +22,7 @@
 //   epilog   wave 0 writes center / dims / R_cam / fp16-quantised vertices, one lane per output group.
 #include <atomic>
 #include <cstddef>
+#include <cstring>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -2013,20 +2014,30 @@ __global__ __launch_bounds__(256) void size_estimate_kernel(const unsigned char*
 // sixteenth of the batch, 64 keys at a time: coalesced loads issued up front, then register broadcasts
 // (v_readlane) - no dependent memory access inside the counting loop.
 constexpr int ORDER_WAVES = 16;
+// sort key of instance j: from the estimate kernel's table, or built on the fly from a caller-supplied area (la3d_fit_args::area_hint)
+__device__ inline unsigned order_key(const unsigned* __restrict__ keys, const int* __restrict__ area, int shift, int j) {
+  if (!area) return keys[j];
+  const int a = area[j];
+  unsigned q = (unsigned)(a < 0 ? 0 : a) >> shift;
+  if (q > 0x3ffffu) q = 0x3ffffu;
+  return (q << KEY_IDX_BITS) | (unsigned)((1 << KEY_IDX_BITS) - 1 - j);
+}
+
 __global__ __launch_bounds__(ORDER_WAVES * 64) void launch_order_kernel(const unsigned* __restrict__ keys, int B, int resident,
-                                                                        int* __restrict__ perm) {
+                                                                        int* __restrict__ perm, const int* __restrict__ area = nullptr,
+                                                                        int shift = 0) {
   __shared__ int part[ORDER_WAVES][64];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = blockIdx.x * 64 + lane;
-  const unsigned mine = i < B ? keys[i] : 0xffffffffu;
+  const unsigned mine = i < B ? order_key(keys, area, shift, i) : 0xffffffffu;
   const int chunk = (((B + ORDER_WAVES - 1) / ORDER_WAVES) + 63) & ~63;
   const int j0 = w * chunk, j1 = (j0 + chunk < B) ? j0 + chunk : B;
   int cnt = 0;
   for (int j = j0; j < j1; j += 256) {
     unsigned v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = (j + k * 64 + lane < j1) ? keys[j + k * 64 + lane] : 0u;  // key 0 never counts
+    for (int k = 0; k < 4; ++k) v[k] = (j + k * 64 + lane < j1) ? order_key(keys, area, shift, j + k * 64 + lane) : 0u;  // key 0 never counts
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (j + k * 64 < j1) {  // wave-uniform
@@ -2090,10 +2101,17 @@ int launch_fit_inst(const FitParams& p_in, size_t lds, hipStream_t s, void* work
       long long amax = (p.rle_counts || p.poly_xy) ? (long long)p.HW : (long long)p.HW / step + 128;
       int shift = 0;
       while ((amax >> shift) > 0x3ffff) ++shift;
-      hipLaunchKernelGGL(size_estimate_kernel, dim3((p.B + 3) / 4), dim3(256), 0, s, p.mask, p.rle_counts, p.rle_offsets, p.poly_xy,
-                         p.poly_ring_off, p.poly_inst_rings, p.B, p.HW, step, shift, est);
-      hipLaunchKernelGGL(launch_order_kernel, dim3((p.B + 63) / 64), dim3(ORDER_WAVES * 64), 0, s, est, p.B, wg_per_cu * 256,
-                         perm);
+      if (p.area_hint) {   // the caller knows the mask areas (annotation metadata, a preceding filter): no estimate pass
+        int hshift = 0;
+        while (((long long)p.HW >> hshift) > 0x3ffff) ++hshift;
+        hipLaunchKernelGGL(launch_order_kernel, dim3((p.B + 63) / 64), dim3(ORDER_WAVES * 64), 0, s, est, p.B, wg_per_cu * 256,
+                           perm, p.area_hint, hshift);
+      } else {
+        hipLaunchKernelGGL(size_estimate_kernel, dim3((p.B + 3) / 4), dim3(256), 0, s, p.mask, p.rle_counts, p.rle_offsets, p.poly_xy,
+                           p.poly_ring_off, p.poly_inst_rings, p.B, p.HW, step, shift, est);
+        hipLaunchKernelGGL(launch_order_kernel, dim3((p.B + 63) / 64), dim3(ORDER_WAVES * 64), 0, s, est, p.B, wg_per_cu * 256,
+                           perm);
+      }
       p.perm = perm;
     }
   }
@@ -2222,7 +2240,8 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
                         const int32_t* rle_counts, const int64_t* rle_offsets, const double* K, int32_t k_stride,
                         const double* ground, const int32_t* sample_idx, int B, int H, int W, double* out,
                         int32_t* status, double* aux, void* workspace, void* stream, const char* who,
-                        const PolyArgs* poly = nullptr, const FilterArgs* filter = nullptr, const ProjArgs* proj = nullptr) {
+                        const PolyArgs* poly = nullptr, const FilterArgs* filter = nullptr, const ProjArgs* proj = nullptr,
+                        const int32_t* area_hint = nullptr) {
   const bool rle = rle_counts != nullptr || poly != nullptr;   // "no u8 plane": the mask is decoded into the LDS bit image
   if (!depth || (!mask && !rle) || (rle_counts && !rle_offsets) || (poly && (!poly->ring_off || !poly->inst_rings)) || !K ||
       !out || !status || B < 0 || H <= 0 || W <= 0 ||
@@ -2255,6 +2274,7 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   p.stagger_ticks = 0;
   p.filter_boundary = -1; p.filter_min_area = 0; p.filter_max_edge = 0; p.filter_stats = nullptr;
   p.proj = proj ? proj->out : nullptr; p.proj_w = proj ? proj->width : 0; p.proj_h = proj ? proj->height : 0;
+  p.area_hint = area_hint;
   if (filter) {
     if (!rle || filter->boundary < 0) {
       snprintf(g_err, sizeof(g_err), "%s: the fused filter needs run-length or polygon masks and boundary >= 0", who);
@@ -2419,11 +2439,14 @@ int la3d_fit_instances_poly_filtered(const float* depth, int64_t depth_plane_str
 }
 
 int la3d_fit_instances_ex(const la3d_fit_args* args) {
-  if (!args || args->struct_size < (int32_t)sizeof(la3d_fit_args)) {   // (a longer struct from a newer caller is fine)
+  constexpr int32_t V1_SIZE = (int32_t)offsetof(la3d_fit_args, area_hint);   // the block as first published: every field up to `stream`
+  if (!args || args->struct_size < V1_SIZE) {   // (a longer block from a newer caller is fine, fields it lacks are taken as zero)
     set_err("la3d_fit_instances_ex: bad struct_size");
     return LA3D_ERR_ARG;
   }
-  const la3d_fit_args& a = *args;
+  la3d_fit_args a;
+  memset(&a, 0, sizeof(a));
+  memcpy(&a, args, (size_t)args->struct_size < sizeof(a) ? (size_t)args->struct_size : sizeof(a));
   const int kinds = (a.mask ? 1 : 0) + (a.rle_counts ? 1 : 0) + (a.poly_xy ? 1 : 0);
   if (kinds != 1 && a.B > 0) {
     set_err("la3d_fit_instances_ex: give exactly one of mask / rle_counts / poly_xy");
@@ -2442,7 +2465,7 @@ int la3d_fit_instances_ex(const la3d_fit_args* args) {
   const ProjArgs pr{a.proj, a.image_width, a.image_height};
   return fit_dispatch(a.depth, a.depth_plane_stride, a.image_index, a.mask, a.rle_counts, a.rle_offsets, a.K, a.k_stride, a.ground,
                       a.sample_idx, a.B, a.H, a.W, a.out, a.status, a.aux, a.workspace, a.stream, "la3d_fit_instances_ex",
-                      a.poly_xy ? &pa : nullptr, a.filter_boundary >= 0 ? &fa : nullptr, a.proj ? &pr : nullptr);
+                      a.poly_xy ? &pa : nullptr, a.filter_boundary >= 0 ? &fa : nullptr, a.proj ? &pr : nullptr, a.area_hint);
 }
 
 int la3d_rle_from_string_host(const char* s, int64_t len, int32_t* counts, int cap) {

@@ -435,6 +435,7 @@ struct FitParams {
   // optional epilogue: bbox2D_proj | bbox2D_trunc of every record ([B][8], la3d_project_boxes' layout), frame size proj_w x proj_h
   double* proj;
   double proj_w, proj_h;
+  const int* area_hint;   // [B] mask areas known to the caller (launch order without the estimate pass), or null
   double* out;
   int* status;
   double* aux;

@@ -201,12 +201,14 @@ def filter_annotations(annotations, image_size, boundary_threshold: int = 10, sc
 
 
 def fit_instances_ex(depth, K, masks=None, rles=None, polys=None, ground=None, sample_idx=None, image_index=None, filter=None,
-                     image_size=None, stream=None, device=None):
+                     image_size=None, area_hint=None, stream=None, device=None):
     """Every option of the fit in one call (C-ABI ``la3d_fit_instances_ex``): exactly one of ``masks`` (B,H,W) u8 / bool,
     ``rles`` (COCO RLE list or ``pack_rle`` tuple), ``polys`` (``pack_polygons`` tuple) gives the masks; ``filter`` as in
     ``fit_instances_poly`` (run-length / polygon masks only); ``image_size=(width, height)`` adds the 2-D boxes the reference's
     Omni3D writer derives from every record - ``bbox2D_proj | bbox2D_trunc`` (B,8), src/tools/combine_results.py:105-108, :238-252 -
-    written by the same kernel epilogue that writes the record.  Returns a dict: boxes, status, aux, and stats / boxes2d when asked."""
+    written by the same kernel epilogue that writes the record.  ``area_hint`` (B,) int: mask areas the caller already knows (the
+    annotation's ``area``, a preceding filter's statistics) - the size-balanced launch order then skips its estimate pass over the
+    masks; a hint only orders the work.  Returns a dict: boxes, status, aux, and stats / boxes2d when asked."""
     import ctypes as C
 
     from ._lib import FitArgs
@@ -256,6 +258,11 @@ def fit_instances_ex(depth, K, masks=None, rles=None, polys=None, ground=None, s
             a.stats = _ptr(out["stats"])
         if image_size is not None:
             a.proj, a.image_width, a.image_height = _ptr(out["boxes2d"]), float(image_size[0]), float(image_size[1])
+        if area_hint is not None:
+            ah = _as_dev(area_hint, torch.int32, dev).reshape(-1)
+            if ah.numel() != B:
+                raise ValueError("area_hint must have one entry per instance")
+            a.area_hint = _ptr(ah); keep.append(ah)
         a.out, a.status, a.aux = _ptr(f.boxes[0]), _ptr(f.status[0]), _ptr(f.aux[0])
         a.workspace, a.stream = _ptr(f.workspace[0]), _stream(stream)
         check(lib.la3d_fit_instances_ex(C.byref(a)), "la3d_fit_instances_ex")
@@ -291,10 +298,13 @@ def fit_annotations(annotations, image_size, depth, K, ground=None, boundary_thr
         sel = np.asarray(idx, np.int64)
         g = None if ground is None else np.asarray(ground, dtype=np.float64)[sel]
         ii = None if image_index is None else np.asarray(image_index)[sel]
-        if kind == "rle":
-            b, s, _, _ = fit_instances_rle(depth, segs, K, ground=g, image_index=ii, device=dev, filter=flt)
-        else:
-            b, s, _, _ = fit_instances_poly(depth, pack_polygons(segs, H_img, W_img), K, ground=g, image_index=ii, device=dev, filter=flt)
+        # the annotation's own "area" (COCO: the mask area in pixels), when every annotation of the group has one, spares the launch
+        # order its estimate pass
+        ar = [annotations[i].get("area") for i in idx]
+        hint = None if any(v is None for v in ar) else np.clip(np.asarray(ar, dtype=np.float64), 0, 2**31 - 1).astype(np.int32)
+        kw = dict(rles=segs) if kind == "rle" else dict(polys=pack_polygons(segs, H_img, W_img))
+        res = fit_instances_ex(depth, K, ground=g, image_index=ii, device=dev, filter=flt, area_hint=hint, **kw)
+        b, s = res["boxes"], res["status"]
         keep = (s != 6).cpu().numpy()
         idx_all.append(sel[keep]); box_all.append(b[torch.as_tensor(keep, device=b.device)]); st_all.append(s[torch.as_tensor(keep, device=s.device)])
     if not idx_all:

@@ -324,7 +324,8 @@ def test_fit_annotations_one_pass(la):
     anns = []
     for i in range(40):
         seg = _random_segmentation(rs, W, H, i % 8)
-        a = {"iscrowd": int(i % 11 == 0), "bbox": [float(i), 1.0, 2.0, 3.0], "category_id": 1 + i % 5, "segmentation": seg}
+        a = {"iscrowd": int(i % 11 == 0), "bbox": [float(i), 1.0, 2.0, 3.0], "category_id": 1 + i % 5, "segmentation": seg,
+             "area": float(rs.randint(10, 50000))}     # (COCO carries the mask area; here arbitrary: a hint only orders the work)
         if i % 3 == 0:      # every third annotation as an RLE of the same shape
             m, _ = P.create_boolean_mask_from_polygon((W, H), seg)
             a["segmentation"] = O.rle_encode(m)
@@ -431,3 +432,30 @@ def test_parts_with_disjoint_bounding_boxes_share_one_pass(la):
     np.testing.assert_array_equal(np_(s1), np_(s2))
     np.testing.assert_array_equal(np_(b1), np_(b2))
     np.testing.assert_array_equal(np_(la.mask_stats_poly(polys))[:, 0], got.reshape(len(segs), -1).sum(1))
+
+
+def test_area_hint_orders_the_launch_without_the_estimate_pass(la, monkeypatch):
+    """la3d_fit_args::area_hint: the launch order is built from the caller's areas instead of the estimate kernel.  Records are those of
+    the unhinted call bit for bit - with the true areas, with useless ones (all equal, random, negative) and for every mask kind -
+    because the order never shows in a record."""
+    import torch
+
+    import bench
+
+    dev = torch.device("cuda", 0)
+    monkeypatch.setenv("LA3D_ENGINE", "instance")
+    B = 1024
+    depth, masks, K, _, rects = bench.make_inputs(B, dev, 3)
+    ref = la.fit_instances_ex(depth, K, masks=masks)
+    areas = masks.reshape(B, -1).sum(1, dtype=torch.int32)
+    rs = np.random.RandomState(0)
+    for hint in (areas, torch.zeros_like(areas), torch.as_tensor(rs.randint(-5, 400000, B).astype(np.int32), device=dev)):
+        got = la.fit_instances_ex(depth, K, masks=masks, area_hint=hint)
+        assert torch.equal(got["boxes"], ref["boxes"]) and torch.equal(got["status"], ref["status"]) and torch.equal(got["aux"], ref["aux"])
+    rc, ro = bench.rect_rle(rects)
+    rles = (rc, ro, bench.H, bench.W)
+    r0 = la.fit_instances_ex(depth, K, rles=rles)
+    r1 = la.fit_instances_ex(depth, K, rles=rles, area_hint=areas)
+    assert torch.equal(r0["boxes"], r1["boxes"]) and torch.equal(r0["boxes"], ref["boxes"])
+    with pytest.raises(ValueError, match="one entry per instance"):
+        la.fit_instances_ex(depth, K, masks=masks, area_hint=areas[:5])
