@@ -309,31 +309,6 @@ def main():
     if args.config3:
         _run = fitter.run
         fitter.run = lambda d, m, k, slot=0, stream=None, ws_slot=0: _run(d, m, k, image_index=image_index, slot=0, stream=stream, ws_slot=ws_slot)
-    if args.area_hint:
-        import ctypes as C
-
-        from labelany3d_amd._lib import FitArgs, check, lib
-        if args.config3 or args.rle or args.poly or args.subsample:
-            raise SystemExit("--area-hint: u8 planes with private depth only")
-        areas = masks.reshape(B, -1).sum(1, dtype=torch.int32)
-        blocks = {}
-
-        def run_hinted(d, m, k, slot=0, stream=None, ws_slot=0):
-            key = (slot, ws_slot, stream.cuda_stream)
-            a = blocks.get(key)
-            if a is None:
-                a = FitArgs()
-                a.struct_size = C.sizeof(FitArgs)
-                a.B, a.H, a.W = B, H, W
-                a.depth, a.depth_plane_stride, a.mask = d.data_ptr(), H * W, m.data_ptr()
-                a.K, a.k_stride, a.filter_boundary = k.data_ptr(), 0, -1
-                a.area_hint = areas.data_ptr()
-                a.out, a.status, a.aux = fitter.boxes[slot].data_ptr(), fitter.status[slot].data_ptr(), fitter.aux[slot].data_ptr()
-                a.workspace, a.stream = fitter.workspace[ws_slot].data_ptr(), stream.cuda_stream
-                blocks[key] = a
-            check(lib.la3d_fit_instances_ex(C.byref(a)), "la3d_fit_instances_ex")
-
-        fitter.run = run_hinted
     sample_idx = None
     if args.subsample:
         from labelany3d_amd import draw_sample_idx
@@ -385,6 +360,39 @@ def main():
                   "la3d_fit_instances_poly")
 
         fitter.run = lambda d, m, k, slot=0, stream=None, ws_slot=0: run_poly(slot, stream, ws_slot)
+
+    if args.area_hint:
+        import ctypes as C
+
+        from labelany3d_amd._lib import FitArgs, check, lib
+        if args.config3 or args.subsample:
+            raise SystemExit("--area-hint: private depth planes, full-mask mode only")
+        areas = masks.reshape(B, -1).sum(1, dtype=torch.int32)     # what the annotation's "area" field holds
+        kfull_h = K[None].expand(B, 3, 3).contiguous()
+        blocks = {}
+
+        def run_hinted(d, m, k, slot=0, stream=None, ws_slot=0):
+            key = (slot, ws_slot, stream.cuda_stream)
+            a = blocks.get(key)
+            if a is None:
+                a = FitArgs()
+                a.struct_size = C.sizeof(FitArgs)
+                a.B, a.H, a.W = B, H, W
+                a.depth, a.depth_plane_stride = d.data_ptr(), H * W
+                if args.rle:
+                    a.rle_counts, a.rle_offsets = rle_c.data_ptr(), rle_o.data_ptr()
+                elif args.poly:
+                    a.poly_xy, a.ring_offsets, a.inst_rings = pxy.data_ptr(), pro.data_ptr(), pir.data_ptr()
+                else:
+                    a.mask = m.data_ptr()
+                a.K, a.k_stride, a.filter_boundary = kfull_h.data_ptr(), 9, -1
+                a.area_hint = areas.data_ptr()
+                a.out, a.status, a.aux = fitter.boxes[slot].data_ptr(), fitter.status[slot].data_ptr(), fitter.aux[slot].data_ptr()
+                a.workspace, a.stream = fitter.workspace[ws_slot].data_ptr(), stream.cuda_stream
+                blocks[key] = a
+            check(lib.la3d_fit_instances_ex(C.byref(a)), "la3d_fit_instances_ex")
+
+        fitter.run = run_hinted
 
     def barrier():
         torch.cuda.synchronize()
