@@ -130,14 +130,17 @@ if os.environ.get("TL_DETAIL"):
     torch.cuda.synchronize()
     tl = f.workspace[0][8192: 8192 + B * 128].view(torch.float64).cpu().numpy().reshape(B, 16)
     t = (tl[:, :7] - tl[:, 8].min()) / 100.0
+    ta = (tl[:, 13] - tl[:, 8].min()) / 100.0     # stream turn acquired (0 when the turns are off)
     blk = tl[:, 7].astype(int)
     order = np.argsort(blk)
     t = t[order]
+    ta = ta[order]
     print("\nstart time percentiles (us):", np.percentile(t[:, 0], [10, 25, 50, 75, 90, 95, 99, 100]).round(1))
     print("end   time percentiles (us):", np.percentile(t[:, 6], [10, 25, 50, 75, 90, 95, 99, 100]).round(1))
     for g in range(4):
         sl = slice(g * 256, (g + 1) * 256)
-        print(f"blocks {g*256:4d}..{g*256+255:4d}: start mean {t[sl, 0].mean():5.1f} max {t[sl, 0].max():5.1f} | stream done mean {t[sl, 1].mean():5.1f} | end mean {t[sl, 6].mean():5.1f} max {t[sl, 6].max():5.1f}")
+        print(f"blocks {g*256:4d}..{g*256+255:4d}: start mean {t[sl, 0].mean():5.1f} max {t[sl, 0].max():5.1f} | turn acquired mean {ta[sl].mean():5.1f} max {ta[sl].max():5.1f} | stream done mean {t[sl, 1].mean():5.1f} max {t[sl, 1].max():5.1f} | "
+              f"passA done mean {t[sl, 3].mean():5.1f} | passB done mean {t[sl, 5].mean():5.1f} | end mean {t[sl, 6].mean():5.1f} max {t[sl, 6].max():5.1f}")
     for x in range(8):
         sl = np.arange(B)[np.arange(B) % 8 == x]
         print(f"XCD {x}: start mean {t[sl, 0].mean():5.1f} max {t[sl, 0].max():5.1f} | end mean {t[sl, 6].mean():5.1f} max {t[sl, 6].max():5.1f}")
