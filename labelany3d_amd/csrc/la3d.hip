@@ -423,6 +423,73 @@ __device__ inline void yaw_rows(const Shared* sh, const double* Mg, double* N0, 
 }
 
 // ------------------------------------------------------------------------------------------
+// size-balanced launch order, decided inside the fit kernel (round 3: the ranking kernel of rounds 1-2 is gone).
+// Measured on MI355X (profiles/microbench/wg_census.hip, profiles/exp_chain.py): workgroup b of a fresh grid starts on
+// CU b % 256, so with G workgroups resident per CU the instances of blocks {c, c+256, ..} share CU c for their whole
+// life and the launch lasts as long as the most loaded CU (random sizes: ~2x the mean; 152 us unordered vs 113 us
+// ordered on the same multiset).  Rank r of the descending size order -> group r/256; group 0 goes to CUs 0..255 in
+// order, every later group in reverse (the CU with the largest instance gets the smallest member of every other group);
+// ranks beyond the resident set follow in descending order (longest-first list scheduling of the dynamic remainder).
+// The ranking is CHUNK-LOCAL: the batch is cut into nch = ceil(B/64) chunks of consecutive instances (the first B % nch
+// one longer), "rank in chunk * nch + chunk" stands in for the global rank (a round-robin merge of the chunk orders: a
+// bijection onto 0..B-1, and what the exact merge gives for equally distributed chunks; per-CU load max/mean 1.27 vs
+// 1.17 for the exact ranking on the config-2 sizes).  So workgroup b inverts the map - block -> rank -> (chunk, rank in
+// chunk) - loads the <= 64 keys of that chunk (L2-resident, written by size_estimate_kernel, or built from the caller's
+// area_hint: then NO helper launch at all) and finds the instance with that rank by register broadcast on one wave.
+// Measured (profiles/r03/r03_launch_order.txt): chunks of 64 / 128 / 256 -> 106.0 / 106.5 / 110.1 us per 1024-instance
+// call against 107.3 with the ranking kernel: the selection sits on every workgroup's critical path, so the cheapest
+// one wins although its balance is the coarsest.
+// The order only steers speed: records do not depend on it (tests/test_gpu_parity.py::test_launch_order_is_invisible).
+// ------------------------------------------------------------------------------------------
+#ifndef LA3D_ORDER_CHUNK
+#define LA3D_ORDER_CHUNK 64
+#endif
+constexpr int ORDER_CHUNK = LA3D_ORDER_CHUNK;   // instances ranked together: 64 keys per wave on ORDER_CHUNK / 64 waves
+constexpr int KEY_IDX_BITS = 14;    // sort key = (area quantised to 18 bits) << 14 | (16383 - instance): unique, and a
+                                    // plain unsigned compare orders by area descending, then index ascending
+constexpr int ORDER_MAX_B = 1 << KEY_IDX_BITS;
+
+__device__ inline unsigned make_order_key(int area, int shift, int inst) {
+  unsigned q = (unsigned)(area < 0 ? 0 : area) >> shift;
+  if (q > 0x3ffffu) q = 0x3ffffu;
+  return (q << KEY_IDX_BITS) | (unsigned)((1 << KEY_IDX_BITS) - 1 - inst);
+}
+
+// every thread of the workgroup calls it (one barrier); returns the instance of block b, wave-uniform
+__device__ inline int order_select(const FitParams& p, int b, Shared* sh, int wave, int lane) {
+  const int R = p.B < p.order_resident ? p.B : p.order_resident;
+  int grank = b;
+  if (b < R) {   // invert: group 0 ascending CU index, every later group descending
+    const int g = b >> 8, ng = (R - (g << 8)) < 256 ? (R - (g << 8)) : 256;
+    grank = (g << 8) + (g >= 1 ? ng - 1 - (b & 255) : (b & 255));
+  }
+  const int nch = p.order_nch;
+  const int lr = grank / nch, c = grank - lr * nch;        // rank in chunk, chunk
+  const int per = p.B / nch, rem = p.B - per * nch;
+  const int start = c * per + (c < rem ? c : rem), size = per + (c < rem ? 1 : 0);
+  if (wave < ORDER_CHUNK / 64) {
+    unsigned k[ORDER_CHUNK / 64];
+#pragma unroll
+    for (int h = 0; h < ORDER_CHUNK / 64; ++h) {
+      const int l = h * 64 + lane;
+      k[h] = 0u;   // key 0 never counts as larger
+      if (l < size) k[h] = p.area_hint ? make_order_key(p.area_hint[start + l], p.order_shift, start + l) : p.order_keys[start + l];
+    }
+    unsigned mine = k[0];
+#pragma unroll
+    for (int h = 1; h < ORDER_CHUNK / 64; ++h) mine = wave == h ? k[h] : mine;
+    int rank = 0;
+#pragma unroll
+    for (int h = 0; h < ORDER_CHUNK / 64; ++h)
+#pragma unroll
+      for (int t = 0; t < 64; ++t) rank += ((unsigned)__builtin_amdgcn_readlane((int)k[h], t) > mine) ? 1 : 0;
+    if (wave * 64 + lane < size && rank == lr) sh->order_inst = start + wave * 64 + lane;
+  }
+  __syncthreads();
+  return __builtin_amdgcn_readfirstlane(sh->order_inst);
+}
+
+// ------------------------------------------------------------------------------------------
 // instance engine: one workgroup per instance
 // ------------------------------------------------------------------------------------------
 // SRC: where the mask comes from - 0 = u8 plane, 1 = COCO run lengths, 2 = polygon parts (both decoded into the LDS bit image)
@@ -445,7 +512,7 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : NT / 64) void fit_instance
   // youngest of the four workgroups of a CU gets its first load - this perm entry - back only when an older one has finished
   // its mask stream, ~25 us in; warming the table through L1 does not help, and s_setprio by dispatch group only moves the
   // starvation to the oldest group, which holds the largest instances: DESIGN.md section 5.2)
-  const int inst = p.perm ? p.perm[blockIdx.x] : xcd_remap(blockIdx.x, p.B);
+  const int inst = p.order_nch > 0 ? order_select(p, (int)blockIdx.x, sh, wave, lane) : xcd_remap(blockIdx.x, p.B);
   const int img = p.image_index ? p.image_index[inst] : inst;
   const int HW = p.HW;
   const float* dpl = p.depth + (long long)img * p.depth_plane_stride;
@@ -1937,23 +2004,13 @@ void allow_big_lds(const void* fn, int bytes = 160 * 1024) {
 constexpr int MAX_MASK_LDS = 128 * 1024;  // bit image budget; larger frames re-read the u8 mask instead
 
 // ------------------------------------------------------------------------------------------
-// launch order.  Measured on MI355X (profiles/microbench/wg_census.hip, profiles/exp_chain.py): workgroup b of a
-// fresh grid starts on CU b % 256 (XCD b % 8), so with G workgroups resident per CU the instances of blocks
-// {c, c+256, ..., c+(G-1)*256} share CU c for their whole life, and the fit passes are VALU-bound per CU: the
-// launch lasts as long as the most loaded CU.  With random sizes that CU carries ~2x the mean.  Two small kernels
-// estimate each instance's mask area and hand out blocks so that every CU gets a balanced set: rank r of the descending
-// order -> group r/256; group 0 goes to CUs 0..255 in order, every later group in reverse, so the CU that holds the largest
-// instance (whose chain is the launch's critical path) gets the smallest member of every other group (measured 1-1.5 %
-// better than alternating directions); ranks beyond the resident set follow in descending order (longest-first list
-// scheduling for the dynamically placed remainder).  Same multiset of sizes on B=1024:
-// 152 us unordered, 113 us snake-ordered (host-arranged), 196 us worst case.
+// launch order (see order_select above): the one helper kernel left estimates every instance's mask area - one wave per
+// instance, spread over the whole chip (eight workgroups pulling the samples through eight CUs take 2x longer than the
+// fit saves: profiles/r03/r03_launch_order.txt) - and writes a sort key per instance.
 // ------------------------------------------------------------------------------------------
 constexpr int EST_STEP = 37;        // area estimate: every 37th 128-byte line of the plane (37 is coprime to W/128 = 5, 10,
                                     // 15: the lattice visits every column block); small frames take a smaller prime so
                                     // that at least 64 lines are sampled
-constexpr int ORDER_MAX_B = 16384;  // the ranking is O(B^2 / lanes); beyond this dynamic placement averages well enough
-constexpr int KEY_IDX_BITS = 14;    // sort key = (area quantised to 18 bits) << 14 | (16383 - instance): unique, and a
-                                    // plain unsigned compare orders by area descending, then index ascending
 
 __global__ __launch_bounds__(256) void size_estimate_kernel(const unsigned char* __restrict__ mask,
                                                             const int* __restrict__ rle_counts,
@@ -2004,62 +2061,7 @@ __global__ __launch_bounds__(256) void size_estimate_kernel(const unsigned char*
   }
   c = wave_sum_i(c);
   if (lane == 0) {
-    unsigned q = (unsigned)c >> shift;
-    if (q > 0x3ffffu) q = 0x3ffffu;
-    keys[inst] = (q << KEY_IDX_BITS) | (unsigned)((1 << KEY_IDX_BITS) - 1 - inst);
-  }
-}
-
-// rank = number of larger keys.  64 instances per workgroup (one per lane); each of the 16 waves counts over a
-// sixteenth of the batch, 64 keys at a time: coalesced loads issued up front, then register broadcasts
-// (v_readlane) - no dependent memory access inside the counting loop.
-constexpr int ORDER_WAVES = 16;
-// sort key of instance j: from the estimate kernel's table, or built on the fly from a caller-supplied area (la3d_fit_args::area_hint)
-__device__ inline unsigned order_key(const unsigned* __restrict__ keys, const int* __restrict__ area, int shift, int j) {
-  if (!area) return keys[j];
-  const int a = area[j];
-  unsigned q = (unsigned)(a < 0 ? 0 : a) >> shift;
-  if (q > 0x3ffffu) q = 0x3ffffu;
-  return (q << KEY_IDX_BITS) | (unsigned)((1 << KEY_IDX_BITS) - 1 - j);
-}
-
-__global__ __launch_bounds__(ORDER_WAVES * 64) void launch_order_kernel(const unsigned* __restrict__ keys, int B, int resident,
-                                                                        int* __restrict__ perm, const int* __restrict__ area = nullptr,
-                                                                        int shift = 0) {
-  __shared__ int part[ORDER_WAVES][64];
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int i = blockIdx.x * 64 + lane;
-  const unsigned mine = i < B ? order_key(keys, area, shift, i) : 0xffffffffu;
-  const int chunk = (((B + ORDER_WAVES - 1) / ORDER_WAVES) + 63) & ~63;
-  const int j0 = w * chunk, j1 = (j0 + chunk < B) ? j0 + chunk : B;
-  int cnt = 0;
-  for (int j = j0; j < j1; j += 256) {
-    unsigned v[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = (j + k * 64 + lane < j1) ? order_key(keys, area, shift, j + k * 64 + lane) : 0u;  // key 0 never counts
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (j + k * 64 < j1) {  // wave-uniform
-#pragma unroll
-        for (int t = 0; t < 64; ++t) cnt += ((unsigned)__builtin_amdgcn_readlane((int)v[k], t) > mine) ? 1 : 0;
-      }
-    }
-  }
-  part[w][lane] = cnt;
-  __syncthreads();
-  if (w == 0 && i < B) {
-    int rank = 0;
-#pragma unroll
-    for (int k = 0; k < ORDER_WAVES; ++k) rank += part[k][lane];
-    int blk = rank;
-    const int R = B < resident ? B : resident;
-    if (rank < R) {
-      const int g = rank >> 8, pos = rank & 255;
-      const int ng = (R - (g << 8)) < 256 ? (R - (g << 8)) : 256;
-      blk = (g << 8) + (g >= 1 ? ng - 1 - pos : pos);   // group 0 ascending CU index, every later group descending
-    }
-    perm[blk] = i;
+    keys[inst] = make_order_key(c, shift, inst);
   }
 }
 
@@ -2083,7 +2085,7 @@ int launch_fit_inst(const FitParams& p_in, size_t lds, hipStream_t s, void* work
   auto kern = fit_instances_kernel<VEC, LDSMASK, SAMPLE, TILED, SRC, RET>;
   allow_big_lds(reinterpret_cast<const void*>(kern));
   FitParams p = p_in;
-  p.perm = nullptr;
+  p.order_nch = 0; p.order_keys = nullptr; p.order_resident = 0; p.order_shift = 0;
   // size-balanced launch order: needs the 16-byte mask groups (VEC), more than one workgroup per CU, and a batch
   // the O(B^2) ranking is cheap for
   if (workspace && VEC && !SAMPLE && p.B > 256 && p.B <= ORDER_MAX_B && balance_enabled()) {
@@ -2092,27 +2094,25 @@ int launch_fit_inst(const FitParams& p_in, size_t lds, hipStream_t s, void* work
     const int by_lds = (int)((160 * 1024) / (lds ? lds : 1));
     if (by_lds < wg_per_cu) wg_per_cu = by_lds;
     if (wg_per_cu >= 1 && p.B <= max_rounds * wg_per_cu * 256) {
-      unsigned* est = static_cast<unsigned*>(workspace);  // [B] area estimates, then [B] block -> instance
-      int* perm = reinterpret_cast<int*>(est + p.B);
-      // quantise the area to 18 bits: run lengths give the exact area (<= HW), the byte lattice about HW / 67
-      int step = 1;
-      for (int cand : {EST_STEP, 31, 17, 7, 3})
-        if ((p.HW >> 7) / cand >= 64) { step = cand; break; }
-      long long amax = (p.rle_counts || p.poly_xy) ? (long long)p.HW : (long long)p.HW / step + 128;
-      int shift = 0;
-      while ((amax >> shift) > 0x3ffff) ++shift;
-      if (p.area_hint) {   // the caller knows the mask areas (annotation metadata, a preceding filter): no estimate pass
-        int hshift = 0;
-        while (((long long)p.HW >> hshift) > 0x3ffff) ++hshift;
-        hipLaunchKernelGGL(launch_order_kernel, dim3((p.B + 63) / 64), dim3(ORDER_WAVES * 64), 0, s, est, p.B, wg_per_cu * 256,
-                           perm, p.area_hint, hshift);
+      p.order_nch = (p.B + ORDER_CHUNK - 1) / ORDER_CHUNK;
+      p.order_resident = wg_per_cu * 256;
+      p.order_shift = 0;
+      p.order_keys = nullptr;
+      if (p.area_hint) {   // the caller knows the mask areas (annotation metadata, a preceding filter): no helper launch at all
+        while (((long long)p.HW >> p.order_shift) > 0x3ffff) ++p.order_shift;
       } else {
+        unsigned* est = static_cast<unsigned*>(workspace);  // [B] sort keys
+        // quantise the area to 18 bits: run lengths give the exact area (<= HW), the byte lattice about HW / 67
+        int step = 1;
+        for (int cand : {EST_STEP, 31, 17, 7, 3})
+          if ((p.HW >> 7) / cand >= 64) { step = cand; break; }
+        long long amax = (p.rle_counts || p.poly_xy) ? (long long)p.HW : (long long)p.HW / step + 128;
+        int shift = 0;
+        while ((amax >> shift) > 0x3ffff) ++shift;
         hipLaunchKernelGGL(size_estimate_kernel, dim3((p.B + 3) / 4), dim3(256), 0, s, p.mask, p.rle_counts, p.rle_offsets, p.poly_xy,
                            p.poly_ring_off, p.poly_inst_rings, p.B, p.HW, step, shift, est);
-        hipLaunchKernelGGL(launch_order_kernel, dim3((p.B + 63) / 64), dim3(ORDER_WAVES * 64), 0, s, est, p.B, wg_per_cu * 256,
-                           perm);
+        p.order_keys = est;
       }
-      p.perm = perm;
     }
   }
   hipLaunchKernelGGL(kern, dim3(p.B), dim3(NT), lds, s, p);
@@ -2169,7 +2169,7 @@ int la3d_set_launch_order(int mode) {
 }
 
 // Workspace layout (one per concurrently running call; contents need not be initialised or preserved):
-//   instance engine: [B] u32 sort keys, then [B] i32 block -> instance (the size-balanced launch order; 8*B bytes)
+//   instance engine: [B] u32 sort keys of the size-balanced launch order (4*B bytes)
 //   split engine:    [B][GEO_D] f64 geometry, then bit images, tile lists and partial-sum slots (split_workspace_bytes)
 size_t la3d_workspace_bytes(int B, int H, int W) {
   if (B <= 0) return 0;
@@ -2269,7 +2269,7 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   p.out = out; p.status = status; p.aux = aux;
   p.ntx = p.nty = p.tiles_per_wave = p.list_cap = 0;
   p.rcp_ntx = 1.0f;
-  p.perm = nullptr;
+  p.order_nch = 0; p.order_keys = nullptr; p.order_resident = 0; p.order_shift = 0;
   p.lds_keep_off = 0;
   p.stagger_ticks = 0;
   p.filter_boundary = -1; p.filter_min_area = 0; p.filter_max_edge = 0; p.filter_stats = nullptr;

@@ -426,7 +426,12 @@ struct FitParams {
   int tiles_per_wave;  // TILED: ceil(ntx*nty / NWAVE)
   int list_cap;        // TILED: entries of the active-tile list that fit the LDS budget
   float rcp_ntx;       // TILED: 1 / ntx
-  const int* perm;     // launch order: workgroup b fits instance perm[b] (nullptr: xcd_remap(b))
+  // size-balanced launch order (order_nch > 0; otherwise workgroup b fits instance xcd_remap(b)): sort keys per instance from
+  // the estimate kernel, or built on the fly from area_hint; every workgroup ranks the <= ORDER_CHUNK keys of its chunk itself
+  const unsigned* order_keys;
+  int order_nch;       // chunks of consecutive instances (ceil(B / ORDER_CHUNK)), 0 = launch order off
+  int order_resident;  // workgroups of the grid that are resident at once
+  int order_shift;     // area_hint >> order_shift fits 18 bits
   int lds_keep_off;    // retaining build: byte offset in dynamic LDS of the per-wave kept step (0: none)
   int stagger_ticks;   // retaining build: the second-dispatched workgroup of every CU starts this many 100 MHz ticks late (0: off)
   // instance filter fused into the fit (run-length / polygon input): boundary < 0 = off
@@ -459,7 +464,7 @@ struct alignas(16) Shared {
   int redo;        // optimistic pass A met a non-finite masked depth: run the checked passes
   double gap;      // relative eigenvalue gap (aux[3]), kept for the deferred aux write
   int nm;          // mask pixels (aux[2])
-  int pad;
+  int order_inst;  // the instance this workgroup fits (size-balanced launch order)
 #ifdef LA3D_TIMELINE
   double* tl;      // measurement build: this workgroup's stamp row (profiles/timeline.py)
 #endif

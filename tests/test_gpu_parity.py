@@ -617,16 +617,18 @@ def test_launch_order_is_invisible(la, B, monkeypatch):
         monkeypatch.setenv("LA3D_BALANCE", flag)
         f = InstanceFitter(B, H, W, torch.device("cuda", 0))
         f.workspace.zero_()
+        # poison the outputs: the order is decided inside the fit kernel (every workgroup ranks the keys of its chunk, round 3),
+        # so "it is a permutation" shows as "every record was written" - a skipped instance would keep the poison
+        f.boxes.fill_(12345.0); f.status.fill_(-1); f.aux.fill_(12345.0)
         b, s, a = f.run(depth, masks, torch.as_tensor(K, device="cuda"))
         torch.cuda.synchronize()
         out[flag] = (b.clone(), s.clone(), a.clone())
-        if flag == "1":  # the order the library chose is a permutation, largest estimated area first
-            ws = f.workspace[0][: 8 * B].view(torch.int32).cpu().numpy()
-            keys, perm = ws[:B].astype(np.int64), ws[B:]
-            assert sorted(perm.tolist()) == list(range(B))
+        assert int((s < 0).sum()) == 0 and not bool((b == 12345.0).any()) and not bool((a == 12345.0).any())
+        if flag == "1":  # the sort keys the estimate kernel left in the workspace: area (18 bits) | 16383 - instance
+            keys = f.workspace[0][: 4 * B].view(torch.int32).cpu().numpy().astype(np.int64)
+            assert ((keys & 16383) == 16383 - np.arange(B)).all()
             area = (m.reshape(B, -1) != 0).sum(1)
             assert np.corrcoef(keys >> 14, area)[0, 1] > 0.9
-            assert area[perm[0]] >= np.percentile(area, 99) * 0.8
     for x, y in zip(out["0"], out["1"]):
         assert torch.equal(x, y, ) or torch.equal(torch.nan_to_num(x, nan=-7.0), torch.nan_to_num(y, nan=-7.0))
     assert int(out["1"][1][5]) == 1 and int((out["1"][1] != 0).sum()) == 1
