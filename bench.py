@@ -270,7 +270,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # LA3D_BENCH_FORCE_DIST=1: initialise torch.distributed even for one rank, so that the RCCL branch (device-tensor gather,
+    # timing all-reduces) can be executed on a single-GPU box (tests/test_gpu_shard.py)
+    if world > 1 or os.environ.get("LA3D_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -520,7 +522,7 @@ def main():
                 "frame": [H, W],
                 "mean_mask_occupancy": n_masked / (B * H * W),
                 "active_tiles_per_instance": active_tiles / B,
-                "sharding": ("single GPU" if world == 1 else "instances sharded per rank, one final RCCL gather of box records"
+                "sharding": ("single GPU" if dist is None else "instances sharded per rank, one final RCCL gather of box records"
                              if dist.get_backend() == "nccl" else
                              f"DRY RUN: {world} ranks sharing one GPU through {dist.get_backend()} (functional check of the multi-rank path, not a measurement)"),
                 "mask_input": ("COCO run lengths (la3d_fit_instances_rle) — not the config-2 format" if args.rle else

@@ -116,7 +116,13 @@ def gather_boxes(boxes: torch.Tensor, status: torch.Tensor, dst: int = 0, group=
             gb = gs = None
         dist.gather(pb, gb, dst=dst, group=group)
         dist.gather(ps, gs, dst=dst, group=group)
-    except (RuntimeError, NotImplementedError):  # a backend without gather: every rank collects, dst keeps
+    except (RuntimeError, NotImplementedError) as e:
+        # ONLY a backend that has no gather at all: every rank collects, dst keeps.  Anything else (a failed RCCL call, a
+        # mismatched shape) must surface - falling back would hide the error and double the traffic.
+        msg = str(e).lower()
+        if not (isinstance(e, NotImplementedError) or "not supported" in msg or "not implemented" in msg or
+                "does not support" in msg or "no backend" in msg):
+            raise
         gb = [torch.empty_like(pb) for _ in range(world)]
         gs = [torch.empty_like(ps) for _ in range(world)]
         dist.all_gather(gb, pb, group=group)

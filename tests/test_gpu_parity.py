@@ -588,6 +588,66 @@ def test_g7_tie_fixtures_on_gpu(la, golden):
     np.testing.assert_array_equal(np.concatenate([c, d, R.ravel(), v.ravel()]), boxes[by["grid27"]])
 
 
+def test_config1_single_image_single_instance(la, golden, monkeypatch):
+    """BASELINE config 1: ONE 640x480 image, ONE instance, against the reference's own output (g14_config1.npz,
+    generated by tests/golden/make_golden_config1.py from src/util.py:52-75 + src/util_3dbox.py:106-178): (1) the literal
+    composition estimate_bbox(depth_to_points(depth[None], K)[mask], None, ground) through the drop-ins, global RNG seeded as
+    the reference was; (2) the batched entry with B = 1 - which the library routes to the split engine - and with each engine
+    pinned; (3) the whole-frame unprojection at the picked pixels."""
+    from labelany3d_amd import util_3dbox as U
+    from labelany3d_amd.util import depth_to_points
+
+    from tests.test_oracle_golden import config1_inputs
+
+    g = golden("g14_config1.npz")
+    depth, masks = config1_inputs(g)
+    K, ground = g["K"], g["ground"]
+    pts = depth_to_points(depth[None], K)
+    assert pts.shape == (480, 640, 3) and pts.dtype == np.float64
+    np.testing.assert_allclose(pts.reshape(-1, 3)[g["pts_pick"]], g["pts_out"], rtol=1e-13, atol=1e-13)
+    for i in range(3):
+        n = int(g["n_masked"][i])
+        for j, gr in enumerate((None, ground)):
+            want = g["out"][i, j][None]
+            np.random.seed(int(g["rng_seed"][i, j]))
+            v, c, d, R, _ = _run_estimate(U, pts[masks[i]], gr, "pca")
+            assert isinstance(d, list) and v.shape == (8, 3)
+            assert_records(O.pack39(v, c, d, R)[None], want, f"config1 drop-in mask{i} ground{j}")
+            si = g["sample_idx"][i, j][None] if n > 500 else None
+            for eng in (None, "split", "instance"):
+                if eng is None:
+                    monkeypatch.delenv("LA3D_ENGINE", raising=False)
+                else:
+                    monkeypatch.setenv("LA3D_ENGINE", eng)
+                boxes, status, aux = la.fit_instances(depth[None], masks[i:i + 1], K, ground=None if gr is None else gr[None],
+                                                      sample_idx=si)
+                assert np_(status).tolist() == [0] and int(np_(aux)[0, 2]) == n
+                assert_records(np_(boxes), want, f"config1 B=1 engine={eng} mask{i} ground{j}")
+    monkeypatch.delenv("LA3D_ENGINE", raising=False)
+
+
+def test_g15_near_tie_sweep_on_gpu(la, golden):
+    """Reference records for footprints with a relative eigen-gap of 1e-7 .. 1e-2 (n = 240: scikit-learn's covariance_eigh
+    branch): the closed-form axis of the kernels must follow the reference within the eigenvector's own conditioning,
+    a few 1e-14 / gap - the quantity `assert_records` gates R_cam on.  Both point-cloud kernels (one wave / one workgroup per
+    cloud) and the drop-in."""
+    from labelany3d_amd.util_3dbox import estimate_bbox
+
+    g = golden("g15_near_ties.npz")
+    clouds = [pc for pc in g["pcs"]]
+    for small in (True, False):
+        boxes, status, aux = la.fit_points(clouds, small_clouds=small)
+        boxes, aux = np_(boxes), np_(aux)
+        assert (np_(status) == 0).all()
+        for k, (ref, gap, yaw) in enumerate(zip(g["out"], g["gap"], g["yaw"])):
+            tol = max(1e-9, 5e-14 / gap)
+            np.testing.assert_allclose(boxes[k, :15], ref[:15], rtol=0, atol=tol, err_msg=f"gap {gap} yaw {yaw} small={small}")
+            assert abs(aux[k, 0] - yaw) < tol and aux[k, 3] == pytest.approx(gap, rel=0.05)
+    v, c, d, R = estimate_bbox(clouds[0])
+    np.testing.assert_allclose(np.concatenate([c, d, R.ravel()]), g["out"][0][:15], rtol=0, atol=5e-14 / g["gap"][0])
+
+
+
 # ------------------------------------------------------------------------------------------
 # size-balanced launch order (instance engine, 256 < B <= 3 resident sets): which workgroup fits which
 # instance must not change a single bit of any record

@@ -283,3 +283,81 @@ def test_bench_multi_rank_path_two_ranks_one_gpu():
     assert abs(d["value"] - 2 * 6 * 512 / (d["ms_per_step"] * 1e-3 * 6)) < 1e-6 * d["value"]     # whole-job aggregate over both ranks
     assert "DRY RUN" in d["config"]["sharding"] and "cpu_baseline" not in d
     assert 0 < d["roofline"]["frac"] < 1
+
+
+_NCCL_WORKER = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import bench
+import labelany3d_amd as la
+from labelany3d_amd.shard import fit_instances_sharded, gather_boxes
+
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == "nccl"
+depth, masks, K, _, image_index = bench.make_config3(12, dev, 77)
+B = masks.shape[0]
+want = la.fit_instances(depth, masks, K, image_index=image_index)
+got = fit_instances_sharded(depth, masks, K, image_index)          # plan -> local fit -> RCCL gather of DEVICE tensors
+assert got is not None and got[0].is_cuda and got[1].is_cuda and got[2] == [B]
+assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+# the gather on its own: ragged payloads are what the other ranks would send; with one rank it must be the identity, on the device
+gb = gather_boxes(want[0][:7].contiguous(), want[1][:7].contiguous(), dst=0)
+assert gb[0].is_cuda and torch.equal(gb[0], want[0][:7]) and gb[2] == [7]
+empty = gather_boxes(want[0][:0].contiguous(), want[1][:0].contiguous(), dst=0)
+assert empty[0].shape == (0, 39) and empty[2] == [0]
+t = torch.ones(1, device=dev)
+dist.all_reduce(t)
+dist.barrier()
+dist.destroy_process_group()
+print("NCCL_OK", B)
+"""
+
+
+def test_rccl_branch_world_size_one(tmp_path):
+    """The RCCL code path itself (backend "nccl" IS RCCL on ROCm): a one-rank process group on the one GPU runs
+    fit_instances_sharded + gather_boxes with DEVICE tensors (no host staging, dist.gather / all_gather on RCCL) - the branch the
+    gloo tests never touch.  No scaling claim; it proves the calls, dtypes and shapes are accepted by the real backend."""
+    import subprocess
+    import sys
+
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "nccl_worker.py"
+    script.write_text(_NCCL_WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, str(script), root, str(_free_port())], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=root)
+    assert r.returncode == 0 and "NCCL_OK" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_bench_rccl_branch_one_rank():
+    """bench.py through its `dist is not None` branch on RCCL with WORLD_SIZE=1 (LA3D_BENCH_FORCE_DIST=1): communicator
+    warm-up, barriers, the gather of all records inside the timed region and the MAX all-reduces run on the device."""
+    import json
+    import subprocess
+    import sys
+
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LA3D_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0",
+               LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("LA3D_BENCH_BACKEND", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--batch", "512",
+           "--no-cpu-baseline", "--no-pipelined"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and "RCCL gather" in d["config"]["sharding"]
+    assert 0 < d["roofline"]["frac"] < 1
