@@ -73,7 +73,7 @@ int main(int argc, char** argv) {
     a.struct_size = (int32_t)sizeof(a);
     a.B = B; a.H = H; a.W = W;
     a.depth = d_depth; a.depth_plane_stride = (int64_t)HW; a.mask = d_mask; a.K = d_K; a.k_stride = 0; a.ground = d_ground;
-    a.filter_boundary = -1;
+    // (a zero-initialised block means: no fused instance filter, no area hints, no 2-D boxes unless proj is set)
     a.proj = d_proj; a.image_width = W; a.image_height = H;
     a.out = d_out2; a.status = d_status; a.aux = d_aux; a.workspace = d_ws; a.stream = stream;
     if (la3d_fit_instances_ex(&a) != LA3D_SUCCESS) { fprintf(stderr, "la3d_fit_instances_ex: %s\n", la3d_last_error()); return 6; }

@@ -84,6 +84,8 @@ int la3d_mask_counts(const uint8_t* mask, int B, int H, int W, int32_t* counts, 
  * it off: the batches then overlap their memory-bound and compute-bound phases by themselves (measured +20 %), and an
  * order computed for an idle chip only gets in the way.  Records never depend on it. */
 int la3d_set_launch_order(int mode);
+/* The mode la3d_set_launch_order last set (-1 / 0 / 1), so that a scoped user can restore it. */
+int la3d_get_launch_order(void);
 
 /* Bytes of device scratch la3d_fit_instances needs for (B,H,W); may be 0. */
 size_t la3d_workspace_bytes(int B, int H, int W);
@@ -178,7 +180,9 @@ int la3d_fit_instances_poly_filtered(const float* depth, int64_t depth_plane_str
 
 /* ---- one extensible entry: every option of the fit calls above, plus the 2-D boxes of the records -----------------
  * Exactly one of mask / rle_counts(+rle_offsets) / poly_xy(+ring_offsets, inst_rings) gives the masks.  filter_boundary >= 0
- * switches the fused instance filter on (run-length / polygon masks; see the *_filtered entry points).  proj != NULL adds
+ * together with filter_max_edge > 0 switches the fused instance filter on (run-length / polygon masks; see the *_filtered
+ * entry points); a zero-initialised block (`la3d_fit_args a = {0}`) therefore means NO filter, and so does
+ * filter_boundary = -1.  proj != NULL adds
  * la3d_project_boxes' output for every record - bbox2D_proj (4) and bbox2D_trunc (4), reference
  * src/tools/combine_results.py:105-108, :238-252 - written by the same epilogue that writes the record (rejected / dropped
  * instances: 8 NaNs); image_width / image_height are the clamp limits.  struct_size = sizeof(la3d_fit_args) of the caller:
@@ -191,7 +195,7 @@ typedef struct la3d_fit_args {
   const int32_t* rle_counts; const int64_t* rle_offsets;
   const int32_t* poly_xy; const int64_t* ring_offsets; const int64_t* inst_rings;
   const double* K; int32_t k_stride;
-  int32_t filter_boundary, filter_min_area, filter_max_edge;   /* filter_boundary < 0: no filter */
+  int32_t filter_boundary, filter_min_area, filter_max_edge;   /* filter_boundary < 0 or filter_max_edge <= 0: no filter */
   const double* ground; const int32_t* sample_idx;
   int32_t* stats;                                              /* [B][4] | NULL (filter) */
   double* proj; double image_width, image_height;              /* [B][8] | NULL */

@@ -35,6 +35,7 @@ _SIGS = {
     "la3d_version": (C.c_int, []),
     "la3d_last_error": (C.c_char_p, []),
     "la3d_set_launch_order": (C.c_int, [C.c_int]),
+    "la3d_get_launch_order": (C.c_int, []),
     "la3d_unproject": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_int,
                                  C.c_void_p, C.c_int, C.c_void_p]),
     "la3d_unproject_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int,

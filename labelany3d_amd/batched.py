@@ -31,7 +31,7 @@ def _dev(device=None) -> torch.device:
 _SMALL_UPLOADS: dict = {}   # (bytes, dtype, shape, device) -> device tensor: small host arrays that callers pass again and again (K)
 
 
-def _as_dev(x, dtype, device) -> torch.Tensor:
+def _as_dev(x, dtype, device, cache: bool = False) -> torch.Tensor:
     if isinstance(x, torch.Tensor):
         t = x
         if t.dtype == torch.bool and dtype == torch.uint8:
@@ -44,15 +44,19 @@ def _as_dev(x, dtype, device) -> torch.Tensor:
     a = np.asarray(x)
     if dtype == torch.uint8 and a.dtype == np.bool_:
         a = a.view(np.uint8)
-    if a.nbytes <= 1024:   # e.g. the 3x3 intrinsics: one upload per distinct value instead of one per call
+    if cache and a.nbytes <= 1024:   # opt-in (the 3x3 intrinsics): one upload per distinct value instead of one per call
         key = (a.tobytes(), str(a.dtype), a.shape, dtype, str(device))
-        t = _SMALL_UPLOADS.get(key)
-        if t is None:
+        hit = _SMALL_UPLOADS.get(key)
+        if hit is None:
             if len(_SMALL_UPLOADS) > 256:
                 _SMALL_UPLOADS.clear()
             t = torch.as_tensor(np.ascontiguousarray(a), device=device).to(dtype).contiguous()
-            _SMALL_UPLOADS[key] = t
-        return t
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(device))       # the upload / conversion runs on the stream current NOW
+            hit = _SMALL_UPLOADS[key] = (t, ev)
+        t, ev = hit
+        torch.cuda.current_stream(device).wait_event(ev)          # a later user on another stream is ordered behind the upload
+        return t                                                  # read-only by contract: shared between callers
     return torch.as_tensor(np.ascontiguousarray(a), device=device).to(dtype).contiguous()
 
 
@@ -60,7 +64,20 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def _stream(stream=None):
+def _order(stream) -> None:
+    """A caller-supplied stream that is not the current one is ordered behind the current stream: the convenience wrappers
+    upload / convert their arguments (and reuse the cached small uploads of _as_dev) on the CURRENT stream."""
+    if stream is not None:
+        cur = torch.cuda.current_stream()
+        if stream != cur:
+            stream.wait_stream(cur)
+
+
+def _stream(stream=None, raw: bool = False):
+    """The launch stream as a C handle.  raw=True (InstanceFitter.run: a pure enqueue whose inputs the caller has made ready on
+    `stream`, e.g. batches pipelined on several streams) skips the ordering of _order()."""
+    if not raw:
+        _order(stream)
     s = torch.cuda.current_stream() if stream is None else stream
     return C.c_void_p(s.cuda_stream)
 
@@ -75,10 +92,13 @@ def _record(stream, *tensors):
             t.record_stream(stream)
 
 
-def set_launch_order(mode) -> None:
+def set_launch_order(mode):
     """Size-balanced launch order of the batched fit (see include/la3d.h): ``True`` / ``False`` / ``None`` (= default: on).
-    Turn it off when independent batches are pipelined on several streams."""
+    Turn it off when independent batches are pipelined on several streams.  Returns the previous setting (same encoding), so a
+    scoped user can put it back."""
+    prev = int(lib.la3d_get_launch_order())
     check(lib.la3d_set_launch_order(-1 if mode is None else int(bool(mode))), "la3d_set_launch_order")
+    return None if prev < 0 else bool(prev)
 
 
 def unpack_boxes(rec):
@@ -145,7 +165,7 @@ class InstanceFitter:
         rc = lib.la3d_fit_instances(_ptr(depth), dstride, _ptr(image_index), _ptr(masks), _ptr(K), kstride,
                                     _ptr(ground), _ptr(sample_idx), B, H, W, _ptr(self.boxes[slot]),
                                     _ptr(self.status[slot]), _ptr(self.aux[slot]), _ptr(self.workspace[ws_slot]),
-                                    _stream(stream))
+                                    _stream(stream, raw=True))
         check(rc, "la3d_fit_instances")
         return self.boxes[slot], self.status[slot], self.aux[slot]
 
@@ -173,7 +193,7 @@ def fit_instances(depth, masks, K, ground=None, sample_idx=None, image_index=Non
         d = d[None]
     if d.shape[1:] != (H, W):
         raise ValueError(f"depth planes {tuple(d.shape[1:])} do not match masks {(H, W)}")
-    k = _as_dev(K, torch.float64, dev)
+    k = _as_dev(K, torch.float64, dev, cache=True)
     if k.dim() == 2:
         k = k[None]
     P = d.shape[0]
@@ -204,6 +224,7 @@ def fit_instances(depth, masks, K, ground=None, sample_idx=None, image_index=Non
             return f.boxes[0], f.status[0], f.aux[0]
         if k.shape[0] == 1 and P > 1:
             k = k.expand(P, 3, 3).contiguous()
+        _order(stream)   # the arguments were uploaded / converted on the current stream
         out = f.run(d if P > 1 else d[0], m, k, g, si, ii, stream=stream)
         _record(stream, d, m, k, g, si, ii, f.workspace, f.boxes, f.status, f.aux)
         return out
@@ -257,7 +278,7 @@ def unproject(depth, K, R=None, t=None, out_dtype=torch.float64, stream=None, de
     d = _as_dev(depth, torch.float32, dev)
     if d.dim() == 3:
         P, H, W = d.shape
-        k = _as_dev(K, torch.float64, dev).reshape(-1, 9)
+        k = _as_dev(K, torch.float64, dev, cache=True).reshape(-1, 9)
         if k.shape[0] not in (1, P):
             raise ValueError("K must be (3,3) or (P,3,3)")
         Rt = None

@@ -16,7 +16,7 @@ def project_boxes(boxes, K, image_size, image_index=None, stream=None) -> torch.
     [0,W]x[0,H]); image_size = (W, H) as in the reference (:233-252).  K (3,3) or (P,3,3) with image_index."""
     dev = boxes.device if isinstance(boxes, torch.Tensor) and boxes.is_cuda else _dev()
     b = _as_dev(boxes, torch.float64, dev)
-    k = _as_dev(K, torch.float64, dev)
+    k = _as_dev(K, torch.float64, dev, cache=True)
     if k.dim() == 2:
         k = k[None]
     B = b.shape[0]

@@ -2159,6 +2159,8 @@ const char* la3d_last_error(void) { return g_err; }
 
 double la3d_f16_round_host(double x) { return f16_round(x); }
 
+int la3d_get_launch_order(void) { return g_launch_order.load(std::memory_order_relaxed); }
+
 int la3d_set_launch_order(int mode) {
   if (mode < -1 || mode > 1) {
     set_err("la3d_set_launch_order: mode must be -1 (default), 0 (off) or 1 (on)");
@@ -2461,11 +2463,14 @@ int la3d_fit_instances_ex(const la3d_fit_args* args) {
     return LA3D_ERR_ARG;
   }
   const PolyArgs pa{a.poly_xy, a.ring_offsets, a.inst_rings};
+  // the fused filter is on when filter_boundary >= 0 AND filter_max_edge > 0: a zero-initialised block (the natural C idiom, and
+  // what "missing fields are zero" gives) means NO filter - max_edge == 0 would reject every instance (edge < 0 never holds)
+  const bool filter_on = a.filter_boundary >= 0 && a.filter_max_edge > 0;
   const FilterArgs fa{a.filter_boundary, a.filter_min_area, a.filter_max_edge, a.stats};
   const ProjArgs pr{a.proj, a.image_width, a.image_height};
   return fit_dispatch(a.depth, a.depth_plane_stride, a.image_index, a.mask, a.rle_counts, a.rle_offsets, a.K, a.k_stride, a.ground,
                       a.sample_idx, a.B, a.H, a.W, a.out, a.status, a.aux, a.workspace, a.stream, "la3d_fit_instances_ex",
-                      a.poly_xy ? &pa : nullptr, a.filter_boundary >= 0 ? &fa : nullptr, a.proj ? &pr : nullptr, a.area_hint);
+                      a.poly_xy ? &pa : nullptr, filter_on ? &fa : nullptr, a.proj ? &pr : nullptr, a.area_hint);
 }
 
 int la3d_rle_from_string_host(const char* s, int64_t len, int32_t* counts, int cap) {

@@ -252,7 +252,6 @@ def fit_instances_ex(depth, K, masks=None, rles=None, polys=None, ground=None, s
         a.depth, a.depth_plane_stride, a.image_index = _ptr(d), (H * W if P > 1 else 0), _ptr(ii)
         a.K, a.k_stride = _ptr(k), (9 if k.shape[0] > 1 else 0)
         a.ground, a.sample_idx = _ptr(g), _ptr(si)
-        a.filter_boundary = -1
         if filter:
             a.filter_boundary, a.filter_min_area, a.filter_max_edge = _filter_args(filter)
             a.stats = _ptr(out["stats"])
@@ -381,7 +380,7 @@ def _fit_common(depth, K, H, W, B, ground, sample_idx, image_index, dev, what):
         d = d[None]
     if d.shape[1:] != (H, W):
         raise ValueError(f"depth planes {tuple(d.shape[1:])} do not match the {what} frame {(H, W)}")
-    k = _as_dev(K, torch.float64, dev)
+    k = _as_dev(K, torch.float64, dev, cache=True)
     if k.dim() == 2:
         k = k[None]
     P = d.shape[0]

@@ -17,16 +17,24 @@ import torch
 from .batched import InstanceFitter, set_launch_order
 
 
-def fit_batches(batches: Iterable, depth_of=None, streams: int = 2) -> Iterator[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
+def fit_batches(batches: Iterable, streams: int = 2, copy: bool = True) -> Iterator[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
     """``batches`` yields ``(depth, masks, K)`` tuples or dicts with the keyword arguments of ``InstanceFitter.run``
     (``depth, masks, K, ground, sample_idx, image_index``); all tensors on the GPU with the ABI's dtypes (f32 / u8|bool / f64 /
     f64 / i32 / i32).  Yields ``(boxes (B,39), status (B,), aux (B,4))`` per batch, in order; every result is complete (its
-    stream has been waited for) when it is handed out.  Buffers are reused per (B, H, W) and stream slot: copy a result you
-    want to keep beyond the next ``streams`` batches."""
+    stream has been waited for) when it is handed out.
+
+    Ordering and lifetime: batches are pulled lazily, so before batch k is issued its pool stream waits for the stream that is
+    current at that moment (where the caller produced the tensors), and every input tensor is recorded on the pool stream so
+    that the caching allocator cannot hand its memory to the producer of batch k+1 while batch k still reads it.
+    ``copy=True`` (default) hands out clones: results stay valid for as long as the caller keeps them (``list(fit_batches(..))``
+    is safe).  ``copy=False`` hands out views of internal buffers (``streams + 1`` rotating sets per batch shape): a result is
+    overwritten once the generator has been advanced TWICE more - use it before asking for the result after next.
+    The process-wide launch-order setting is saved and put back at the end."""
     dev = None
     pool, fitters = [], {}
     pending = []          # (event, result) in issue order
-    set_launch_order(False)
+    nbuf = max(1, streams) + 1
+    prev_order = set_launch_order(False)
     try:
         for k, b in enumerate(batches):
             kw = dict(b) if isinstance(b, dict) else dict(zip(("depth", "masks", "K"), b))
@@ -35,25 +43,26 @@ def fit_batches(batches: Iterable, depth_of=None, streams: int = 2) -> Iterator[
                 kw["masks"] = masks.view(torch.uint8)
             if dev is None:
                 dev = masks.device
-                cur = torch.cuda.current_stream(dev)
                 pool = [torch.cuda.Stream(device=dev) for _ in range(max(1, streams))]
-                for s in pool:
-                    s.wait_stream(cur)          # the inputs were produced on the caller's stream
-            slot = k % len(pool)
+            st = pool[k % len(pool)]
+            st.wait_stream(torch.cuda.current_stream(dev))   # this batch's tensors were produced on the stream current NOW
+            for t in kw.values():
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(st)
             B, H, W = kw["masks"].shape
-            key = (B, H, W, slot)
+            key = (B, H, W, k % nbuf)
             if key not in fitters:
                 fitters[key] = InstanceFitter(B, H, W, dev)
-            while len(pending) >= len(pool):    # the buffers of this slot are about to be reused: hand out its previous result
+            while len(pending) >= len(pool):    # keep at most `streams` batches in flight: hand out the oldest result
                 ev, res = pending.pop(0)
                 ev.synchronize()
-                yield res
-            res = fitters[key].run(stream=pool[slot], **kw)
+                yield tuple(t.clone() for t in res) if copy else res
+            res = fitters[key].run(stream=st, **kw)
             ev = torch.cuda.Event()
-            ev.record(pool[slot])
+            ev.record(st)
             pending.append((ev, res))
         for ev, res in pending:
             ev.synchronize()
-            yield res
+            yield tuple(t.clone() for t in res) if copy else res
     finally:
-        set_launch_order(None)
+        set_launch_order(prev_order)

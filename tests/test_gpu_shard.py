@@ -180,10 +180,26 @@ def test_pipelined_batches_and_retaining_build_give_the_same_records(la, monkeyp
         depth, masks, K, _, _ = bench.make_inputs(700 + 100 * k, dev, 40 + k)
         batches.append((depth, masks, K))
         want.append(tuple(t.clone() for t in la.fit_instances(depth, masks, K)))
-    got = [tuple(t.clone() for t in r) for r in la.fit_batches(batches)]
+    got = list(la.fit_batches(batches))          # results are clones by default: keeping all of them is safe
     assert len(got) == 5
     for g, w in zip(got, want):
         assert torch.equal(g[0], w[0]) and torch.equal(g[1], w[1]) and torch.equal(g[2], w[2])
+
+    def lazily():   # batches PRODUCED while the generator runs (uploads on the current stream, freed right after the yield)
+        for k in range(5):
+            d, m, K_ = batches[k]
+            yield d.clone(), m.clone(), K_.clone()
+    prev = la.set_launch_order(True)
+    try:
+        views = []
+        for k, r in enumerate(la.fit_batches(lazily(), copy=False)):   # zero-copy views: valid until two more are requested
+            assert torch.equal(r[0], want[k][0]) and torch.equal(r[1], want[k][1])
+            views.append(r)
+            if k >= 1:
+                assert torch.equal(views[k - 1][0], want[k - 1][0])
+        assert la.set_launch_order(prev) is True      # fit_batches put the caller's explicit setting back
+    finally:
+        la.set_launch_order(prev)
     monkeypatch.setenv("LA3D_RETAIN", "1")
     for (depth, masks, K), w in zip(batches[:2], want[:2]):
         b, s, a = la.fit_instances(depth, masks, K)
