@@ -512,7 +512,12 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : NT / 64) void fit_instance
   // youngest of the four workgroups of a CU gets its first load - this perm entry - back only when an older one has finished
   // its mask stream, ~25 us in; warming the table through L1 does not help, and s_setprio by dispatch group only moves the
   // starvation to the oldest group, which holds the largest instances: DESIGN.md section 5.2)
+#ifdef LA3D_DEBUG_ORDER
+  const int inst = p.debug_perm ? p.debug_perm[blockIdx.x]
+                                : (p.order_nch > 0 ? order_select(p, (int)blockIdx.x, sh, wave, lane) : xcd_remap(blockIdx.x, p.B));
+#else
   const int inst = p.order_nch > 0 ? order_select(p, (int)blockIdx.x, sh, wave, lane) : xcd_remap(blockIdx.x, p.B);
+#endif
   const int img = p.image_index ? p.image_index[inst] : inst;
   const int HW = p.HW;
   const float* dpl = p.depth + (long long)img * p.depth_plane_stride;
@@ -2065,6 +2070,10 @@ __global__ __launch_bounds__(256) void size_estimate_kernel(const unsigned char*
   }
 }
 
+#ifdef LA3D_DEBUG_ORDER
+std::atomic<const int*> g_debug_perm{nullptr};   // measurement build only: a caller-supplied block -> instance table
+std::atomic<int> g_debug_perm_n{0};
+#endif
 std::atomic<int> g_launch_order{-1};   // la3d_set_launch_order: -1 = default (on, unless LA3D_BALANCE=0), 0 = off, 1 = on
 
 inline bool balance_enabled() {
@@ -2115,6 +2124,10 @@ int launch_fit_inst(const FitParams& p_in, size_t lds, hipStream_t s, void* work
       }
     }
   }
+#ifdef LA3D_DEBUG_ORDER
+  p.debug_perm = (g_debug_perm_n.load() == p.B) ? g_debug_perm.load() : nullptr;
+  if (p.debug_perm) p.order_nch = 0;
+#endif
   hipLaunchKernelGGL(kern, dim3(p.B), dim3(NT), lds, s, p);
   return check_launch("fit_instances_kernel");
 }
@@ -2158,6 +2171,13 @@ int la3d_version(void) { return LA3D_ABI_VERSION; }
 const char* la3d_last_error(void) { return g_err; }
 
 double la3d_f16_round_host(double x) { return f16_round(x); }
+
+#ifdef LA3D_DEBUG_ORDER
+int la3d_debug_set_block_order(const int32_t* perm_dev, int n) {   // measurement hook (not in include/la3d.h): n = 0 clears
+  g_debug_perm.store(perm_dev); g_debug_perm_n.store(perm_dev ? n : 0);
+  return LA3D_SUCCESS;
+}
+#endif
 
 int la3d_get_launch_order(void) { return g_launch_order.load(std::memory_order_relaxed); }
 

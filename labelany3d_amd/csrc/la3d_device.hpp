@@ -432,6 +432,9 @@ struct FitParams {
   int order_nch;       // chunks of consecutive instances (ceil(B / ORDER_CHUNK)), 0 = launch order off
   int order_resident;  // workgroups of the grid that are resident at once
   int order_shift;     // area_hint >> order_shift fits 18 bits
+#ifdef LA3D_DEBUG_ORDER
+  const int* debug_perm;   // measurement build only (profiles/r03/order_search.py): block -> instance table set by la3d_debug_set_block_order
+#endif
   int lds_keep_off;    // retaining build: byte offset in dynamic LDS of the per-wave kept step (0: none)
   int stagger_ticks;   // retaining build: the second-dispatched workgroup of every CU starts this many 100 MHz ticks late (0: off)
   // instance filter fused into the fit (run-length / polygon input): boundary < 0 = off

@@ -144,6 +144,31 @@ if os.environ.get("TL_DETAIL"):
     for x in range(8):
         sl = np.arange(B)[np.arange(B) % 8 == x]
         print(f"XCD {x}: start mean {t[sl, 0].mean():5.1f} max {t[sl, 0].max():5.1f} | end mean {t[sl, 6].mean():5.1f} max {t[sl, 6].max():5.1f}")
+
+    if os.environ.get("TL_BW"):
+        # aggregate demand profile: every workgroup's mask bytes spread over its stream interval, its active-tile bytes over its
+        # pass A interval, the not-retained share over its pass B interval -> TB/s per 5 us bucket
+        tiles = torch.nn.functional.max_pool2d(masks.float().view(B, 1, H, W), (8, 32)).view(B, -1).sum(1).cpu().numpy()
+        tiles = tiles[np.argsort(np.argsort(blk))] if False else tiles
+        inst_of_row = np.arange(B)                      # stamp rows are indexed by instance
+        tt = (tl[:, :7] - tl[:, 8].min()) / 100.0
+        keep = float(os.environ.get("TL_KEEP_TILES", "160"))
+        edges = np.arange(0, tt[:, 6].max() + 5, 5.0)
+        prof = np.zeros((3, len(edges) - 1))
+        def spread(row, a, b, nbytes):
+            if b <= a:
+                b = a + 0.1
+            for k in range(len(edges) - 1):
+                ov = max(0.0, min(b, edges[k + 1]) - max(a, edges[k]))
+                prof[row, k] += nbytes * ov / (b - a)
+        for i in range(B):
+            spread(0, tt[i, 0], tt[i, 1], H * W)
+            spread(1, tt[i, 2], tt[i, 3], tiles[i] * 1024.0)
+            spread(2, tt[i, 4], tt[i, 5], max(0.0, tiles[i] - keep) * 1024.0)
+        print("\nmodelled traffic per 5 us bucket, TB/s (mask stream | pass A tiles | pass B re-read | sum):")
+        for k in range(len(edges) - 1):
+            m, a, b2 = prof[:, k] / 5e-6 / 1e12
+            print(f"  {edges[k]:5.0f}-{edges[k+1]:3.0f} us: {m:5.2f} {a:5.2f} {b2:5.2f} | {m + a + b2:5.2f}")
     late = np.argsort(-t[:, 6])[:8]
     print("latest finishers (block, start, stream, list, passA, axis, passB, end):")
     for b in late:
