@@ -60,12 +60,18 @@ def run(B, config5, seed):
     octs = [r[edges[k]:edges[k + 1]] for k in range(8)]
     # block groups take the rank groups PI[k]; group sizes differ by at most one, so walk the blocks in order
     pat = np.concatenate([octs[PI[k]] for k in range(8)])
+    # "spread" instead of "balance": the second static group in the SAME direction as the first, so that the round-1 finish
+    # times of the CUs are spread out and the dynamically placed rest starts staggered
+    spread = lpt.copy()
+    if B > R:
+        spread[256:R] = np.arange(256, R)
     time(None, 10, 1)
-    return time(None), time(lpt), time(pat)
+    return time(None), time(lpt), time(pat), time(spread)
 
 
-print(f"{'B':>6s} {'mix':>4s} {'library':>9s} {'LPT table':>10s} {'octile table':>13s}")
+print(f"{'B':>6s} {'mix':>4s} {'seed':>5s} {'library':>9s} {'LPT table':>10s} {'octile table':>13s} {'spread table':>13s}")
 for B in (640, 768, 896, 1024, 1152, 1280):
     for c5 in (False, True):
-        a, b, c = run(B, c5, 1234)
-        print(f"{B:6d} {'c5' if c5 else 'c2':>4s} {a:9.1f} {b:10.1f} {c:13.1f}", flush=True)
+        for seed in (1234, 3):
+            a, b, c, d = run(B, c5, seed)
+            print(f"{B:6d} {'c5' if c5 else 'c2':>4s} {seed:5d} {a:9.1f} {b:10.1f} {c:13.1f} {d:13.1f}", flush=True)
