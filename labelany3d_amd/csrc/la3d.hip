@@ -494,7 +494,10 @@ __device__ inline int order_select(const FitParams& p, int b, Shared* sh, int wa
 // ------------------------------------------------------------------------------------------
 // SRC: where the mask comes from - 0 = u8 plane, 1 = COCO run lengths, 2 = polygon parts (both decoded into the LDS bit image)
 template <bool VEC, bool LDSMASK, bool SAMPLE, bool TILED, int SRC, int RET>
-__global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : NT / 64) void fit_instances_kernel(const FitParams p) {
+#ifndef LA3D_POLY_WAVES
+#define LA3D_POLY_WAVES (NT / 64)
+#endif
+__global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVES : NT / 64)) void fit_instances_kernel(const FitParams p) {
   constexpr bool RLE = SRC == 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned* bits = reinterpret_cast<unsigned*>(smem);
@@ -644,7 +647,7 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : NT / 64) void fit_instance
     // the reference's instance filter (src/util.py:375) on the bit image just built: a dropped instance costs no passes
     int st4[4];
     bits_filter_stats<NT>(bits, p.H, p.W, p.filter_boundary, reinterpret_cast<int*>(sh->part), tid, st4);
-    if (p.filter_stats && tid < 4) p.filter_stats[(long long)inst * 4 + tid] = st4[tid];
+    if (p.filter_stats && tid < 4) (p.filter_stats + (long long)inst * 4)[tid] = st4[tid];   // (uniform base: scalar address arithmetic)
     const int height = SRC == 1 ? st4[1] : st4[2];   // run lengths: rows holding a pixel (:368-369); polygons: last - first + 1 (:328-335)
     const bool keep = 16 * height > p.H && st4[3] < p.filter_max_edge && st4[0] >= p.filter_min_area;   // height / H > 0.0625
     if (!keep) {
@@ -2369,7 +2372,11 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
     const long ntiles = (long)p.ntx * p.nty;
     const long want = ntiles < 256 ? ntiles : 256;
     long cap = 0;
-    const int ret = mask != nullptr ? retain_steps(p.B) : 0;   // u8 planes only: run-length / polygon input has no mask stream to stagger
+    // u8 planes only: run-length / polygon input has no mask stream to overlap, and with nothing to stream the plain build's four
+    // workgroups per CU hide the passes' latency better (LA3D_RETAIN_NOMASK=1 forces the retaining build for measurements:
+    // profiles/r03/r03_rle_poly.txt)
+    const char* rn = getenv("LA3D_RETAIN_NOMASK");
+    const int ret = (mask != nullptr || (rn && rn[0] == '1')) ? retain_steps(p.B) : 0;
     for (int wg_per_cu = ret > 0 ? 2 : 4; wg_per_cu >= 1 && cap < want; --wg_per_cu) {
       const long budget = (160 * 1024 / wg_per_cu) & ~15L;
       cap = (budget - (long)fixed) / 2;

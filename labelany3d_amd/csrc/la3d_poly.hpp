@@ -40,35 +40,45 @@ constexpr int POLY_STAGE_BYTES = POLY_CHUNK * (int)sizeof(PolySide) + POLY_META_
 // these loops), 20-40 % more with 2; spiky 40 / 80-vertex parts: +4...9 % with 4, +25...40 % with 2.
 constexpr int POLY_KEEP = LA3D_POLY_KEEP;
 
-// cv::clipLine(Size2l, Point2l&, Point2l&): end points are updated in place even when the line misses the image
-__device__ inline bool poly_clip_line(long long width, long long height, long long& x1, long long& y1, long long& x2, long long& y2) {
-  const long long right = width - 1, bottom = height - 1;
+// cv::clipLine(Size2l, Point2l&, Point2l&): end points are updated in place even when the line misses the image.
+// OpenCV works on int64 points; with shift 0 every coordinate (int32 vertices, and every clipped value, which lies between the two
+// end points) stays inside int32, and (double)(p - q) of two int32 values equals (double)p - (double)q exactly - so the same
+// double products / quotients / truncations are formed from 32-bit registers (the int64 form kept ~30 more VGPRs alive inside
+// the scanline loops of poly_ring_general: the fit kernel spilled).
+// p + (int64)((double)(a - q) * (s1 - s0) / (r1 - r0)), the update clipLine applies to a coordinate p.  The truncated term can
+// exceed int32 for end points 2^31 apart, the sum cannot (it lies between the two end points): add in double, convert once.
+__device__ inline int poly_clip_add(int p, int a, int q, int s0, int s1, int r0, int r1) {
+  const double t = ((double)a - (double)q) * ((double)s1 - (double)s0) / ((double)r1 - (double)r0);
+  return (int)((double)p + trunc(t));
+}
+__device__ inline bool poly_clip_line(int width, int height, int& x1, int& y1, int& x2, int& y2) {
+  const int right = width - 1, bottom = height - 1;
   int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
   int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
   if ((c1 & c2) == 0 && (c1 | c2) != 0) {
-    long long a;
+    int a;
     if (c1 & 12) {
       a = c1 < 8 ? 0 : bottom;
-      x1 += (long long)((double)(a - y1) * (double)(x2 - x1) / (double)(y2 - y1));
+      x1 = poly_clip_add(x1, a, y1, x1, x2, y1, y2);
       y1 = a;
       c1 = (x1 < 0) + (x1 > right) * 2;
     }
     if (c2 & 12) {
       a = c2 < 8 ? 0 : bottom;
-      x2 += (long long)((double)(a - y2) * (double)(x2 - x1) / (double)(y2 - y1));
+      x2 = poly_clip_add(x2, a, y2, x1, x2, y1, y2);
       y2 = a;
       c2 = (x2 < 0) + (x2 > right) * 2;
     }
     if ((c1 & c2) == 0 && (c1 | c2) != 0) {
       if (c1) {
         a = c1 == 1 ? 0 : right;
-        y1 += (long long)((double)(a - x1) * (double)(y2 - y1) / (double)(x2 - x1));
+        y1 = poly_clip_add(y1, a, x1, y1, y2, x1, x2);
         x1 = a;
         c1 = 0;
       }
       if (c2) {
         a = c2 == 1 ? 0 : right;
-        y2 += (long long)((double)(a - x2) * (double)(y2 - y1) / (double)(x2 - x1));
+        y2 = poly_clip_add(y2, a, x2, y1, y2, x1, x2);
         x2 = a;
         c2 = 0;
       }
@@ -77,37 +87,47 @@ __device__ inline bool poly_clip_line(long long width, long long height, long lo
   return (c1 | c2) == 0;
 }
 
+// trunc(num / den) for |num| < 2^52, den != 0 (C++ truncating division): the double quotient is within one of the exact one, one
+// multiply-subtract puts it right - a fraction of the registers and instructions of the inlined 64-bit integer division
+__device__ inline long long poly_div_trunc(long long num, long long den) {
+  const unsigned long long a = (unsigned long long)(num < 0 ? -num : num), b = (unsigned long long)(den < 0 ? -den : den);
+  unsigned long long q = (unsigned long long)((double)a / (double)b);
+  const long long r = (long long)(a - q * b);
+  if (r < 0) --q;
+  else if ((unsigned long long)r >= b) ++q;
+  return ((num < 0) != (den < 0)) ? -(long long)q : (long long)q;
+}
+
 // One polygon side p0 -> p1 (one thread): CollectPolyEdges for line_type 8, shift 0, offset 0 — the segment Line() draws
 // (LineIterator: 8-connected, left to right, clipped) and the scan edge.
 __device__ inline PolySide poly_side(int x0i, int y0i, int x1i, int y1i, int W, int H) {
-  const long long px0 = x0i, py0 = y0i, px1 = x1i, py1 = y1i;
-  long long ax = px0, ay = py0, bx = px1, by = py1;
-  const bool inside = (unsigned long long)px0 < (unsigned long long)W && (unsigned long long)px1 < (unsigned long long)W &&
-                      (unsigned long long)py0 < (unsigned long long)H && (unsigned long long)py1 < (unsigned long long)H;
+  int ax = x0i, ay = y0i, bx = x1i, by = y1i;
+  const bool inside = (unsigned)x0i < (unsigned)W && (unsigned)x1i < (unsigned)W && (unsigned)y0i < (unsigned)H && (unsigned)y1i < (unsigned)H;
   bool draw = true;
   if (!inside) draw = poly_clip_line(W, H, ax, ay, bx, by);
   // (ax, ay, bx, by) are also what CollectPolyEdges sees after its own clipLine call (same function, same inputs)
   PolySide s;
   if (draw) {
-    if (bx < ax) { s.sx = (int)bx; s.sy = (int)by; s.ex = (int)ax; s.ey = (int)ay; }    // start from the left end point
-    else { s.sx = (int)ax; s.sy = (int)ay; s.ex = (int)bx; s.ey = (int)by; }
+    if (bx < ax) { s.sx = bx; s.sy = by; s.ex = ax; s.ey = ay; }    // start from the left end point
+    else { s.sx = ax; s.sy = ay; s.ex = bx; s.ey = by; }
   } else {
     s.sx = 1; s.ex = 0; s.sy = s.ey = 0;
   }
   PolyEdge& e = s.e;
   e.y0 = e.y1 = 0; e.x = e.dx = 0;
-  if (py0 == py1) return s;                                       // horizontal sides are not swept
-  long long c0x = (px0 << POLY_XY_SHIFT), c0y = py0, c1x = (px1 << POLY_XY_SHIFT), c1y = py1;
+  if (y0i == y1i) return s;                                       // horizontal sides are not swept
+  long long c0x = ((long long)x0i << POLY_XY_SHIFT), c1x = ((long long)x1i << POLY_XY_SHIFT);
+  int c0y = y0i, c1y = y1i;
   if (inside) {
     c0x += 1 << (POLY_XY_SHIFT - 1);
     c1x += 1 << (POLY_XY_SHIFT - 1);
   } else if (ay != by) {                                          // clipped end points, without the half
-    c0x = ax << POLY_XY_SHIFT; c0y = ay;
-    c1x = bx << POLY_XY_SHIFT; c1y = by;
+    c0x = (long long)ax << POLY_XY_SHIFT; c0y = ay;
+    c1x = (long long)bx << POLY_XY_SHIFT; c1y = by;
   }
-  e.dx = (c1x - c0x) / (c1y - c0y);                               // C++ truncating division
-  if (py0 < py1) { e.y0 = (int)py0; e.y1 = (int)py1; e.x = c0x + (py0 - c0y) * e.dx; }
-  else { e.y0 = (int)py1; e.y1 = (int)py0; e.x = c1x + (py1 - c1y) * e.dx; }
+  e.dx = poly_div_trunc(c1x - c0x, (long long)c1y - (long long)c0y);   // C++ truncating division (|numerator| < 2^49)
+  if (y0i < y1i) { e.y0 = y0i; e.y1 = y1i; e.x = c0x + ((long long)y0i - c0y) * e.dx; }
+  else { e.y0 = y1i; e.y1 = y0i; e.x = c1x + ((long long)y1i - c1y) * e.dx; }
   return s;
 }
 
@@ -308,9 +328,16 @@ __device__ __forceinline__ void poly_ring_general(const int* __restrict__ xy, lo
 // All rings [r0, r1) of one instance -> bit image (zeroed here).  xy: int32 pairs; ring_off: point offsets of the rings
 // (ring r = points ring_off[r] .. ring_off[r+1]).  stage: LDS, POLY_STAGE_BYTES; flags: LDS, max(NTH/64, 4) words.
 // Returns this thread's share of the pixel count.
+// wave-uniform 64-bit value -> SGPR pair (the ring bookkeeping below is uniform, but it is loaded through vector memory
+// instructions: left alone it occupies ~10 VGPRs across the rasteriser's loops, which is what made the 64-VGPR fit kernel spill)
+__device__ inline long long poly_uniform(long long v) {
+  return ((long long)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 template <int NTH>
 __device__ __forceinline__ int poly_to_bits(const int* __restrict__ xy, const long long* __restrict__ ring_off, long long r0, long long r1,
                                    PolySide* stage, unsigned* flags, unsigned* bits, int nwords, int H, int W, int tid) {
+  r0 = poly_uniform(r0); r1 = poly_uniform(r1);
   for (int i = tid; i < nwords; i += NTH) bits[i] = 0;
   int* meta = reinterpret_cast<int*>(stage + POLY_CHUNK);   // [0..8] part bounds, [9 + 4 j ..] bounding box of part j, [41] verdict
   const int nr = (int)(r1 - r0);
@@ -349,8 +376,8 @@ __device__ __forceinline__ int poly_to_bits(const int* __restrict__ xy, const lo
       __syncthreads();
       if (meta[41]) joint = nr;   // uniform
     }
-    const long long p0 = ring_off[r0];
-    const int n = (int)(ring_off[r0 + joint] - p0);
+    const long long p0 = poly_uniform(ring_off[r0]);
+    const int n = __builtin_amdgcn_readfirstlane((int)(ring_off[r0 + joint] - p0));
     if (joint == 1) {
       if (tid == 0) { meta[0] = 0; meta[1] = n; }
       __syncthreads();
@@ -362,8 +389,8 @@ __device__ __forceinline__ int poly_to_bits(const int* __restrict__ xy, const lo
     r = r0 + joint;
   }
   for (; r < r1; ++r) {   // whatever is left is OR-ed in by the general form
-    const long long p0 = ring_off[r];
-    const int n = (int)(ring_off[r + 1] - p0);
+    const long long p0 = poly_uniform(ring_off[r]);
+    const int n = __builtin_amdgcn_readfirstlane((int)(ring_off[r + 1] - p0));
     poly_ring_general<NTH>(xy, p0, n, stage, flags, bits, H, W, tid);
   }
   __syncthreads();
