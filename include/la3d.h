@@ -255,6 +255,13 @@ int la3d_align_select(const float* relative, const float* metric, const uint8_t*
                       float* relative_out, float* metric_out, int64_t* count, void* workspace, void* stream);
 int la3d_align_apply(const float* relative, const uint8_t* mask, int64_t n, float coef, float intercept, float fill,
                      float* out, void* stream);
+/* la3d_align_select for P frames of n pixels each in ONE call (three launches for the whole batch instead of three per frame plus an
+ * 8-byte read-back each; the reference loops over images, src/batch_scripts/depth.py:138-160): relative / metric dev f32 [P][n],
+ * mask dev u8 [P][n] | NULL; relative_out / metric_out dev f32 [P][n] (frame p's selection at [p][0 .. counts[p]), row-major order
+ * kept); counts dev i64 [P] - left on the device; workspace: P * la3d_align_workspace_bytes(n) bytes.  P <= 65535. */
+int la3d_align_select_batch(const float* relative, const float* metric, const uint8_t* mask, int P, int64_t n,
+                            float max_valid_depth, float* relative_out, float* metric_out, int64_t* counts, void* workspace,
+                            void* stream);
 
 /* ---- sparse unprojection at match points -------------------------------------------------------
  * Reference src/matching/matcher.py:70-91: depth dev f32 [H][W] looked up at (int(v), int(u)) of each match

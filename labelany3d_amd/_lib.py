@@ -72,6 +72,8 @@ _SIGS = {
     "la3d_align_select": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
     "la3d_align_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "la3d_align_select_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "la3d_unproject_matches": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double,
                                          C.c_double, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                          C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1655,8 +1655,11 @@ __global__ __launch_bounds__(256) void iou_matrix_kernel(const double* __restric
 }
 
 // Masked depth-ratio median — reference src/util.py:476-486 (align_to_depth_match): overlap = mask_a & mask_b,
-// scale = np.median(num[overlap] / den[overlap]) in float32.  One 256-thread workgroup per instance:
+// scale = np.median(num[overlap] / den[overlap]) in float32.  One 512-thread workgroup per instance:
 //   phase 1  the two u8 masks are read once with 16-byte loads into an overlap bit image in LDS;
+//   fast     (round 3) sample -> bracket -> one counting sweep -> one collecting sweep -> exact select in LDS: see the block
+//            marked "fast path" in the kernel; 650 -> 360 us per 1024 VGA instances, identical results; falls through to the
+//            rounds below whenever a count does not confirm it
 //   rounds   the k-th smallest ratio is found exactly by a most-significant-first radix select on an order-preserving key,
 //            four rounds of 8 bits; a wave takes 64 consecutive pixels per step (coalesced 256-byte loads of num and den,
 //            chunks without an overlap pixel are skipped), so the ratios are re-derived from memory once per round instead of
@@ -1674,9 +1677,118 @@ __device__ inline float f32_unkey(unsigned k) {
   return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
 }
 
-constexpr int RM_COPIES = 16;
+#ifndef LA3D_RM_COPIES
+#define LA3D_RM_COPIES 16
+#endif
+constexpr int RM_COPIES = LA3D_RM_COPIES;
 
 constexpr int RM_NT = 512;   // threads per workgroup
+constexpr int RM_CAP = 6144; // keys the LDS buffer of the fast path holds (sample, then the candidates of the median's bin)
+#ifndef LA3D_RM_FAST
+#define LA3D_RM_FAST 1
+#endif
+
+// Keys at ranks ra <= rb (0-based, ascending) among the m keys in LDS buf: most-significant-first radix select, four rounds of
+// 8 bits, both ranks at once (wave 0 follows ra, wave 1 follows rb).  h2: LDS [2][256]; st: LDS [4] = prefix a, rank a, prefix b,
+// rank b (initialised here).  Every thread of the workgroup calls it; results in st[0], st[2] after the final barrier.
+__device__ inline void lds_select2(const unsigned* buf, int m, unsigned ra, unsigned rb, unsigned* h2, unsigned* st, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) { st[0] = 0u; st[1] = ra; st[2] = 0u; st[3] = rb; }
+  unsigned pmask = 0;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    h2[tid] = 0u;                        // RM_NT == 512 == 2 * 256
+    __syncthreads();
+    const unsigned pa = st[0], pb = st[2];
+    for (int i = tid; i < m; i += RM_NT) {
+      const unsigned k = buf[i], d = (k >> shift) & 0xffu;
+      if ((k & pmask) == pa) atomicAdd(&h2[d], 1u);
+      if ((k & pmask) == pb) atomicAdd(&h2[256 + d], 1u);
+    }
+    __syncthreads();
+    if (wave < 2) {                      // four bins per lane, exclusive scan over the lanes
+      const unsigned* h = h2 + 256 * wave;
+      const unsigned b0 = h[4 * lane], b1 = h[4 * lane + 1], b2 = h[4 * lane + 2], b3 = h[4 * lane + 3];
+      const unsigned mine = b0 + b1 + b2 + b3;
+      unsigned incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+      }
+      const unsigned rank = st[2 * wave + 1], excl = incl - mine;
+      if (excl <= rank && rank < incl) { // exactly one lane
+        unsigned acc = excl, bsel = 0;
+        if (rank >= acc + b0) { acc += b0; bsel = 1;
+          if (rank >= acc + b1) { acc += b1; bsel = 2;
+            if (rank >= acc + b2) { acc += b2; bsel = 3; } } }
+        st[2 * wave] = st[2 * wave] | ((4u * (unsigned)lane + bsel) << shift);
+        st[2 * wave + 1] = rank - acc;
+      }
+    }
+    pmask |= 0xffu << shift;
+    __syncthreads();
+  }
+}
+
+// One sweep of the fast path over the chunks that hold an overlap pixel (every cstep-th one).  MODE 0: append every key to buf
+// (the sample).  MODE 1: count the keys below klo, histogram those in [klo, khi] by (key - klo) >> sh (256 bins x 4 copies),
+// note NaN ratios.  MODE 2: append the keys in [klo, khi] to buf.  cnt: LDS counter of appended keys (entries beyond RM_CAP are
+// dropped but counted); lt: LDS counter; nanflag: LDS.
+template <int MODE>
+__device__ inline void rm_sweep(const float* __restrict__ np_, const float* __restrict__ dp, const unsigned* bits, int nwords,
+                                const unsigned short* clist, int nact, int cstep, unsigned klo, unsigned khi, int sh, unsigned* buf,
+                                unsigned* cnt, unsigned* h1, unsigned* lt, unsigned* nanflag, int wave, int lane) {
+#ifndef LA3D_RM_SWEEP_U
+#define LA3D_RM_SWEEP_U 8
+#endif
+  constexpr int U = LA3D_RM_SWEEP_U;     // chunks in flight per wave
+  unsigned lt_local = 0, nan_local = 0;
+  for (int j0 = wave * U * cstep; j0 < nact; j0 += (RM_NT / 64) * U * cstep) {
+    float a[U], d[U];
+    unsigned on[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      on[u] = 0; a[u] = 0.f; d[u] = 1.f;
+      const int j = j0 + u * cstep;
+      if (j < nact) {
+        const int c = clist[j];
+        const unsigned w0 = bits[2 * c], w1 = (2 * c + 1 < nwords) ? bits[2 * c + 1] : 0u;
+        on[u] = lane < 32 ? (w0 >> lane) & 1u : (w1 >> (lane - 32)) & 1u;
+        if (on[u]) { a[u] = np_[c * 64 + lane]; d[u] = dp[c * 64 + lane]; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (j0 + u * cstep >= nact) continue;   // uniform
+      const float r = a[u] / d[u];
+      const unsigned key = f32_key(r);
+      bool take = on[u] != 0;
+      if (MODE == 1) {
+        if (take) {
+          nan_local |= (r != r) ? 1u : 0u;
+          lt_local += key < klo ? 1u : 0u;
+          if (key >= klo && key <= khi) atomicAdd(&h1[((key - klo) >> sh) * 4 + (lane & 3)], 1u);
+        }
+        continue;
+      }
+      if (MODE == 2) take = take && key >= klo && key <= khi;
+      const unsigned long long bal = __ballot(take);
+      if (bal == 0) continue;
+      unsigned base = 0;
+      if (lane == 0) base = atomicAdd(cnt, (unsigned)__popcll(bal));
+      base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+      if (take) {
+        const unsigned pos = base + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+        if (pos < (unsigned)RM_CAP) buf[pos] = key;
+      }
+    }
+  }
+  if (MODE == 1) {
+    lt_local = (unsigned)wave_sum_i((int)lt_local);
+    if (lane == 0 && lt_local) atomicAdd(lt, lt_local);
+    if (__ballot(nan_local != 0) != 0 && lane == 0) *nanflag = 1u;
+  }
+}
 
 __global__ __launch_bounds__(RM_NT) void ratio_median_kernel(const float* __restrict__ num, long long num_stride,
                                                            const int* __restrict__ image_index, const float* __restrict__ den,
@@ -1685,17 +1797,20 @@ __global__ __launch_bounds__(RM_NT) void ratio_median_kernel(const float* __rest
                                                            float* __restrict__ median, int* __restrict__ count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned* bits = reinterpret_cast<unsigned*>(smem);
-  unsigned* hist = bits + ((nwords + 3) & ~3);   // [256][RM_COPIES]
-  unsigned* bsum = hist + 256 * RM_COPIES;       // [256] bin totals
+  unsigned* hist = bits + ((nwords + 3) & ~3);   // fallback rounds: [256][RM_COPIES]; fast path: the key buffer, RM_CAP words
+  static_assert(RM_CAP >= 256 * RM_COPIES, "the key buffer also holds the fallback's histogram");
+  unsigned* h1 = hist + RM_CAP;                  // fast path: [256][4] bins of the bracket; lds_select2: [2][256]
+  unsigned* bsum = h1 + 1024;                    // [256] bin totals
   unsigned* misc = bsum + 256;                   // [0] n, [1] nan flag, [2] prefix, [3] rank, [4] count of the selected bin, [5] min key above,
-                                                 // [6] number of active chunks
-  unsigned short* clist = reinterpret_cast<unsigned short*>(misc + 8);   // ids of the 64-pixel chunks holding an overlap pixel
+                                                 // [6] number of active chunks, [7] appended keys, [8] keys below the bracket,
+                                                 // [9] fast-path verdict, [10..13] lds_select2 state, [14] lo2, [15] hi2
+  unsigned short* clist = reinterpret_cast<unsigned short*>(misc + 16);   // ids of the 64-pixel chunks holding an overlap pixel
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, inst = blockIdx.x;
   const float* np_ = num + (long long)(image_index ? image_index[inst] : inst) * num_stride;
   const float* dp = den + (long long)inst * HW;
   const unsigned char* ma = mask_a + (long long)inst * HW;
   const unsigned char* mb = mask_b ? mask_b + (long long)inst * HW : nullptr;
-  if (tid < 8) misc[tid] = tid == 5 ? 0xffffffffu : 0u;
+  if (tid < 16) misc[tid] = tid == 5 ? 0xffffffffu : 0u;
   // ---- phase 1: overlap bit image ----
   unsigned n_local = 0;
   const bool vec = (HW % 16 == 0) && ((reinterpret_cast<uintptr_t>(ma) & 15) == 0) && (!mb || (reinterpret_cast<uintptr_t>(mb) & 15) == 0);
@@ -1751,6 +1866,100 @@ __global__ __launch_bounds__(RM_NT) void ratio_median_kernel(const float* __rest
   }
   __syncthreads();
   const int nact = (int)misc[6];
+#if LA3D_RM_FAST
+  // ---- fast path (round 3): sample -> bracket -> one counting sweep -> one collecting sweep -> exact select in LDS --------
+  // The four radix rounds below visit every overlap pixel four (five) times, each time re-deriving the ratio from two loads and
+  // a division, and they are latency-bound.  Here: (0) the keys of every cstep-th active chunk (~2-4 k keys) go to LDS and two
+  // of their order statistics, 50 % -/+ 1/12, bracket the median; (1) one sweep counts the keys below the bracket and
+  // histograms the keys inside it in <= 256 power-of-two bins; the bin(s) holding the middle rank(s) hold n / 1000 keys or so;
+  // (2) one sweep collects exactly those keys; (3) an in-LDS radix select gives the exact middle value(s).  Every step is
+  // verified by counts: if the bracket misses the median, a bin overflows the buffer, or the sample was too small, the
+  // verdict stays 0 and the radix rounds below run as before.  An overlap of <= RM_CAP pixels is selected from step (0) alone.
+  {
+    unsigned* st = misc + 10;
+    const unsigned rlo = (n & 1u) ? n / 2 : n / 2 - 1, rhi = n / 2;       // 0-based ranks of the middle value(s)
+#ifndef LA3D_RM_SAMPLE
+#define LA3D_RM_SAMPLE 2048
+#endif
+    const int cstep = (int)(n <= (unsigned)RM_CAP ? 1u : (n + (unsigned)LA3D_RM_SAMPLE - 1u) / (unsigned)LA3D_RM_SAMPLE);
+    rm_sweep<0>(np_, dp, bits, nwords, clist, nact, cstep, 0u, 0xffffffffu, 0, hist, &misc[7], h1, &misc[8], &misc[1], wave, lane);
+    __syncthreads();
+    const unsigned ns_all = misc[7];
+    const int ns = (int)(ns_all < (unsigned)RM_CAP ? ns_all : (unsigned)RM_CAP);
+    if (cstep == 1 && ns_all == n) {     // uniform: every key is in LDS - select directly (NaN keys sort last: check them here)
+      unsigned nanl = 0;
+      for (int i = tid; i < ns; i += RM_NT) nanl |= (hist[i] > 0xff800000u || (hist[i] < 0x007fffffu)) ? 1u : 0u;   // NaN keys
+      if (__ballot(nanl != 0) != 0 && lane == 0) misc[1] = 1u;
+      lds_select2(hist, ns, rlo, rhi, h1, st, tid);
+      if (tid == 0) {
+        const float v0 = f32_unkey(st[0]), v1 = f32_unkey(st[2]);
+        median[inst] = misc[1] ? NAN : ((n & 1u) ? v0 : (v0 + v1) / 2.0f);
+        count[inst] = (int)n;
+      }
+      return;
+    }
+    if (ns >= 512) {                     // uniform: enough of a sample to bracket with
+      const unsigned w = (unsigned)ns / 12u;
+      lds_select2(hist, ns, (unsigned)ns / 2u - w, (unsigned)ns / 2u + w, h1, st, tid);
+      const unsigned klo = st[0], khi = st[2];
+      const unsigned width = khi - klo;
+      const int sh = width < 256u ? 0 : (32 - __clz((int)width)) - 8;    // (width >> sh) < 256
+      __syncthreads();                   // everyone has read st before the counters are reused
+      for (int i = tid; i < 1024; i += RM_NT) h1[i] = 0u;
+      if (tid == 0) { misc[7] = 0u; misc[8] = 0u; }
+      __syncthreads();
+      rm_sweep<1>(np_, dp, bits, nwords, clist, nact, 1, klo, khi, sh, hist, &misc[7], h1, &misc[8], &misc[1], wave, lane);
+      __syncthreads();
+      if (misc[1] != 0) {                // uniform: a NaN ratio
+        if (tid == 0) { median[inst] = NAN; count[inst] = (int)n; }
+        return;
+      }
+      if (tid < 256) bsum[tid] = h1[4 * tid] + h1[4 * tid + 1] + h1[4 * tid + 2] + h1[4 * tid + 3];
+      __syncthreads();
+      if (tid == 0) {                    // (256 bins, one thread: ~1 us, once per instance)
+        const unsigned below = misc[8];
+        unsigned acc = below, b0 = 256, b1 = 256, before = 0;
+        for (unsigned b = 0; b < 256; ++b) {
+          const unsigned c = bsum[b];
+          if (b0 == 256 && rlo >= acc && rlo < acc + c) { b0 = b; before = acc; }
+          if (b1 == 256 && rhi >= acc && rhi < acc + c) b1 = b;
+          acc += c;
+        }
+        unsigned ok = (rlo >= below && b0 < 256 && b1 < 256) ? 1u : 0u;
+        unsigned tot = 0;
+        if (ok) {
+          for (unsigned b = b0; b <= b1; ++b) tot += bsum[b];
+          if (tot > (unsigned)RM_CAP) ok = 0;
+        }
+        misc[9] = ok;
+        if (ok) {
+          misc[14] = klo + (b0 << sh);
+          const unsigned long long top = (unsigned long long)klo + ((unsigned long long)(b1 + 1) << sh) - 1ull;
+          misc[15] = top > (unsigned long long)khi ? khi : (unsigned)top;
+          misc[4] = rlo - before; misc[3] = rhi - before; misc[2] = tot;
+        }
+      }
+      __syncthreads();
+      if (misc[9] != 0) {                // uniform
+        rm_sweep<2>(np_, dp, bits, nwords, clist, nact, 1, misc[14], misc[15], 0, hist, &misc[7], h1, &misc[8], &misc[1], wave, lane);
+        __syncthreads();
+        if (misc[7] == misc[2]) {        // uniform: exactly the keys the histogram promised
+          lds_select2(hist, (int)misc[7], misc[4], misc[3], h1, st, tid);
+          if (tid == 0) {
+            const float v0 = f32_unkey(st[0]), v1 = f32_unkey(st[2]);
+            median[inst] = (n & 1u) ? v0 : (v0 + v1) / 2.0f;
+            count[inst] = (int)n;
+          }
+          return;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < 16 && tid != 0 && tid != 6) misc[tid] = tid == 5 ? 0xffffffffu : 0u;   // back to the state the radix rounds expect
+    if (tid == 0) misc[3] = (n & 1u) ? n / 2 : n / 2 - 1;
+    __syncthreads();
+  }
+#endif
   const int copy = lane & (RM_COPIES - 1);
   unsigned pmask = 0;
   for (int shift = 24; shift >= 0; shift -= 8) {
@@ -1758,7 +1967,10 @@ __global__ __launch_bounds__(RM_NT) void ratio_median_kernel(const float* __rest
     __syncthreads();                     // also publishes misc[2..3] of the previous round
     const unsigned prefix = misc[2];
     unsigned nan_local = 0;
-    constexpr int RM_U = 4;              // chunks in flight per wave: 2 x RM_U coalesced loads issued before any is used
+#ifndef LA3D_RM_U
+#define LA3D_RM_U 4
+#endif
+    constexpr int RM_U = LA3D_RM_U;      // chunks in flight per wave: 2 x RM_U coalesced loads issued before any is used
     for (int j0 = wave * RM_U; j0 < nact; j0 += (RM_NT / 64) * RM_U) {
       float a[RM_U], d[RM_U];
       unsigned on[RM_U];
@@ -1860,6 +2072,10 @@ __global__ __launch_bounds__(256) void align_count_kernel(const float* __restric
                                                           const unsigned char* __restrict__ mask, long long n, float max_valid,
                                                           long long* __restrict__ counts) {
   __shared__ int part[4];
+  // blockIdx.y = frame of a batch (la3d_align_select_batch): planes n apart, (gridDim.x + 1) count slots per frame
+  rel += (long long)blockIdx.y * n; met += (long long)blockIdx.y * n;
+  if (mask) mask += (long long)blockIdx.y * n;
+  counts += (long long)blockIdx.y * (gridDim.x + 1);
   const long long base = (long long)blockIdx.x * AL_TILE;
   int c = 0;
   for (int k = 0; k < AL_TILE / 256; ++k) {
@@ -1876,6 +2092,8 @@ __global__ __launch_bounds__(256) void align_count_kernel(const float* __restric
 __global__ __launch_bounds__(256) void align_scan_kernel(long long* __restrict__ counts, int nb, long long* __restrict__ total) {
   __shared__ long long carry;
   __shared__ long long wsum[4];
+  counts += (long long)blockIdx.x * (nb + 1);   // one workgroup per frame
+  total += blockIdx.x;
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();
   for (int b0 = 0; b0 < nb; b0 += 256) {
@@ -1905,6 +2123,10 @@ __global__ __launch_bounds__(256) void align_scatter_kernel(const float* __restr
                                                             float* __restrict__ met_out) {
   __shared__ int wtot[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  rel += (long long)blockIdx.y * n; met += (long long)blockIdx.y * n;       // frame of a batch: outputs have capacity n per frame
+  if (mask) mask += (long long)blockIdx.y * n;
+  rel_out += (long long)blockIdx.y * n; met_out += (long long)blockIdx.y * n;
+  offsets += (long long)blockIdx.y * (gridDim.x + 1);
   const long long base = (long long)blockIdx.x * AL_TILE;
   long long out = offsets[blockIdx.x];
   for (int k = 0; k < AL_TILE / 256; ++k) {   // 256 consecutive elements per step: row-major order is kept
@@ -2627,7 +2849,7 @@ int la3d_masked_ratio_median(const float* num, int64_t num_plane_stride, const i
   }
   if (B == 0) return LA3D_SUCCESS;
   const int HW = H * W, nwords = (HW + 31) / 32;
-  const size_t lds = (size_t)((nwords + 3) & ~3) * 4 + (256 * RM_COPIES + 256 + 8) * 4 + (size_t)((HW + 63) / 64) * 2 + 16;
+  const size_t lds = (size_t)((nwords + 3) & ~3) * 4 + (size_t)(RM_CAP + 1024 + 256 + 16) * 4 + (size_t)((HW + 63) / 64) * 2 + 16;
   allow_big_lds(reinterpret_cast<const void*>(ratio_median_kernel));
   hipLaunchKernelGGL(ratio_median_kernel, dim3(B), dim3(RM_NT), lds, static_cast<hipStream_t>(stream), num,
                      (long long)num_plane_stride, image_index, den, mask_a, mask_b, HW, nwords, median, count);
@@ -2636,7 +2858,29 @@ int la3d_masked_ratio_median(const float* num, int64_t num_plane_stride, const i
 
 size_t la3d_align_workspace_bytes(int64_t n) {
   if (n <= 0) return 8;
-  return (size_t)((n + AL_TILE - 1) / AL_TILE + 2) * 8;
+  return (size_t)((n + AL_TILE - 1) / AL_TILE + 2) * 8;   // per frame: la3d_align_select_batch needs P times this
+}
+
+int la3d_align_select_batch(const float* relative, const float* metric, const uint8_t* mask, int P, int64_t n,
+                            float max_valid_depth, float* relative_out, float* metric_out, int64_t* counts, void* workspace,
+                            void* stream) {
+  if (P < 0 || P > 65535 || n < 0 || (P > 0 && (!counts || !workspace)) ||
+      (P > 0 && n > 0 && (!relative || !metric || !relative_out || !metric_out))) {
+    set_err("la3d_align_select_batch: bad argument (P <= 65535)");
+    return LA3D_ERR_ARG;
+  }
+  if (P == 0) return LA3D_SUCCESS;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  long long* tile_counts = static_cast<long long*>(workspace);   // [P][nb + 1]
+  const int nb = (int)((n + AL_TILE - 1) / AL_TILE);
+  if (nb > 0)
+    hipLaunchKernelGGL(align_count_kernel, dim3(nb, P), dim3(256), 0, s, relative, metric, mask, (long long)n, max_valid_depth,
+                       tile_counts);
+  hipLaunchKernelGGL(align_scan_kernel, dim3(P), dim3(256), 0, s, tile_counts, nb, reinterpret_cast<long long*>(counts));
+  if (nb > 0)
+    hipLaunchKernelGGL(align_scatter_kernel, dim3(nb, P), dim3(256), 0, s, relative, metric, mask, (long long)n, max_valid_depth,
+                       tile_counts, relative_out, metric_out);
+  return check_launch("align_select_batch");
 }
 
 int la3d_align_select(const float* relative, const float* metric, const uint8_t* mask, int64_t n, float max_valid_depth,
@@ -2645,16 +2889,7 @@ int la3d_align_select(const float* relative, const float* metric, const uint8_t*
     set_err("la3d_align_select: bad argument");
     return LA3D_ERR_ARG;
   }
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  long long* counts = static_cast<long long*>(workspace);
-  const int nb = (int)((n + AL_TILE - 1) / AL_TILE);
-  if (nb > 0)
-    hipLaunchKernelGGL(align_count_kernel, dim3(nb), dim3(256), 0, s, relative, metric, mask, (long long)n, max_valid_depth, counts);
-  hipLaunchKernelGGL(align_scan_kernel, dim3(1), dim3(256), 0, s, counts, nb, reinterpret_cast<long long*>(count));
-  if (nb > 0)
-    hipLaunchKernelGGL(align_scatter_kernel, dim3(nb), dim3(256), 0, s, relative, metric, mask, (long long)n, max_valid_depth,
-                       counts, relative_out, metric_out);
-  return check_launch("align_select");
+  return la3d_align_select_batch(relative, metric, mask, 1, n, max_valid_depth, relative_out, metric_out, count, workspace, stream);
 }
 
 int la3d_align_apply(const float* relative, const uint8_t* mask, int64_t n, float coef, float intercept, float fill,

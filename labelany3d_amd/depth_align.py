@@ -40,6 +40,33 @@ def align_select(relative_depth, metric_depth, mask=None, max_valid_depth: float
     return ro[:k], mo[:k]
 
 
+def align_select_batch(relative_depth, metric_depth, mask=None, max_valid_depth: float = 400.0, device=None, stream=None):
+    """``align_select`` for a stack of P frames in one call (C-ABI ``la3d_align_select_batch``; the reference loops over images,
+    src/batch_scripts/depth.py:138-160): ``relative_depth`` / ``metric_depth`` (P,H,W) [``mask`` (P,H,W)] ->
+    ``(rel_sel (P,n), met_sel (P,n), counts (P,) int64)``, all on the GPU and without any host synchronisation; frame p's selection
+    is ``rel_sel[p, :counts[p]]`` in row-major order."""
+    dev = _dev(device)
+    rel = _as_dev(relative_depth, torch.float32, dev)
+    met = _as_dev(metric_depth, torch.float32, dev)
+    if rel.dim() < 2 or rel.shape != met.shape:
+        raise ValueError("relative_depth and metric_depth must be stacks of equal shape (P, ...)")
+    P = rel.shape[0]
+    rel, met = rel.reshape(P, -1), met.reshape(P, -1)
+    n = rel.shape[1]
+    m = None
+    if mask is not None:
+        m = _as_dev(mask, torch.uint8, dev).reshape(P, -1)
+        if m.shape != rel.shape:
+            raise ValueError("mask must have the shape of the depth stack")
+    ro, mo = torch.empty((P, n), dtype=torch.float32, device=dev), torch.empty((P, n), dtype=torch.float32, device=dev)
+    cnt = torch.zeros(P, dtype=torch.int64, device=dev)
+    ws = torch.empty(max(P, 1) * int(lib.la3d_align_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.la3d_align_select_batch(_ptr(rel), _ptr(met), _ptr(m), P, n, float(max_valid_depth), _ptr(ro), _ptr(mo), _ptr(cnt),
+                                          _ptr(ws), _stream(stream)), "la3d_align_select_batch")
+    return ro, mo, cnt
+
+
 def align_apply(relative_depth, coef, intercept=0.0, mask=None, fill: float = 10000.0, device=None, stream=None):
     """``depth = full(fill); depth[sel] = relative[sel] * coef + intercept`` in float32, ``sel`` = mask if given else
     ``~isinf(relative)`` (reference depth.py:82-90).  Returns a float32 tensor shaped like ``relative_depth``."""

@@ -118,6 +118,11 @@ def main():
     rel[torch.rand((H, W), device="cuda") < 0.05] = float("inf")
     t = timed(lambda: la.align_select(rel, met, None, 200.0), n=50)
     out["align_select_640x480"] = dict(s=t, frames_per_s=1 / t, note="three small launches + one 8-byte read-back of the count")
+    P = 64
+    relb, metb = rel[None].expand(P, -1, -1).contiguous(), met[None].expand(P, -1, -1).contiguous()
+    from labelany3d_amd.depth_align import align_select_batch
+    t = timed(lambda: align_select_batch(relb, metb, None, 200.0), n=20)
+    out["align_select_batch_64x640x480"] = dict(s=t, frames_per_s=P / t, note="three launches for 64 frames, counts stay on the device (incl. the wrapper's output allocation)")
     t = timed(lambda: la.align_apply(rel, 2.5, 0.0), n=50)
     out["align_apply_640x480"] = dict(s=t, frames_per_s=1 / t)
     # consumers
