@@ -131,6 +131,54 @@ def required_bytes(masks, image_index=None, num_images=0):
     return B * h * w + depth_tiles * 1024 + B * 39 * 8, tiles
 
 
+def measured_stream_ceiling(masks, min_ms=30.0):
+    """Read-only stream over the SAME mask planes the fit reads (la3d_mask_counts: 16-byte loads, nothing else), timed with HIP
+    events on the launch stream: the bandwidth this box delivers to a pure reader in this run ('also report against
+    a measured read-only stream ceiling').  Runs before the warm-up steps, for at least min_ms of GPU time."""
+    import ctypes as C
+
+    from labelany3d_amd._lib import check, lib
+    B, Hh, Ww = masks.shape
+    counts = torch.empty(B, dtype=torch.int32, device=masks.device)
+    st = torch.cuda.current_stream()
+
+    def run():
+        check(lib.la3d_mask_counts(C.c_void_p(masks.data_ptr()), B, Hh, Ww, C.c_void_p(counts.data_ptr()), C.c_void_p(st.cuda_stream)),
+              "la3d_mask_counts")
+    for _ in range(5):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    nbytes = float(masks.numel())
+    iters = max(20, int(min_ms * 1e-3 * 5.0e12 / nbytes))      # ~min_ms at 5 TB/s
+    best, total_ms, reps = 0.0, 0.0, 0
+    while total_ms < min_ms and reps < 8:
+        torch.cuda.synchronize()
+        e0.record(st)
+        for _ in range(iters):
+            run()
+        e1.record(st)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        total_ms += ms
+        reps += 1
+        best = max(best, nbytes * iters / (ms * 1e-3) / 1e9)
+    return best, int(counts.sum())
+
+
+def traffic_mode_key(args, B):
+    """Key of this run's workload in profiles/traffic_per_launch.json (PMC-measured HBM bytes per step, profiles/r03_run.sh)."""
+    if args.config3:
+        key = f"config3_{args.config3}"
+    elif args.config5:
+        key = "config5" if B == 1024 else f"config5_B{B}"
+    else:
+        key = "config2" if B == 1024 else f"config2_B{B}"
+    for flag in ("rle", "poly", "subsample", "area_hint"):
+        if getattr(args, flag):
+            key += "_" + flag
+    return key
+
+
 def kernel_source_sha256():
     """Hash of the kernel sources: stamps the PMC traffic figure so that a stale constant is detectable."""
     import hashlib
@@ -402,6 +450,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # measured read-only stream ceiling of THIS run (also what brings the chip to its working clocks before the warm-up steps:
+    # a 20-step timed region entered from an idle chip reads ~5 % slower, profiles/r03/exp_step_ramp.py)
+    stream_GBps, _ = measured_stream_ceiling(masks)
     for _ in range(warmup):
         fitter.run(depth, masks, K, slot=0, stream=stream)
     if dist is not None:  # warm the communicator outside the timed region
@@ -482,12 +533,16 @@ def main():
             req_bytes = B * H * W + int(big.sum()) * 500 * 64 + tiles_small * 1024 + B * 39 * 8
         step_s = kern_ms * 1e-3
         achieved = req_bytes / step_s / 1e9
-        traffic, traffic_src, traffic_stale = None, None, None
+        traffic, traffic_src, traffic_stale, traffic_kernel_ns = None, None, None, None
         tp = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
-        if os.path.exists(tp) and not (args.config3 or args.config5 or args.rle or args.poly or args.subsample or args.area_hint) and B == 1024:
+        mode = traffic_mode_key(args, B)
+        if os.path.exists(tp):
             tj = json.load(open(tp))
-            traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
-            traffic_stale = tj.get("kernel_source_sha256") != kernel_source_sha256()
+            ent = tj.get("modes", {}).get(mode)
+            if ent:
+                traffic, traffic_src = ent.get("hbm_bytes_per_step"), ent.get("source")
+                traffic_kernel_ns = ent.get("dominant_kernel_avg_ns")
+                traffic_stale = tj.get("kernel_source_sha256") != kernel_source_sha256()
         if args.config3:
             workload = (f"BASELINE config-3 stand-in: {args.config3} images with a SHARED 480x640 depth plane each, {B} instances "
                         "(~Poisson(7) per image, elliptical u8 masks, log-uniform area 400..100k px) in one call per step")
@@ -542,6 +597,8 @@ def main():
                 "required_bytes_per_launch": req_bytes,
                 "byte_model": "B*H*W mask bytes once + 1024 B x (32 px x 8 row tiles holding a mask pixel; shared depth planes: "
                               "union per image) depth once + 312 B x B records; computed from the generated masks in this run",
+                "measured_stream_GBps": stream_GBps,
+                "frac_of_measured_stream": achieved / stream_GBps if stream_GBps else None,
                 "avg_launch_ms": kern_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "algorithmic_GBps": alg_bytes / step_s / 1e9,
@@ -550,8 +607,14 @@ def main():
                 "traffic_frac_of_peak": (traffic / step_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                 "traffic_source": traffic_src,
                 "traffic_stale": traffic_stale,
-                "note": "frac = required bytes (byte_model) / HIP-event time per step on the launch stream (max over ranks) / 8 TB/s. "
-                        "A step = the fit kernel plus, for 256 < B <= 3072, its two ~5 us launch-order helper kernels. "
+                "traffic_mode": mode,
+                "traffic_kernel_avg_ns_under_rocprof": traffic_kernel_ns,
+                "note": "frac = required bytes (byte_model) / avg_launch_ms / 8 TB/s, where avg_launch_ms is the HIP-EVENT time per step on "
+                        "the launch stream (max over ranks); `value` and ms_per_step are on the WALL clock between the two barriers (a few "
+                        "us per step more at K = 20). measured_stream_GBps = la3d_mask_counts (a pure 16-byte-load reader) over the same "
+                        "mask planes, HIP events, same run, before the warm-up. "
+                        "A step = the fit kernel plus, for 256 < B <= 3072 without area hints, ONE ~5 us estimate kernel (the ranking "
+                        "kernel of rounds 1-2 is gone: every workgroup ranks its chunk's keys itself). "
                         "algorithmic_GBps is SURVEY 8d's H*W*5+312 B/box figure (the kernel never loads depth lines without a mask "
                         "pixel, so that figure exceeds the physical peak and is NOT a roofline fraction). traffic = PMC-measured "
                         "HBM bytes per launch of the profiled build (profiles/, TCC_EA0_RDREQ x 128 B + WRITE_SIZE); "

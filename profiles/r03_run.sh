@@ -1,0 +1,29 @@
+#!/bin/bash
+# Round-3 measurement set (run on the GPU box: gpurun -- bash profiles/r03_run.sh): every bench mode as the driver would run it
+# + a light rocprofv3 profile (kernel stats and HBM counters from the SAME 55-launch command) of every mode, the full profile of
+# the headline, the auxiliary kernels, and traffic_per_launch.json with one entry per mode.
+set -u
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$REPO/gpurun_out/r03
+mkdir -p $O
+rm -f $REPO/gpurun_out/traffic_modes.jsonl
+cd $REPO
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_style.json 2> $O/bench_driver_style.err
+python bench.py > $O/bench_default.json 2>/dev/null
+modes=("config2|" "config2_rle|--rle" "config2_poly|--poly" "config2_subsample|--subsample" "config2_area_hint|--area-hint" "config2_rle_area_hint|--rle --area-hint" \
+       "config5|--config5" "config5_B16384|--config5 --batch 16384" "config3_5000|--config3 5000" "config3_14750|--config3 14750" \
+       "config2_B256|--batch 256" "config2_B8192|--batch 8192")
+for m in "${modes[@]}"; do
+  tag=${m%%|*}; args=${m#*|}
+  python bench.py --no-cpu-baseline $args > $O/bench_$tag.json 2>/dev/null
+  if [ "$tag" == "config2" ]; then LIGHT=0 bash profiles/run_profile.sh r03_$tag $args > /dev/null 2>&1
+  else LIGHT=1 bash profiles/run_profile.sh r03_$tag $args > /dev/null 2>&1; fi
+  cp $REPO/gpurun_out/profile_r03_$tag.md $O/profile_$tag.md
+done
+python profiles/make_traffic_json.py r03
+python profiles/bench_aux.py > $O/bench_aux_mi355x.json 2>/dev/null
+# re-run the headline with the fresh traffic table in place (traffic_stale must read false)
+cp $REPO/gpurun_out/traffic_per_launch.json $REPO/profiles/traffic_per_launch.json
+python bench.py > $O/bench_default_final.json 2>/dev/null
+python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_style_final.json 2>/dev/null
+ls -la $O
