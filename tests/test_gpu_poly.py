@@ -459,3 +459,28 @@ def test_area_hint_orders_the_launch_without_the_estimate_pass(la, monkeypatch):
     assert torch.equal(r0["boxes"], r1["boxes"]) and torch.equal(r0["boxes"], ref["boxes"])
     with pytest.raises(ValueError, match="one entry per instance"):
         la.fit_instances_ex(depth, K, masks=masks, area_hint=areas[:5])
+
+
+def test_g16_fillpoly_against_opencv_itself_on_gpu():
+    """The HIP rasteriser against cv2.fillPoly's own masks (tests/golden/g16_fillpoly.npz, generated where cv2 exists): decoder and
+    filter statistics.  Skipped while the fixture is absent."""
+    import os
+
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g16_fillpoly.npz")
+    if not os.path.exists(path):
+        pytest.skip("g16_fillpoly.npz absent (needs cv2: tests/golden/make_golden_fillpoly.py)")
+    from labelany3d_amd import poly_decode
+
+    g = np.load(path, allow_pickle=False)
+    for tag in ("a", "b", "c"):
+        W, H = (int(v) for v in g[tag + "_size"])
+        off, xy = g[tag + "_off"], g[tag + "_xy"]
+        n = len(off) - 1
+        want = np.unpackbits(g[tag + "_bits"], axis=1)[:, : H * W].reshape(n, H, W).astype(bool)
+        polys = (xy.reshape(-1, 2).astype(np.int32), off.astype(np.int64), np.arange(n + 1, dtype=np.int64), H, W)
+        got = poly_decode(polys).cpu().numpy()
+        assert np.array_equal(got, want), (tag, int((got != want).sum()))

@@ -188,3 +188,27 @@ def test_round_trip_through_the_reference_converter():
         assert iou > (0.98 if len(polys) == 1 and filled.sum() > 10000 else 0.8), (H, W, len(polys), iou)   # thin / ragged shapes lose more
         n += 1
     assert n == 20
+
+
+def _g16():
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g16_fillpoly.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/g16_fillpoly.npz absent: generate it with tests/golden/make_golden_fillpoly.py on a machine with cv2 "
+                    "(the build container has none) - until then the polygon row is 'parity unpinned'")
+    return np.load(path, allow_pickle=False)
+
+
+def test_g16_fillpoly_against_opencv_itself():
+    """cv2.fillPoly's own masks (tests/golden/make_golden_fillpoly.py) against the restatement, bit for bit - runs only where the
+    fixture exists."""
+    g = _g16()
+    for tag in ("a", "b", "c"):
+        W, H = (int(v) for v in g[tag + "_size"])
+        off, xy = g[tag + "_off"], g[tag + "_xy"]
+        want = np.unpackbits(g[tag + "_bits"], axis=1)[:, : H * W].reshape(-1, H, W)
+        for i in range(len(off) - 1):
+            m = np.zeros((H, W), np.uint8)
+            P.fill_poly(m, xy[off[i]:off[i + 1]])
+            assert np.array_equal(m, want[i]), (tag, i, int((m != want[i]).sum()))
