@@ -483,10 +483,14 @@ __device__ inline int order_select(const FitParams& p, int b, Shared* sh, int wa
     for (int h = 0; h < ORDER_CHUNK / 64; ++h)
 #pragma unroll
       for (int t = 0; t < 64; ++t) rank += ((unsigned)__builtin_amdgcn_readlane((int)k[h], t) > mine) ? 1 : 0;
+    // (keys are unique, so exactly one lane matches; the default and the clamp below only matter if the key table was
+    // clobbered - a workspace shared by two concurrent calls - and turn a wild instance index into a duplicated fit)
+    if (wave == 0 && lane == 0) sh->order_inst = start;
     if (wave * 64 + lane < size && rank == lr) sh->order_inst = start + wave * 64 + lane;
   }
   __syncthreads();
-  return __builtin_amdgcn_readfirstlane(sh->order_inst);
+  const int inst = __builtin_amdgcn_readfirstlane(sh->order_inst);
+  return inst < 0 ? 0 : (inst >= p.B ? p.B - 1 : inst);
 }
 
 // ------------------------------------------------------------------------------------------
