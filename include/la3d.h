@@ -239,7 +239,8 @@ int la3d_iou_matrix(const double* boxes_a, int na, const double* boxes_b, int nb
  * scale = np.median(depth_map[overlap] / depth_render[overlap])  (float32 arithmetic, float32 result).
  * num   dev f32 planes (plane of instance n = image_index[n] or n; stride in floats, 0 = one shared plane)
  * den   dev f32 [B][H*W];  mask_a dev u8 [B][H*W];  mask_b dev u8 [B][H*W] | NULL (non-zero = True)
- * median dev f32 [B] (NaN when the overlap is empty or a ratio is NaN, as np.median);  count dev i32 [B]. */
+ * median dev f32 [B] (NaN when the overlap is empty or a ratio is NaN, as np.median);  count dev i32 [B].
+ * H*W <= 819200 (the overlap bit image, the chunk list and the key buffer share one CU's LDS); larger frames: LA3D_ERR_UNSUPPORTED. */
 int la3d_masked_ratio_median(const float* num, int64_t num_plane_stride, const int32_t* image_index, const float* den,
                              const uint8_t* mask_a, const uint8_t* mask_b, int B, int H, int W, float* median,
                              int32_t* count, void* stream);

@@ -12,6 +12,8 @@
 // la3d_split.hip is the other engine) and every other kernel of the C-ABI.  `fit_instances_kernel` in short:
 //   one 512-thread workgroup (8 wave64) per instance, 64 VGPRs / 40 KB LDS -> 4 workgroups per CU (the "retaining" build for
 //            u8 planes up to 1280 instances: 128 VGPRs, 2 workgroups per CU, depth tiles kept on chip between the passes);
+//   order    256 < B <= 3 resident sets: which instance a workgroup fits is decided in the kernel (order_select) from the sort
+//            keys of ONE estimate kernel (or the caller's area hints: no helper launch) - size-balanced, speed only;
 //   phase 0  streams the u8 mask plane once with 16-byte non-temporal loads (or decodes COCO run lengths / rasterises polygon
 //            parts) into a 1-bit-per-pixel image in LDS (38.4 KB for 640x480); meanwhile one lane computes K^-1, Rg, M;
 //   list     deterministic compaction of the 32 px x 8 row tiles that contain a set bit;
@@ -2848,12 +2850,16 @@ int la3d_masked_ratio_median(const float* num, int64_t num_plane_stride, const i
                              int32_t* count, void* stream) {
   if (!num || !den || !mask_a || !median || !count || B < 0 || H <= 0 || W <= 0 || num_plane_stride < 0 ||
       (long long)H * W > (1LL << 20)) {
-    set_err("la3d_masked_ratio_median: bad argument (H*W <= 1048576)");
+    set_err("la3d_masked_ratio_median: bad argument (H*W <= 819200)");
     return LA3D_ERR_ARG;
   }
   if (B == 0) return LA3D_SUCCESS;
   const int HW = H * W, nwords = (HW + 31) / 32;
   const size_t lds = (size_t)((nwords + 3) & ~3) * 4 + (size_t)(RM_CAP + 1024 + 256 + 16) * 4 + (size_t)((HW + 63) / 64) * 2 + 16;
+  if (lds > 160 * 1024) {   // bit image + chunk list + key buffer must fit one CU's LDS: frames up to ~820 k pixels
+    set_err("la3d_masked_ratio_median: frame too large for the LDS bit image (H*W <= 819200)");
+    return LA3D_ERR_UNSUPPORTED;
+  }
   allow_big_lds(reinterpret_cast<const void*>(ratio_median_kernel));
   hipLaunchKernelGGL(ratio_median_kernel, dim3(B), dim3(RM_NT), lds, static_cast<hipStream_t>(stream), num,
                      (long long)num_plane_stride, image_index, den, mask_a, mask_b, HW, nwords, median, count);
