@@ -228,7 +228,7 @@ template <int PASS, bool CHK, int RET>
 __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__ dpl, const unsigned* bits,
                                    const unsigned short* list, int nactive, const double* A0, const double* A1,
                                    const double* A2, int wave, int lane, double* acc, int* cnt, Keep<RET>& keep,
-                                   uint4* lds_keep = nullptr) {
+                                   uint4* lds_keep = nullptr, unsigned* qhead = nullptr) {
   TileCtx c;
   c.W = p.W; c.H = p.H; c.ntx = p.ntx; c.r = lane >> 3; c.cq = lane & 7;
   c.a00 = A0[0]; c.a01 = A0[1]; c.a02 = A0[2];
@@ -285,10 +285,26 @@ __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__
     }
   }
   const int rev_base = (PASS == 1 && !dense) ? kept + nsteps - 1 : -1;
-  for (int j0 = jstart; j0 < nsteps; j0 += NWAVE * TG) {
-    uint4 dq[TG];
-    const unsigned pk = tile_fetch(c, dpl, bits, list, nsteps, dense, j0, rev_base, dq);
-    tile_compute<PASS, CHK>(c, list, nsteps, dense, j0, rev_base, dq, pk, sv, &n);
+  if (PASS == 1 && qhead != nullptr && !dense) {
+    // pass B: the not-retained tiles are an LDS WORK QUEUE - a wave that is done pulls the next TG tiles (one ds_add_rtn per
+    // step) instead of walking a fixed stride, so no wave waits for a slower neighbour at the end of the pass.  Extents are
+    // min / max: exact whatever the order, so the records stay bit-identical (pass A, whose fp64 sums depend on the grouping,
+    // keeps its static assignment).
+    while (true) {
+      unsigned off = 0;
+      if (lane == 0) off = atomicAdd(qhead, (unsigned)TG);
+      const int j0 = kept + __builtin_amdgcn_readfirstlane((int)off);
+      if (j0 >= nsteps) break;
+      uint4 dq[TG];
+      const unsigned pk = tile_fetch(c, dpl, bits, list, nsteps, false, j0, rev_base, dq);
+      tile_compute<PASS, CHK>(c, list, nsteps, false, j0, rev_base, dq, pk, sv, &n);
+    }
+  } else {
+    for (int j0 = jstart; j0 < nsteps; j0 += NWAVE * TG) {
+      uint4 dq[TG];
+      const unsigned pk = tile_fetch(c, dpl, bits, list, nsteps, dense, j0, rev_base, dq);
+      tile_compute<PASS, CHK>(c, list, nsteps, dense, j0, rev_base, dq, pk, sv, &n);
+    }
   }
 #pragma unroll
   for (int i = 0; i < (PASS == 0 ? 5 : 6); ++i) acc[i] = sv[i];
@@ -342,6 +358,7 @@ __device__ inline void stage_moments_to_axis(Shared* sh, const FitParams& p, int
     double cy = NAN, sy = NAN;
     if (st == LA3D_BOX_OK) axis_from_sums((double)n, s[0], s[1], s[2], s[3], s[4], &cy, &sy, &gap);
     sh->cyaw = cy; sh->syaw = sy;
+    sh->qhead = 0u;   // pass B's work queue starts at the first not-retained tile
     sh->st = st;
     sh->n_valid = n;
     sh->gap = gap;
@@ -907,8 +924,15 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
     yaw_rows(sh, Mg, N0, N2);
     int d0 = 0, d1 = 0;
     if (TILED) {
-      if (checked) sweep_tiled<1, true, RET>(p, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0, keep, lds_keep);
-      else sweep_tiled<1, false, RET>(p, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0, keep, lds_keep);
+#ifndef LA3D_QUEUE
+#define LA3D_QUEUE 1
+#endif
+      // (plain build only: in the retaining build the queue covers just the not-retained remainder and measured 3 us SLOWER at
+      // B = 1024; plain build: run-length input 74.8 -> 71.3 us, B = 512 88.7 -> 85.5, config 5 at 16 k 945 -> 927;
+      // profiles/r03/r03_pass_b_queue.txt)
+      unsigned* qh = (LA3D_QUEUE && RET == 0) ? &sh->qhead : nullptr;
+      if (checked) sweep_tiled<1, true, RET>(p, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0, keep, lds_keep, qh);
+      else sweep_tiled<1, false, RET>(p, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0, keep, lds_keep, qh);
     }
     else sweep<VEC, LDSMASK, 1>(p, dpl, mpl, bits, N0, Mg + 3, N2, wave, lane, ext, &d0, &d1);
 #else

@@ -468,6 +468,8 @@ struct alignas(16) Shared {
   double gap;      // relative eigenvalue gap (aux[3]), kept for the deferred aux write
   int nm;          // mask pixels (aux[2])
   int order_inst;  // the instance this workgroup fits (size-balanced launch order)
+  unsigned qhead;  // pass B: head of the LDS work queue over the not-retained part of the active-tile list
+  unsigned qpad[3];
 #ifdef LA3D_TIMELINE
   double* tl;      // measurement build: this workgroup's stamp row (profiles/timeline.py)
 #endif
