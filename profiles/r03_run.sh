@@ -20,6 +20,10 @@ for m in "${modes[@]}"; do
   else LIGHT=1 bash profiles/run_profile.sh r03_$tag $args > /dev/null 2>&1; fi
   cp $REPO/gpurun_out/profile_r03_$tag.md $O/profile_$tag.md
 done
+# the headline workload with the plain build pinned (same time since the pass-B work queue; more bytes): for DESIGN.md section 5
+LA3D_RETAIN=0 python bench.py --no-cpu-baseline > $O/bench_config2_plain.json 2>/dev/null
+LA3D_RETAIN=0 LIGHT=1 bash profiles/run_profile.sh r03_config2_plain > /dev/null 2>&1
+cp $REPO/gpurun_out/profile_r03_config2_plain.md $O/profile_config2_plain.md
 python profiles/make_traffic_json.py r03
 python profiles/bench_aux.py > $O/bench_aux_mi355x.json 2>/dev/null
 # re-run the headline with the fresh traffic table in place (traffic_stale must read false)
