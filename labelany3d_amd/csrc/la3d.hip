@@ -147,6 +147,9 @@ __device__ inline void sweep(const FitParams& p, const float* __restrict__ dpl, 
 #define LA3D_TG 4
 #endif
 constexpr int TG = LA3D_TG;
+#ifndef LA3D_LDSKEEP0
+#define LA3D_LDSKEEP0 1
+#endif
 
 // Depth tiles kept on chip between the two passes (RET > 0: the "retaining" build of the kernel, 128 VGPRs, two workgroups
 // per CU).  The first RET steps of every wave (RET x TG tiles, i.e. RET x TG x NWAVE tiles per instance) keep their depth
@@ -160,6 +163,10 @@ struct Keep {
 
 struct TileCtx {
   int W, H, ntx, r, cq;
+  // compacted bit image (plain build): list entry e owns the eight row words of its tile at words [8e, 8e + 8) of the image
+  // region, and the depth quads of list entries < keepn stay in the LDS that frees (1 KiB per tile) between the passes
+  int compact, keepn;
+  uint4* keep;
   double a00, a01, a02, a10, a11, a12, a20, a21, a22;
 };
 
@@ -176,38 +183,46 @@ __device__ inline void tile_coords(const TileCtx& c, const unsigned short* list,
 
 // stage 1 of a step (TG consecutive list entries of one wave): bit-image nibbles, then all depth loads back to back.
 // Returns the TG nibbles packed into one word.
+template <int PASS, bool LK>
 __device__ inline unsigned tile_fetch(const TileCtx& c, const float* __restrict__ dpl, const unsigned* bits,
                                       const unsigned short* list, int nsteps, bool dense, int j0, int rev_base, uint4* dq) {
   unsigned nib[TG];
-  int txs[TG], tys[TG];
+  int txs[TG], tys[TG], ent[TG];
 #pragma unroll
   for (int g = 0; g < TG; ++g) {
     const int j = j0 + g;
-    nib[g] = 0; txs[g] = 0; tys[g] = 0;
+    nib[g] = 0; txs[g] = 0; tys[g] = 0; ent[g] = 0x7fffffff;
     dq[g] = make_uint4(0u, 0u, 0u, 0u);
     if (j < nsteps) {
       tile_coords(c, list, dense, j, rev_base, &txs[g], &tys[g]);
-      const int row = tys[g] * 8 + c.r;
-      if (row < c.H) nib[g] = (bits[row * c.ntx + txs[g]] >> (c.cq * 4)) & 0xFu;
+      if (LK && c.compact) {   // uniform
+        ent[g] = rev_base >= 0 ? rev_base - j : j;
+        nib[g] = (bits[ent[g] * 8 + c.r] >> (c.cq * 4)) & 0xFu;   // rows past the frame were stored as zeros
+      } else {
+        const int row = tys[g] * 8 + c.r;
+        if (row < c.H) nib[g] = (bits[row * c.ntx + txs[g]] >> (c.cq * 4)) & 0xFu;
+      }
     }
   }
   unsigned pk = 0;
 #pragma unroll
   for (int g = 0; g < TG; ++g) {
-    if (nib[g]) dq[g] = *reinterpret_cast<const uint4*>(dpl + (long long)(tys[g] * 8 + c.r) * c.W + txs[g] * 32 + c.cq * 4);
+    if (LK && PASS == 1 && ent[g] < c.keepn) dq[g] = c.keep[ent[g] * 64 + (c.r * 8 + c.cq)];   // kept by pass A
+    else if (nib[g]) dq[g] = *reinterpret_cast<const uint4*>(dpl + (long long)(tys[g] * 8 + c.r) * c.W + txs[g] * 32 + c.cq * 4);
     pk |= nib[g] << (4 * g);
   }
   return pk;
 }
 
 // stage 2: the pixel math of a step on quads dq / nibbles pk (all lanes; unmasked lanes carry zeros / NaNs)
-template <int PASS, bool CHK>
+template <int PASS, bool CHK, bool LK = false>
 __device__ inline void tile_compute(const TileCtx& c, const unsigned short* list, int nsteps, bool dense, int j0, int rev_base,
                                     const uint4* dq, unsigned pk, double* sv, int* n) {
 #pragma unroll
   for (int g = 0; g < TG; ++g) {
     const int j = j0 + g;
     if (j >= nsteps) continue;   // wave-uniform
+    if (LK && PASS == 0 && j < c.keepn) c.keep[j * 64 + (c.r * 8 + c.cq)] = dq[g];   // (pass A walks the list forwards: entry = j)
     const unsigned nib = (pk >> (4 * g)) & 0xFu;
     if (dense && __ballot(nib != 0) == 0) continue;
     int tx, ty;
@@ -228,9 +243,15 @@ template <int PASS, bool CHK, int RET>
 __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__ dpl, const unsigned* bits,
                                    const unsigned short* list, int nactive, const double* A0, const double* A1,
                                    const double* A2, int wave, int lane, double* acc, int* cnt, Keep<RET>& keep,
-                                   uint4* lds_keep = nullptr, unsigned* qhead = nullptr) {
+                                   uint4* lds_keep = nullptr, unsigned* qhead = nullptr, int compact = 0) {
+  constexpr bool LK = LA3D_LDSKEEP0 && RET == 0;
   TileCtx c;
   c.W = p.W; c.H = p.H; c.ntx = p.ntx; c.r = lane >> 3; c.cq = lane & 7;
+  c.compact = LK ? compact : 0; c.keepn = 0; c.keep = nullptr;
+  if (LK && compact) {   // uniform: the image region behind the compacted entries holds depth tiles between the passes
+    c.keepn = (p.mask_lds_bytes - nactive * 32) >> 10;
+    c.keep = const_cast<uint4*>(reinterpret_cast<const uint4*>(bits + nactive * 8));
+  }
   c.a00 = A0[0]; c.a01 = A0[1]; c.a02 = A0[2];
   c.a20 = A2[0]; c.a21 = A2[1]; c.a22 = A2[2];
   c.a10 = c.a11 = c.a12 = 0;
@@ -250,7 +271,7 @@ __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__
       for (int s = 0; s < RET; ++s) {
         const int j0 = (s * NWAVE + wave) * TG;
         keep.nib[s] = 0;
-        if (j0 < nsteps) keep.nib[s] = tile_fetch(c, dpl, bits, list, nsteps, false, j0, -1, keep.dq[s]);
+        if (j0 < nsteps) keep.nib[s] = tile_fetch<PASS, false>(c, dpl, bits, list, nsteps, false, j0, -1, keep.dq[s]);
       }
     }
 #pragma unroll
@@ -269,7 +290,7 @@ __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__
         uint4 dq[TG];
         unsigned pk;
         if (PASS == 0) {
-          pk = tile_fetch(c, dpl, bits, list, nsteps, false, jstart, -1, dq);
+          pk = tile_fetch<PASS, false>(c, dpl, bits, list, nsteps, false, jstart, -1, dq);
 #pragma unroll
           for (int g = 0; g < TG; ++g) slot[g * 64] = dq[g];
           *nslot = pk;
@@ -296,14 +317,14 @@ __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__
       const int j0 = kept + __builtin_amdgcn_readfirstlane((int)off);
       if (j0 >= nsteps) break;
       uint4 dq[TG];
-      const unsigned pk = tile_fetch(c, dpl, bits, list, nsteps, false, j0, rev_base, dq);
-      tile_compute<PASS, CHK>(c, list, nsteps, false, j0, rev_base, dq, pk, sv, &n);
+      const unsigned pk = tile_fetch<PASS, LK>(c, dpl, bits, list, nsteps, false, j0, rev_base, dq);
+      tile_compute<PASS, CHK, LK>(c, list, nsteps, false, j0, rev_base, dq, pk, sv, &n);
     }
   } else {
     for (int j0 = jstart; j0 < nsteps; j0 += NWAVE * TG) {
       uint4 dq[TG];
-      const unsigned pk = tile_fetch(c, dpl, bits, list, nsteps, dense, j0, rev_base, dq);
-      tile_compute<PASS, CHK>(c, list, nsteps, dense, j0, rev_base, dq, pk, sv, &n);
+      const unsigned pk = tile_fetch<PASS, LK>(c, dpl, bits, list, nsteps, dense, j0, rev_base, dq);
+      tile_compute<PASS, CHK, LK>(c, list, nsteps, dense, j0, rev_base, dq, pk, sv, &n);
     }
   }
 #pragma unroll
@@ -544,6 +565,7 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
 #else
   const int inst = p.order_nch > 0 ? order_select(p, (int)blockIdx.x, sh, wave, lane) : xcd_remap(blockIdx.x, p.B);
 #endif
+  if (tid == 0) sh->order_inst = inst;   // (re-read after the mask stage, see below)
   const int img = p.image_index ? p.image_index[inst] : inst;
   const int HW = p.HW;
   const float* dpl = p.depth + (long long)img * p.depth_plane_stride;
@@ -666,22 +688,25 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
   }
   __syncthreads();
   LA3D_STAMP(1);
+  // (from here on the instance index is re-read from LDS: live across the decode stage it costs the polygon build a spilled
+  // register pair)
+  const int inst_p = __builtin_amdgcn_readfirstlane(sh->order_inst);
   if (SRC != 0 && LDSMASK && p.filter_boundary >= 0) {   // uniform
     // the reference's instance filter (src/util.py:375) on the bit image just built: a dropped instance costs no passes
     int st4[4];
     bits_filter_stats<NT>(bits, p.H, p.W, p.filter_boundary, reinterpret_cast<int*>(sh->part), tid, st4);
-    if (p.filter_stats && tid < 4) (p.filter_stats + (long long)inst * 4)[tid] = st4[tid];   // (uniform base: scalar address arithmetic)
+    if (p.filter_stats && tid < 4) (p.filter_stats + (long long)inst_p * 4)[tid] = st4[tid];   // (uniform base: scalar address arithmetic)
     const int height = SRC == 1 ? st4[1] : st4[2];   // run lengths: rows holding a pixel (:368-369); polygons: last - first + 1 (:328-335)
     const bool keep = 16 * height > p.H && st4[3] < p.filter_max_edge && st4[0] >= p.filter_min_area;   // height / H > 0.0625
     if (!keep) {
       if (tid == 0) {
         if (p.aux) {
-          double* a = p.aux + (long long)inst * LA3D_AUX;
+          double* a = p.aux + (long long)inst_p * LA3D_AUX;
           a[0] = NAN; a[1] = 0.0; a[2] = (double)st4[0]; a[3] = NAN;
         }
-        p.status[inst] = LA3D_BOX_FILTERED;
-        write_nan_box(p.out + (long long)inst * LA3D_REC);
-        if (p.proj) { for (int j = 0; j < 8; ++j) p.proj[(long long)inst * 8 + j] = NAN; }
+        p.status[inst_p] = LA3D_BOX_FILTERED;
+        write_nan_box(p.out + (long long)inst_p * LA3D_REC);
+        if (p.proj) { for (int j = 0; j < 8; ++j) p.proj[(long long)inst_p * 8 + j] = NAN; }
       }
       return;
     }
@@ -704,6 +729,10 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
 
   // ---- active-tile list (deterministic two-pass compaction: count, prefix, write) ----------------
   int nactive = 0;
+  // plain build: the bit image is compacted to the active tiles (eight row words per list entry) and the LDS that frees keeps
+  // depth tiles between the passes (sweep_tiled)
+  constexpr bool LK = LA3D_LDSKEEP0 && TILED && !SAMPLE && RET == 0;
+  int compact = 0;
   if (TILED && !sampled) {
     const int ntiles = p.ntx * p.nty, per = p.tiles_per_wave;
     const int tbeg = wave * per, tend = min(tbeg + per, ntiles);
@@ -712,6 +741,7 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
       // one pass: a wave looks at up to 4 x 64 tiles; the ballots stay in SGPRs across the barrier, the eight row words
       // of a tile are read back to back (rows past the frame re-read the last one), no integer division
       unsigned long long bal[4];
+      unsigned wrd[LK ? 4 : 1][8];
       int wcount = 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -722,7 +752,11 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
           const int rmax = p.H - 1 - ty * 8;                                        // >= 0
           const unsigned* bw = bits + (ty * 8) * p.ntx + tx;
 #pragma unroll
-          for (int rr = 0; rr < 8; ++rr) any |= bw[min(rr, rmax) * p.ntx];
+          for (int rr = 0; rr < 8; ++rr) {
+            const unsigned w = bw[min(rr, rmax) * p.ntx];
+            any |= w;
+            if (LK) wrd[k][rr] = rr <= rmax ? w : 0u;
+          }
         }
         bal[k] = __ballot(any != 0);
         wcount += __popcll(bal[k]);
@@ -746,6 +780,20 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
             list[off + __popcll(bal[k] & ((1ull << lane) - 1ull))] = (unsigned short)((ty << 8) | tx);
           }
           off += __popcll(bal[k]);
+        }
+        if (LK && nactive * 32 <= p.mask_lds_bytes) {   // uniform
+          // every wave read its row words before the barrier above: the image region can be overwritten in place
+          compact = 1;
+          off = base;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if ((bal[k] >> lane) & 1ull) {
+              uint4* e = reinterpret_cast<uint4*>(bits) + 2 * (off + __popcll(bal[k] & ((1ull << lane) - 1ull)));
+              e[0] = make_uint4(wrd[k][0], wrd[k][1], wrd[k][2], wrd[k][3]);
+              e[1] = make_uint4(wrd[k][4], wrd[k][5], wrd[k][6], wrd[k][7]);
+            }
+            off += __popcll(bal[k]);
+          }
         }
       }
     } else {
@@ -885,7 +933,7 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
 #ifndef LA3D_ABL_NO_PASSA
   if (!sampled) {
     if (TILED) {
-      sweep_tiled<0, false, RET>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, lds_keep);
+      sweep_tiled<0, false, RET>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, lds_keep, nullptr, compact);
       cnt = nmask;   // the optimistic pass does not count: with every masked depth finite, valid pixels = mask pixels
     }
     else sweep<VEC, LDSMASK, 0>(p, dpl, mpl, bits, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, &nmask);
@@ -895,15 +943,15 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
 #endif
 
   LA3D_STAMP(3);
-  stage_moments_to_axis(sh, p, inst, acc, cnt, nmask, tid, wave, lane, TILED && !sampled);
+  stage_moments_to_axis(sh, p, inst_p, acc, cnt, nmask, tid, wave, lane, TILED && !sampled);
   if (TILED && sh->redo) {  // uniform
     __syncthreads();        // everyone has read sh->redo and the partials before they are rewritten
 #pragma unroll
     for (int i = 0; i < 5; ++i) acc[i] = 0;
     cnt = 0;
     checked = true;
-    sweep_tiled<0, true, RET>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, lds_keep);
-    stage_moments_to_axis(sh, p, inst, acc, cnt, nmask, tid, wave, lane, false);
+    sweep_tiled<0, true, RET>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, lds_keep, nullptr, compact);
+    stage_moments_to_axis(sh, p, inst_p, acc, cnt, nmask, tid, wave, lane, false);
   }
   LA3D_STAMP(4);
   if (sh->st != LA3D_BOX_OK) return;
@@ -931,8 +979,8 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
       // B = 1024; plain build: run-length input 74.8 -> 71.3 us, B = 512 88.7 -> 85.5, config 5 at 16 k 945 -> 927;
       // profiles/r03/r03_pass_b_queue.txt)
       unsigned* qh = (LA3D_QUEUE && RET == 0) ? &sh->qhead : nullptr;
-      if (checked) sweep_tiled<1, true, RET>(p, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0, keep, lds_keep, qh);
-      else sweep_tiled<1, false, RET>(p, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0, keep, lds_keep, qh);
+      if (checked) sweep_tiled<1, true, RET>(p, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0, keep, lds_keep, qh, compact);
+      else sweep_tiled<1, false, RET>(p, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0, keep, lds_keep, qh, compact);
     }
     else sweep<VEC, LDSMASK, 1>(p, dpl, mpl, bits, N0, Mg + 3, N2, wave, lane, ext, &d0, &d1);
 #else
@@ -940,8 +988,8 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
 #endif
   }
   LA3D_STAMP(5);
-  stage_extents_to_box(sh, p, inst, ext, tid, wave, lane);
-  stage_status_aux(sh, p, inst, tid);
+  stage_extents_to_box(sh, p, inst_p, ext, tid, wave, lane);
+  stage_status_aux(sh, p, inst_p, tid);
   LA3D_STAMP(6);
 }
 
@@ -1278,67 +1326,48 @@ struct UnprojParams {
   float rcpW;
 };
 
+#ifndef LA3D_UNPROJ_V16
+#define LA3D_UNPROJ_V16 1
+#endif
+#ifndef LA3D_UNPROJ_NTLOAD
+#define LA3D_UNPROJ_NTLOAD 0   // (a depth plane that a previous kernel left in the cache should be found there)
+#endif
+// One wave turns 64 consecutive pixels into 64 points per step.  The points go through a per-wave LDS stage so that the wave
+// writes its 1536 (f64) / 768 (f32) contiguous output bytes as whole 16-byte non-temporal stores (the output is written once and
+// read by somebody else: measured 64 / 256 / 1024 frames of 640x480 -> f64: 148 / 541 / 1921 us with plain per-lane stores,
+// 89 / 477 / 1656 us this way = 6.1 / 4.6 / 5.3 TB/s; a device copy of the same size moves 5.3 / 4.4 / 4.7 TB/s, a pure fill
+// 6.4 / 6.8 / 6.8 TB/s: profiles/r03/r03_unproject.txt).  vec16: every frame's output base is
+// 16-byte aligned.  kinv: the frame's inverse intrinsics in LDS.
 template <typename OutT>
-__global__ __launch_bounds__(256) void unproject_kernel(const float* __restrict__ depth, OutT* __restrict__ out,
-                                                        const UnprojParams p) {
-  const int stride = gridDim.x * blockDim.x;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < p.HW; i += stride) {
-    unsigned u, v;
-    pix_uv((unsigned)i, p.W, p.rcpW, &u, &v);
-    const double d = (double)depth[i], ud = (double)u, vd = (double)v;
-    // (D * Kinv) @ [u, v, 1]   — precedence as in the reference, src/util.py:71-72
-    double q[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) q[r] = (d * p.Kinv[r * 3]) * ud + (d * p.Kinv[r * 3 + 1]) * vd + (d * p.Kinv[r * 3 + 2]);
-    if (p.has_rt) {  // R @ p + t  (:74)
-      double w[3];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) w[r] = p.R[r * 3] * q[0] + p.R[r * 3 + 1] * q[1] + p.R[r * 3 + 2] * q[2] + p.t[r];
-      q[0] = w[0]; q[1] = w[1]; q[2] = w[2];
-    } else {
-      // R = I, t = 0 in the reference still multiplies: 1*x + 0*y + 0*z + 0 — a NaN/inf component
-      // poisons its neighbours exactly as there
-      const double w0 = 1.0 * q[0] + 0.0 * q[1] + 0.0 * q[2] + 0.0;
-      const double w1 = 0.0 * q[0] + 1.0 * q[1] + 0.0 * q[2] + 0.0;
-      const double w2 = 0.0 * q[0] + 0.0 * q[1] + 1.0 * q[2] + 0.0;
-      q[0] = w0; q[1] = w1; q[2] = w2;
-    }
-    OutT* o = out + (long long)i * 3;
-    o[0] = (OutT)q[0]; o[1] = (OutT)q[1]; o[2] = (OutT)q[2];
-  }
-}
-
-// P frames in one launch: blockIdx.y = frame; the frame's K is inverted by one thread (device inv3 = the host routine's elimination)
-template <typename OutT>
-__global__ __launch_bounds__(256) void unproject_batch_kernel(const float* __restrict__ depth, const double* __restrict__ K,
-                                                              int k_stride, OutT* __restrict__ out, const UnprojParams p) {
-  __shared__ double kinv[9];
-  __shared__ OutT stage[4][192];   // one wave's 64 points, so that every store instruction writes whole lines (lane-contiguous)
-  if (threadIdx.x == 0) inv3(K + (long long)blockIdx.y * k_stride, kinv);
-  __syncthreads();
-  const float* dp = depth + (long long)blockIdx.y * p.HW;
-  OutT* op = out + (long long)blockIdx.y * p.HW * 3;
-  const int stride = gridDim.x * blockDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i0 = blockIdx.x * blockDim.x + wave * 64; i0 < p.HW; i0 += stride) {   // wave-uniform trip count
+__device__ inline void unproject_frame(const float* __restrict__ dp, OutT* __restrict__ op, const double* kinv, OutT* sl,
+                                       const UnprojParams& p, int first, int stride, int lane, bool vec16) {
+  constexpr int N16 = 64 * 3 * (int)sizeof(OutT) / 16;   // 16-byte pieces per 64 points
+  for (int i0 = first; i0 < p.HW; i0 += stride) {   // wave-uniform trip count
     const int i = i0 + lane;
     double w[3] = {0, 0, 0};
     if (i < p.HW) {
       unsigned u, v;
       pix_uv((unsigned)i, p.W, p.rcpW, &u, &v);
+#if LA3D_UNPROJ_NTLOAD
+      const double d = (double)__builtin_nontemporal_load(dp + i), ud = (double)u, vd = (double)v;
+#else
       const double d = (double)dp[i], ud = (double)u, vd = (double)v;
+#endif
+      // (D * Kinv) @ [u, v, 1]   - precedence as in the reference, src/util.py:71-72
       double q[3];
 #pragma unroll
       for (int r = 0; r < 3; ++r) q[r] = (d * kinv[r * 3]) * ud + (d * kinv[r * 3 + 1]) * vd + (d * kinv[r * 3 + 2]);
-      if (p.has_rt) {
+      if (p.has_rt) {   // R @ p + t  (:74)
 #pragma unroll
         for (int r = 0; r < 3; ++r) w[r] = p.R[r * 3] * q[0] + p.R[r * 3 + 1] * q[1] + p.R[r * 3 + 2] * q[2] + p.t[r];
-      } else {   // the reference's identity transform, multiplied out (NaN / inf propagate as there)
+      } else {
+        // R = I, t = 0 in the reference still multiplies: 1*x + 0*y + 0*z + 0 - a NaN / inf component poisons its
+        // neighbours exactly as there
         w[0] = 1.0 * q[0] + 0.0 * q[1] + 0.0 * q[2] + 0.0;
         w[1] = 0.0 * q[0] + 1.0 * q[1] + 0.0 * q[2] + 0.0;
         w[2] = 0.0 * q[0] + 0.0 * q[1] + 1.0 * q[2] + 0.0;
       }
     }
-    OutT* sl = stage[wave];
     sl[lane * 3] = (OutT)w[0]; sl[lane * 3 + 1] = (OutT)w[1]; sl[lane * 3 + 2] = (OutT)w[2];
     // lanes exchange through LDS: the hardware completes a wave's LDS operations in order, but the compiler must be told that the
     // reads below depend on OTHER lanes' writes (it can prove that 3 lane + 1 never equals 64 + lane and would hoist that read)
@@ -1346,13 +1375,45 @@ __global__ __launch_bounds__(256) void unproject_batch_kernel(const float* __res
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const long long base = (long long)i0 * 3, lim = (long long)p.HW * 3;
+    if (LA3D_UNPROJ_V16 && vec16 && i0 + 64 <= p.HW) {   // uniform
+      const u32x4* s16 = reinterpret_cast<const u32x4*>(sl);
+      u32x4* o16 = reinterpret_cast<u32x4*>(op + base);
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-      if (base + k * 64 + lane < lim) op[base + k * 64 + lane] = sl[k * 64 + lane];
+      for (int k = 0; k < (N16 + 63) / 64; ++k)
+        if (k * 64 + lane < N16) __builtin_nontemporal_store(s16[k * 64 + lane], o16 + k * 64 + lane);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (base + k * 64 + lane < lim) __builtin_nontemporal_store(sl[k * 64 + lane], op + base + k * 64 + lane);
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void unproject_kernel(const float* __restrict__ depth, OutT* __restrict__ out,
+                                                        const UnprojParams p, int vec16) {
+  __shared__ double kinv[9];
+  __shared__ __attribute__((aligned(16))) OutT stage[4][192];
+  if (threadIdx.x < 9) kinv[threadIdx.x] = p.Kinv[threadIdx.x];   // (inverted on the host: la3d_unproject)
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unproject_frame<OutT>(depth, out, kinv, stage[wave], p, blockIdx.x * blockDim.x + wave * 64, gridDim.x * blockDim.x, lane, vec16 != 0);
+}
+
+// P frames in one launch: blockIdx.y = frame; the frame's K is inverted by one thread (device inv3 = the host routine's elimination)
+template <typename OutT>
+__global__ __launch_bounds__(256) void unproject_batch_kernel(const float* __restrict__ depth, const double* __restrict__ K,
+                                                              int k_stride, OutT* __restrict__ out, const UnprojParams p, int vec16) {
+  __shared__ double kinv[9];
+  __shared__ __attribute__((aligned(16))) OutT stage[4][192];
+  if (threadIdx.x == 0) inv3(K + (long long)blockIdx.y * k_stride, kinv);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unproject_frame<OutT>(depth + (long long)blockIdx.y * p.HW, out + (long long)blockIdx.y * p.HW * 3, kinv, stage[wave], p,
+                        blockIdx.x * blockDim.x + wave * 64, gridDim.x * blockDim.x, lane, vec16 != 0);
 }
 
 __global__ __launch_bounds__(256) void mask_counts_kernel(const unsigned char* __restrict__ mask, int HW, int vec,
@@ -2469,8 +2530,9 @@ int la3d_unproject(const float* depth, const double* K9, const double* Rt12, int
   p.H = H; p.W = W; p.HW = H * W; p.rcpW = 1.0f / (float)W;
   const int blocks = (p.HW + 255) / 256 < 2048 ? (p.HW + 255) / 256 : 2048;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (out_is_f64) hipLaunchKernelGGL(unproject_kernel<double>, dim3(blocks), dim3(256), 0, s, depth, static_cast<double*>(out), p);
-  else hipLaunchKernelGGL(unproject_kernel<float>, dim3(blocks), dim3(256), 0, s, depth, static_cast<float*>(out), p);
+  const int vec16 = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+  if (out_is_f64) hipLaunchKernelGGL(unproject_kernel<double>, dim3(blocks), dim3(256), 0, s, depth, static_cast<double*>(out), p, vec16);
+  else hipLaunchKernelGGL(unproject_kernel<float>, dim3(blocks), dim3(256), 0, s, depth, static_cast<float*>(out), p, vec16);
   return check_launch("unproject_kernel");
 }
 
@@ -2492,8 +2554,10 @@ int la3d_unproject_batch(const float* depth, const double* K, int32_t k_stride, 
   const int want = (8192 + P - 1) / P;   // enough workgroups over all frames to fill the chip several times
   if (bx > want) bx = want < 1 ? 1 : want;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (out_is_f64) hipLaunchKernelGGL(unproject_batch_kernel<double>, dim3(bx, P), dim3(256), 0, s, depth, K, k_stride, static_cast<double*>(out), p);
-  else hipLaunchKernelGGL(unproject_batch_kernel<float>, dim3(bx, P), dim3(256), 0, s, depth, K, k_stride, static_cast<float*>(out), p);
+  // 16-byte stores need every frame's output base 16-aligned: HW * 3 * sizeof(OutT) a multiple of 16
+  const int vec16 = (reinterpret_cast<uintptr_t>(out) & 15) == 0 && ((long long)p.HW * 3 * (out_is_f64 ? 8 : 4)) % 16 == 0;
+  if (out_is_f64) hipLaunchKernelGGL(unproject_batch_kernel<double>, dim3(bx, P), dim3(256), 0, s, depth, K, k_stride, static_cast<double*>(out), p, vec16);
+  else hipLaunchKernelGGL(unproject_batch_kernel<float>, dim3(bx, P), dim3(256), 0, s, depth, K, k_stride, static_cast<float*>(out), p, vec16);
   return check_launch("unproject_batch_kernel");
 }
 

@@ -125,6 +125,16 @@ def test_unproject_batch_many_frames_one_launch(la, golden):
     ob = la.unproject(big, Kb)
     for i in (0, 17, 36):
         np.testing.assert_allclose(np_(ob[i]), np_(la.unproject(big[i], Kb[i])), rtol=1e-14, atol=0)
+    # frame sizes off the 64-pixel / 16-byte grid: ragged last group with 16-byte stores (33x48), frames whose output base is
+    # only 8-byte aligned (33x47: per-lane stores), f64 and f32
+    for (hh, ww) in ((33, 48), (33, 47), (5, 13)):
+        odd = rs.uniform(0.5, 10, (3, hh, ww)).astype(np.float32)
+        oo = la.unproject(odd, Kb[:3])
+        o32 = la.unproject(odd, Kb[:3], out_dtype=torch.float32)
+        for i in range(3):
+            np.testing.assert_allclose(np_(oo[i]), O.depth_to_points(odd[i][None], Kb[i]), rtol=1e-13, atol=1e-13)
+            np.testing.assert_allclose(np_(oo[i]), np_(la.unproject(odd[i], Kb[i])), rtol=1e-14, atol=0)
+        np.testing.assert_allclose(np_(o32), np_(oo).astype(np.float32), rtol=1e-6)
     with pytest.raises(ValueError, match="K must be"):
         la.unproject(d, Ks[:2])
 
