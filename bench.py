@@ -588,8 +588,8 @@ def main():
             "roofline": {
                 "bound": "hbm",
                 "kernel": ("fit_instances_kernel<VEC,LDSMASK,SAMPLE=1> (instance engine, reference-subsample mode)" if args.subsample else
-                           "fit_instances_kernel<VEC,LDSMASK,SAMPLE=0,TILED,SRC,RET> (instance engine; u8 planes with 336 < B <= 1280 take "
-                           "the retaining build RET=4, larger batches and run-length / polygon input RET=0; B <= 336 takes the split engine)"),
+                           "fit_instances_kernel<VEC,LDSMASK,SAMPLE=0,TILED,SRC,RET> (instance engine; u8 planes with 272 < B <= 1280 take "
+                           "the retaining build RET=4, larger batches and run-length / polygon input RET=0; B <= 272 (u8) / 288 (run lengths, polygons) takes the split engine)"),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",

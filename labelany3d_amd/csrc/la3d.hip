@@ -8,8 +8,8 @@
 //
 // Memory-bound integer/byte + fp64 reduction work: no MFMA.  Layout, kernel design and measurements are in
 // DESIGN.md.  This file holds the INSTANCE ENGINE of la3d_fit_instances (one workgroup per instance; used for
-// B > 336, for run-length masks, for reference-subsample mode and for frames the split engine does not take —
-// la3d_split.hip is the other engine) and every other kernel of the C-ABI.  `fit_instances_kernel` in short:
+// B > 272 (u8 planes) / 288 (run lengths, polygon parts), for the fused instance filter, for reference-subsample mode and
+// for frames the split engine does not take - la3d_split.hip is the other engine) and every other kernel of the C-ABI.  `fit_instances_kernel` in short:
 //   one 512-thread workgroup (8 wave64) per instance, 64 VGPRs / 40 KB LDS -> 4 workgroups per CU (the "retaining" build for
 //            u8 planes up to 1280 instances: 128 VGPRs, 2 workgroups per CU, depth tiles kept on chip between the passes);
 //   order    256 < B <= 3 resident sets: which instance a workgroup fits is decided in the kernel (order_select) from the sort
@@ -2639,7 +2639,7 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   // polygons: the side stage sits behind Shared, where the tile list / rank prefix go later (disjoint in time)
   const size_t poly_stage = poly ? (size_t)POLY_STAGE_BYTES : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (!rle && split_eligible(p, vec, ldsmask)) {
+  if (!sample && split_eligible(p, vec, ldsmask)) {
     const int rc = split_fit(p, workspace, s);   // (the split engine's final kernel does not project: one small follow-up launch)
     if (rc != LA3D_SUCCESS || !p.proj) return rc;
     hipLaunchKernelGGL(project_boxes_kernel, dim3((B + 127) / 128), dim3(128), 0, s, out, K, k_stride, image_index, B, p.proj_w, p.proj_h,

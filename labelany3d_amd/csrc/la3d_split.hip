@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 #include "la3d_device.hpp"
+#include "la3d_poly.hpp"
 
 namespace la3d {
 
@@ -176,6 +177,77 @@ __global__ __launch_bounds__(SNT) void scan_kernel(const SplitParams sp) {
   for (int it = tid; it < nslots * 8; it += SNT) {
     const unsigned short at = pos[it >> 3];
     if (at != 0xffff) outb[(int)at * 8 + (it & 7)] = bandbits[it];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// scan for masks that are not u8 planes (SRC 1 = COCO run lengths, 2 = polygon parts): one 512-thread workgroup per instance
+// decodes into a row-major LDS bit image with the instance engine's own decoders (rle_to_bits / poly_to_bits: same bits), then
+// every wave turns whole bands of it into the scan_kernel's output - compacted active-tile ids, their eight row words, the
+// band's pixel count.  Small batches of the reference's own mask formats thereby get the split engine's parallelism: one big
+// instance no longer sits on one CU (measured, largest mask 60-95 k px, B = 1 / 8 / 64 / 128: 47 / 46 / 59 / 59 us per call with one
+// workgroup per instance; profiles/r03/r03_small_batches.txt).
+// dynamic LDS: bit image (mask_lds_bytes) | 16 flag words | decode scratch (column-scan block totals / polygon side stage)
+// ------------------------------------------------------------------------------------------
+constexpr int DNT = 512;
+#ifndef LA3D_SPLIT_MAXB_NOMASK
+#define LA3D_SPLIT_MAXB_NOMASK 288   // measured crossover with the instance engine (see split_eligible)
+#endif
+constexpr int DEC_SCRATCH_BYTES = POLY_STAGE_BYTES > 8192 ? POLY_STAGE_BYTES : 8192;
+template <int SRC>
+__global__ __launch_bounds__(DNT) void scan_bits_kernel(const SplitParams sp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const FitParams& p = sp.f;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int inst = sp.b0 + blockIdx.x;
+  unsigned* bits = reinterpret_cast<unsigned*>(smem);
+  unsigned* flags = reinterpret_cast<unsigned*>(smem + p.mask_lds_bytes);
+  unsigned char* scratch = smem + p.mask_lds_bytes + 64;
+  if (SRC == 1) {
+    const long long o0 = p.rle_offsets[inst];
+    (void)rle_to_bits<DNT>(p.rle_counts + o0, (int)(p.rle_offsets[inst + 1] - o0), bits, p.nwords, p.H, p.W, flags, tid,
+                           reinterpret_cast<unsigned*>(scratch), DEC_SCRATCH_BYTES / 4);
+  } else {
+    (void)poly_to_bits<DNT>(p.poly_xy, p.poly_ring_off, p.poly_inst_rings[inst], p.poly_inst_rings[inst + 1],
+                            reinterpret_cast<PolySide*>(scratch), flags, bits, p.nwords, p.H, p.W, tid);
+  }
+  __syncthreads();
+  const int ntx = p.ntx, nty = p.nty, H = p.H;
+  for (int band = wave; band < sp.nband; band += DNT / 64) {
+    const int trow0 = band * BAND_TROWS;
+    const int trows = min(BAND_TROWS, nty - trow0);
+    const int nslots = trows * ntx;
+    const long long seg = (long long)inst * sp.nband + band;
+    unsigned short* tl = sp.tlist + seg * sp.tpb;
+    uint4* tb = reinterpret_cast<uint4*>(sp.tbits + seg * sp.tpb * 8);
+    int base = 0, nm = 0;
+    for (int s0 = 0; s0 < nslots; s0 += 64) {   // ascending slot order, like scan_kernel's compaction
+      const int sl = s0 + lane;
+      unsigned w[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+      unsigned any = 0;
+      int ty = 0, tx = 0;
+      if (sl < nslots) {
+        ty = sl / ntx; tx = sl - ty * ntx;
+        const int row0 = (trow0 + ty) * 8;
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          if (row0 + rr < H) w[rr] = bits[(row0 + rr) * ntx + tx];
+          any |= w[rr];
+          nm += __popc(w[rr]);
+        }
+      }
+      const unsigned long long bal = __ballot(any != 0);
+      if (any) {
+        const int at = base + __popcll(bal & ((1ull << lane) - 1ull));
+        tl[at] = (unsigned short)(((trow0 + ty) << 8) | tx);
+        tb[at * 2] = make_uint4(w[0], w[1], w[2], w[3]);
+        tb[at * 2 + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+      }
+      base += __popcll(bal);
+    }
+    nm = wave_sum_i(nm);
+    if (lane == 0) { sp.tcount[seg] = base; sp.nmaskb[seg] = nm; }
   }
 }
 
@@ -554,13 +626,20 @@ bool split_eligible(const FitParams& p, bool vec, bool ldsmask) {
   if (ntx > 64 || nty > 255) return false;  // scan keeps a band's bits in LDS: 8 tile rows x ntx x 32 B <= 16 KB
   const int nband = (nty + BAND_TROWS - 1) / BAND_TROWS;
   if (nband > 64) return false;
-  // Measured on MI355X (BASELINE config-2 inputs): split is 1.8x / 1.5x / 1.3x / 1.2x faster than one
-  // workgroup per instance at B = 16 / 64 / 128 / 256 (that engine fills only B of 1024 workgroup slots),
-  // and 0.85x / 0.86x / 0.75x at B = 512 / 1024 / 2048 (five dependent launches per sub-batch).
+  // Measured on MI355X, round 3 (BASELINE config-2 inputs, us per call, split vs one workgroup per instance;
+  // profiles/r03/r03_small_batches.txt): u8 planes B = 1 / 16 / 64 / 128 / 192 / 272 / 288 / 304 / 336: 34 / 37 / 45 / 50 / 58 / 70 / 74 / 76 /
+  // 81 vs 40 / 52 / 57 / 58 / 62 / 75 / 72 / 71 / 76; run lengths B = 1 / 16 / 64 / 160 / 256 / 288 / 304: 36 / 40 / 46 / 53 / 59 / 65 / 66 vs
+  // 47 / 57 / 59 / 66 / 64 / 66 / 65 (polygons ~1 us below both).  A lone 60-90 k-px instance keeps ONE CU's fp64 VALU busy for ~40 us
+  // in the instance engine; the split engine spreads its tiles over the chip at the price of six dependent launches.
   const char* e = getenv("LA3D_ENGINE");  // experiments only
   if (e && !strcmp(e, "instance")) return false;
+  if (p.mask == nullptr) {   // run lengths / polygon parts (scan_bits_kernel): the bit image must fit the decode workgroup's LDS
+    if (p.mask_lds_bytes <= 0 || (size_t)p.mask_lds_bytes + 64 + DEC_SCRATCH_BYTES > 160 * 1024 - 256 || p.filter_boundary >= 0) return false;
+    if (e && !strcmp(e, "split")) return true;
+    return p.B <= LA3D_SPLIT_MAXB_NOMASK;
+  }
   if (e && !strcmp(e, "split")) return true;
-  return p.B <= 336;  // measured crossover with the (size-ordered) instance engine: 320 -> split 82 vs 84 us, 352 -> 84 vs 81 us
+  return p.B <= 272;
 }
 
 // One call = one batch.  Sub-batch j: scan on the scan stream (scans are bandwidth-bound, so they run
@@ -617,9 +696,20 @@ int split_fit(const FitParams& pin, void* workspace, hipStream_t s) {
     sp.wstart = reinterpret_cast<int*>(sub + L.sub_wstart);
     sp.partA = reinterpret_cast<double*>(sub + L.sub_partA);
     sp.partB = reinterpret_cast<double*>(sub + L.sub_partB);
-    const size_t scan_lds = (size_t)sp.tpb * 34 + 64 * 4 + SNW * 4 + 16;
-    hipLaunchKernelGGL(scan_kernel, dim3(sp.nb * sp.nband), dim3(SNT), scan_lds, scan_s, sp);
-    if (int rc = check_launch("scan_kernel")) return rc;
+    if (sp.f.mask == nullptr) {   // run lengths / polygon parts: decode front end, one workgroup per instance
+      const size_t dec_lds = (size_t)sp.f.mask_lds_bytes + 64 + DEC_SCRATCH_BYTES;
+      if (dec_lds > 64 * 1024) {   // frames above ~690 k px: allow the large dynamic LDS (per kernel and device; cheap, rare)
+        const void* fn = sp.f.poly_xy ? reinterpret_cast<const void*>(scan_bits_kernel<2>) : reinterpret_cast<const void*>(scan_bits_kernel<1>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError();
+      }
+      if (sp.f.poly_xy) hipLaunchKernelGGL(scan_bits_kernel<2>, dim3(sp.nb), dim3(DNT), dec_lds, scan_s, sp);
+      else hipLaunchKernelGGL(scan_bits_kernel<1>, dim3(sp.nb), dim3(DNT), dec_lds, scan_s, sp);
+      if (int rc = check_launch("scan_bits_kernel")) return rc;
+    } else {
+      const size_t scan_lds = (size_t)sp.tpb * 34 + 64 * 4 + SNW * 4 + 16;
+      hipLaunchKernelGGL(scan_kernel, dim3(sp.nb * sp.nband), dim3(SNT), scan_lds, scan_s, sp);
+      if (int rc = check_launch("scan_kernel")) return rc;
+    }
     hipStream_t ps = scan_s;
     if (!single) {
       ps = st.aux[j & 1];

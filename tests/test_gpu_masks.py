@@ -125,6 +125,44 @@ def test_fit_from_rle_equals_fit_from_planes(la):
     np.testing.assert_allclose(np_(b_s)[ok][:, :15], ref_s[ok][:, :15], rtol=0, atol=1e-8)
 
 
+def test_run_lengths_through_both_engines_ragged_frames(la, monkeypatch):
+    """Run-length input on the split engine's decode front end (scan_bits_kernel) and on the instance engine, frames whose height
+    is not a multiple of the 8-row tiles (rows past the frame must read as zeros in the last band), shared depth planes, a
+    degenerate ground and an empty mask: each engine against the oracle, and bit for bit against ITS u8-plane entry."""
+    rs = np.random.RandomState(123)
+    for (H, W, B) in ((61, 64, 9), (100, 96, 17), (477, 640, 6), (8, 32, 3)):
+        K = np.array([[0.8 * W, 0, W / 2], [0, 0.8 * W, H / 2], [0, 0, 1]])
+        P_img = max(1, B // 3)
+        depth = rs.uniform(0.5, 10, (P_img, H, W)).astype(np.float32)
+        img = rs.randint(0, P_img, B).astype(np.int32)
+        masks = np.zeros((B, H, W), bool)
+        for i in range(B - 1):
+            h, w = rs.randint(1, H + 1), rs.randint(1, W + 1)
+            r0, c0 = rs.randint(0, H - h + 1), rs.randint(0, W - w + 1)
+            masks[i, r0:r0 + h, c0:c0 + w] = rs.rand(h, w) < (0.5 if i % 3 else 1.0)
+        masks[0, H - 1, :] = True            # the last (ragged) tile row is in use
+        ground = np.array([[0.02, -0.98, 0.1, 1.5]] * B) + 0.03 * rs.randn(B, 4)
+        ground[1] = [0.0, -1.0, 0.0, 0.0]
+        rles = [O.rle_encode(m) for m in masks]
+        ref, rst, _, _ = O.fit_instances(depth[img], masks, K[None].repeat(B, 0), ground=ground)
+        got = {}
+        for eng in ("split", "instance"):
+            monkeypatch.setenv("LA3D_ENGINE", eng)
+            b_r, s_r, a_r = la.fit_instances_rle(depth, rles, K, ground=ground, image_index=img)
+            b_p, s_p, a_p = la.fit_instances(depth, masks, K, ground=ground, image_index=img)
+            np.testing.assert_array_equal(np_(s_r), rst)
+            np.testing.assert_array_equal(np_(s_r), np_(s_p))
+            np.testing.assert_array_equal(np_(b_r), np_(b_p))
+            np.testing.assert_array_equal(np_(a_r)[:, 2], masks.reshape(B, -1).sum(1))
+            ok = rst == 0
+            scale = np.maximum(1, np.abs(ref[ok][:, :6]).max(1))[:, None]
+            assert (np.abs(np_(b_r)[ok][:, :15] - ref[ok][:, :15]) <= 1e-9 * scale).all(), (H, W, eng)
+            got[eng] = np_(b_r)
+        monkeypatch.delenv("LA3D_ENGINE")
+        ok = rst == 0
+        np.testing.assert_allclose(got["split"][ok][:, :15], got["instance"][ok][:, :15], rtol=1e-10, atol=1e-11)
+
+
 def test_box_consumers_vs_reference(la, golden):
     """la3d_project_boxes / la3d_iou_matrix against the reference's project_to_2d, iou2D and hungarian_matching."""
     g = golden("g9_consumers.npz")

@@ -28,17 +28,28 @@ def np_(t):
     return t.detach().cpu().numpy()
 
 
-class _instance_engine:
-    """Pin the instance engine for the u8-plane call (small batches of planes take the split engine, whose partial sums are
-    grouped differently; polygon / run-length input always takes the instance engine)."""
+class _engine:
+    """Pin one engine for the calls inside (LA3D_ENGINE): up to 288 instances of polygon / run-length input and up to 272 of u8 planes
+    take the split engine, whose partial sums are grouped differently from the instance engine's - comparisons "bit for bit" are
+    between calls of the SAME engine."""
+
+    def __init__(self, name="instance"):
+        self.name = name
 
     def __enter__(self):
         import os
-        os.environ["LA3D_ENGINE"] = "instance"
+        self.prev = os.environ.get("LA3D_ENGINE")
+        os.environ["LA3D_ENGINE"] = self.name
 
     def __exit__(self, *a):
         import os
-        del os.environ["LA3D_ENGINE"]
+        if self.prev is None:
+            del os.environ["LA3D_ENGINE"]
+        else:
+            os.environ["LA3D_ENGINE"] = self.prev
+
+
+_instance_engine = _engine
 
 
 def _star(rs, w, h, n, jitter=0.6, margin=0.0):
@@ -129,13 +140,19 @@ def test_fit_from_polygons_equals_fit_from_planes(la):
     segs = [_random_segmentation(rs, W, H, k % 8) for k in range(B - 1)] + [[]]
     ground = np.array([[0.05, -0.97, 0.1, 1.2]] * B) + 0.02 * rs.randn(B, 4)
     polys = la.pack_polygons(segs, H, W)
-    b1, s1, a1 = la.fit_instances_poly(depth, polys, K, ground=ground)
     masks = la.poly_decode(polys)
-    with _instance_engine():
-        b2, s2, a2 = la.fit_instances(depth, masks, K, ground=ground)
-    np.testing.assert_array_equal(np_(s1), np_(s2))
-    np.testing.assert_array_equal(np_(b1), np_(b2))
-    np.testing.assert_array_equal(np_(a1), np_(a2))
+    for eng in ("split", "instance"):      # the split engine's decode front end (scan_bits_kernel) and the fused instance engine
+        with _engine(eng):
+            b1, s1, a1 = la.fit_instances_poly(depth, polys, K, ground=ground)
+            b2, s2, a2 = la.fit_instances(depth, masks, K, ground=ground)
+            b3, s3, a3 = la.fit_instances_rle(depth, [O.rle_encode(m) for m in np_(masks).astype(bool)], K, ground=ground)
+        np.testing.assert_array_equal(np_(s1), np_(s2))
+        np.testing.assert_array_equal(np_(b1), np_(b2))
+        np.testing.assert_array_equal(np_(a1), np_(a2))
+        np.testing.assert_array_equal(np_(s3), np_(s2))
+        np.testing.assert_array_equal(np_(b3), np_(b2))
+    b1, s1, a1 = la.fit_instances_poly(depth, polys, K, ground=ground)      # the library's own choice (40 instances: split both)
+    np.testing.assert_array_equal(np_(b1), np_(la.fit_instances(depth, masks, K, ground=ground)[0]))
     assert np_(s1)[-1] == 1                    # the empty instance: "No valid points"
     for i in range(0, B - 1, 5):
         want, _ = P.create_boolean_mask_from_polygon((W, H), segs[i])
@@ -241,7 +258,8 @@ def test_the_reference_converters_own_polygons(la, monkeypatch):
             assert tuple(stats[i]) == O.mask_stats(w) and stats[i][2] == height
         depth = rs.uniform(0.5, 10, (len(segs), H, W)).astype(np.float32)
         K = np.array([[0.8 * W, 0, W / 2], [0, 0.8 * W, H / 2], [0, 0, 1]])
-        b1, s1, a1 = la.fit_instances_poly(depth, packed, K)
+        with _instance_engine():
+            b1, s1, a1 = la.fit_instances_poly(depth, packed, K)
         # polygon input takes the plain build; pin it for the planes too: the 107 k-px blob has more active tiles (> 912) than the
         # plain build's list holds and is walked densely there, which groups the partial sums differently from the retaining
         # build's longer list (last-ulp differences; checked to rounding below)
@@ -255,6 +273,13 @@ def test_the_reference_converters_own_polygons(la, monkeypatch):
         np.testing.assert_array_equal(np_(b1), np_(b2))
         np.testing.assert_array_equal(np_(a1)[:, 2], [w.sum() for w in want])
         np.testing.assert_array_equal(np_(s1), np_(s3))
+        with _engine("split"):          # the same parts through the split engine's decode front end vs its u8 scan: bit for bit
+            b4, s4, _ = la.fit_instances_poly(depth, packed, K)
+            b5, s5, _ = la.fit_instances(depth, np.stack(want), K)
+        np.testing.assert_array_equal(np_(s4), np_(s5))
+        np.testing.assert_array_equal(np_(b4), np_(b5))
+        np.testing.assert_array_equal(np_(s4), np_(s1))
+        np.testing.assert_allclose(np_(b4)[:, :15], np_(b1)[:, :15], rtol=1e-12, atol=1e-12)
         np.testing.assert_allclose(np_(b3)[:, :15], np_(b1)[:, :15], rtol=1e-12, atol=1e-12)
 
 
@@ -275,7 +300,8 @@ def test_fused_instance_filter_polygons_and_run_lengths(la):
     B = len(segs)
     depth = rs.uniform(0.5, 10, (B, H, W)).astype(np.float32)
     polys = la.pack_polygons(segs, H, W)
-    b0, s0, a0 = la.fit_instances_poly(depth, polys, K)
+    with _instance_engine():        # the fused filter lives in the instance engine: compare with that engine's unfiltered records
+        b0, s0, a0 = la.fit_instances_poly(depth, polys, K)
     b1, s1, a1, st = la.fit_instances_poly(depth, polys, K, filter=True)
     want_stats = np_(la.mask_stats_poly(polys))
     np.testing.assert_array_equal(np_(st), want_stats)
@@ -297,7 +323,8 @@ def test_fused_instance_filter_polygons_and_run_lengths(la):
     # run lengths: same masks, RLE branch of the rule (rows holding a pixel)
     masks = np_(la.poly_decode(polys))
     rles = [O.rle_encode(m) for m in masks]
-    r0 = la.fit_instances_rle(depth, rles, K)
+    with _instance_engine():
+        r0 = la.fit_instances_rle(depth, rles, K)
     r1 = la.fit_instances_rle(depth, rles, K, filter=True)
     want_r = np_(la.mask_stats_rle(rles))
     np.testing.assert_array_equal(np_(r1[3]), want_r)
@@ -426,11 +453,12 @@ def test_parts_with_disjoint_bounding_boxes_share_one_pass(la):
         assert np.array_equal(got[i], want), (i, len(seg), np.argwhere(got[i] != want)[:5])
     depth = rs.uniform(0.5, 10, (len(segs), H, W)).astype(np.float32)
     K = np.array([[250.0, 0, 160], [0, 250.0, 120], [0, 0, 1]])
-    b1, s1, a1 = la.fit_instances_poly(depth, polys, K)
-    with _instance_engine():
-        b2, s2, a2 = la.fit_instances(depth, got, K)
-    np.testing.assert_array_equal(np_(s1), np_(s2))
-    np.testing.assert_array_equal(np_(b1), np_(b2))
+    for eng in ("split", "instance"):
+        with _engine(eng):
+            b1, s1, a1 = la.fit_instances_poly(depth, polys, K)
+            b2, s2, a2 = la.fit_instances(depth, got, K)
+        np.testing.assert_array_equal(np_(s1), np_(s2))
+        np.testing.assert_array_equal(np_(b1), np_(b2))
     np.testing.assert_array_equal(np_(la.mask_stats_poly(polys))[:, 0], got.reshape(len(segs), -1).sum(1))
 
 
