@@ -163,6 +163,45 @@ def test_run_lengths_through_both_engines_ragged_frames(la, monkeypatch):
         np.testing.assert_allclose(got["split"][ok][:, :15], got["instance"][ok][:, :15], rtol=1e-10, atol=1e-11)
 
 
+@pytest.mark.parametrize("H,W", [(1024, 1024), (720, 1280)])
+def test_run_lengths_and_polygons_large_frames_both_engines(la, monkeypatch, H, W):
+    """Frames whose bit image needs more than the 64 KiB default of dynamic LDS (1024x1024: 128 KiB image + decode scratch in the
+    split engine's decode front end; the limit of run-length / polygon input is H*W <= 1048576): run lengths and polygon parts
+    through both engines against the oracle and against the u8-plane entry of the same engine."""
+    from oracle import poly_oracle as P
+    rs = np.random.RandomState(H + W)
+    B = 4
+    K = np.array([[0.8 * W, 0, W / 2], [0, 0.8 * W, H / 2], [0, 0, 1]])
+    depth = rs.uniform(0.5, 10, (B, H, W)).astype(np.float32)
+    segs = []
+    for i in range(B):
+        n = 5 + 3 * i
+        ang = np.sort(rs.uniform(0, 2 * np.pi, n))
+        cx, cy = rs.uniform(0.3 * W, 0.7 * W), rs.uniform(0.3 * H, 0.7 * H)
+        rad = rs.uniform(0.4, 1.0, n)
+        segs.append([np.stack([cx + 0.3 * W * rad * np.cos(ang), cy + 0.3 * H * rad * np.sin(ang)], 1).round().ravel().tolist()])
+    segs[1].append([5, H - 40, 300, H - 40, 300, H - 1, 5, H - 1])           # a second part in the last rows of the frame
+    polys = la.pack_polygons(segs, H, W)
+    masks = np.stack([P.create_boolean_mask_from_polygon((W, H), sg)[0] for sg in segs])
+    np.testing.assert_array_equal(np_(la.poly_decode(polys)).astype(bool), masks)
+    rles = [O.rle_encode(m) for m in masks]
+    ref, rst, _, _ = O.fit_instances(depth, masks, K[None].repeat(B, 0))
+    assert (rst == 0).all()
+    for eng in ("split", "instance"):
+        monkeypatch.setenv("LA3D_ENGINE", eng)
+        b_u, s_u, _ = la.fit_instances(depth, masks, K)
+        b_r, s_r, a_r = la.fit_instances_rle(depth, rles, K)
+        b_p, s_p, a_p = la.fit_instances_poly(depth, polys, K)
+        for b, st in ((b_r, s_r), (b_p, s_p)):
+            np.testing.assert_array_equal(np_(st), rst)
+            np.testing.assert_array_equal(np_(b), np_(b_u))
+            scale = np.maximum(1, np.abs(ref[:, :6]).max(1))[:, None]
+            assert (np.abs(np_(b)[:, :15] - ref[:, :15]) <= 1e-9 * scale).all(), (H, W, eng)
+        np.testing.assert_array_equal(np_(a_r)[:, 2], masks.reshape(B, -1).sum(1))
+        np.testing.assert_array_equal(np_(a_p)[:, 2], masks.reshape(B, -1).sum(1))
+    monkeypatch.delenv("LA3D_ENGINE")
+
+
 def test_box_consumers_vs_reference(la, golden):
     """la3d_project_boxes / la3d_iou_matrix against the reference's project_to_2d, iou2D and hungarian_matching."""
     g = golden("g9_consumers.npz")
