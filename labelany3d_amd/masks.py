@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 from ._lib import AUX, REC, check, lib
-from .batched import InstanceFitter, _as_dev, _dev, _ptr, _record, _stream
+from .batched import InstanceFitter, _as_dev, _bulk, _dev, _ptr, _record, _stream, _upload_many
 
 
 def rle_from_string(s) -> np.ndarray:
@@ -225,12 +225,19 @@ def fit_instances_ex(depth, K, masks=None, rles=None, polys=None, ground=None, s
         what = "mask"
     elif rles is not None:
         counts, offsets, H, W = pack_rle(rles)
+        counts, offsets, ground, image_index, sample_idx, area_hint = _bulk(
+            dev, (counts, torch.int32), (offsets, torch.int64), (ground, torch.float64), (image_index, torch.int32), (sample_idx, torch.int32),
+            (area_hint, torch.int32))
         c, o = _as_dev(counts, torch.int32, dev), _as_dev(offsets, torch.int64, dev)
         B = o.numel() - 1
         a.rle_counts, a.rle_offsets = _ptr(c), _ptr(o); keep += [c, o]
         what = "RLE"
     else:
-        xy, ro, ir, H, W = _poly_dev(polys, dev)
+        pxy, pro, pir, H, W = polys
+        pxy, pro, pir, ground, image_index, sample_idx, area_hint = _bulk(
+            dev, (pxy, torch.int32), (pro, torch.int64), (pir, torch.int64), (ground, torch.float64), (image_index, torch.int32),
+            (sample_idx, torch.int32), (area_hint, torch.int32))
+        xy, ro, ir, H, W = _poly_dev((pxy, pro, pir, H, W), dev)
         B = ir.numel() - 1
         a.poly_xy, a.ring_offsets, a.inst_rings = _ptr(xy), _ptr(ro), _ptr(ir); keep += [xy, ro, ir]
         what = "polygon"
@@ -290,30 +297,48 @@ def fit_annotations(annotations, image_size, depth, K, ground=None, boundary_thr
         groups[kind][0].append(i)
         groups[kind][1].append({"size": seg["size"], "counts": seg["counts"]} if kind == "rle" else seg)
     flt = {"boundary_threshold": boundary_threshold, "scale_threshold": scale_threshold}
-    idx_all, box_all, st_all = [], [], []
+    sels, box_all, st_all = [], [], []
     for kind, (idx, segs) in groups.items():
         if not idx:
             continue
         sel = np.asarray(idx, np.int64)
-        g = None if ground is None else np.asarray(ground, dtype=np.float64)[sel]
-        ii = None if image_index is None else np.asarray(image_index)[sel]
+        g = None if ground is None else (ground[torch.as_tensor(sel, device=ground.device)] if isinstance(ground, torch.Tensor)
+                                         else np.asarray(ground, dtype=np.float64)[sel])
+        ii = None if image_index is None else (image_index[torch.as_tensor(sel, device=image_index.device)]
+                                               if isinstance(image_index, torch.Tensor) else np.asarray(image_index)[sel])
         # the annotation's own "area" (COCO: the mask area in pixels), when every annotation of the group has one, spares the launch
         # order its estimate pass
         ar = [annotations[i].get("area") for i in idx]
         hint = None if any(v is None for v in ar) else np.clip(np.asarray(ar, dtype=np.float64), 0, 2**31 - 1).astype(np.int32)
-        kw = dict(rles=segs) if kind == "rle" else dict(polys=pack_polygons(segs, H_img, W_img))
-        res = fit_instances_ex(depth, K, ground=g, image_index=ii, device=dev, filter=flt, area_hint=hint, **kw)
-        b, s = res["boxes"], res["status"]
-        keep = (s != 6).cpu().numpy()
-        idx_all.append(sel[keep]); box_all.append(b[torch.as_tensor(keep, device=b.device)]); st_all.append(s[torch.as_tensor(keep, device=s.device)])
-    if not idx_all:
+        # every small host array of the group goes up in ONE copy (six to eight separate uploads cost ~100 us per image)
+        host = lambda v: None if isinstance(v, torch.Tensor) else v     # noqa: E731   (device tensors pass through as they are)
+        if kind == "rle":
+            counts, offsets, Hh, Ww = pack_rle(segs)
+            up = _upload_many([(counts, torch.int32), (offsets, torch.int64), (host(g), torch.float64), (host(ii), torch.int32),
+                               (hint, torch.int32), (host(K), torch.float64)], dev)
+            kw = dict(rles=(up[0], up[1], Hh, Ww))
+        else:
+            xy, ro, ir, Hh, Ww = pack_polygons(segs, H_img, W_img)
+            up = _upload_many([(xy, torch.int32), (ro, torch.int64), (ir, torch.int64), (host(g), torch.float64), (host(ii), torch.int32),
+                               (hint, torch.int32), (host(K), torch.float64)], dev)
+            kw = dict(polys=(up[0], up[1], up[2], Hh, Ww))
+        g_d = up[-4] if up[-4] is not None else g
+        ii_d = up[-3] if up[-3] is not None else ii
+        K_d = up[-1] if up[-1] is not None else K
+        res = fit_instances_ex(depth, K_d, ground=g_d, image_index=ii_d, device=dev, filter=flt, area_hint=up[-2], **kw)
+        sels.append(sel); box_all.append(res["boxes"]); st_all.append(res["status"])
+    if not sels:
         return [], np.zeros(0, np.int64), [], torch.zeros((0, 39), dtype=torch.float64, device=dev), torch.zeros(0, dtype=torch.int32, device=dev)
-    kept = np.concatenate(idx_all)
-    order = np.argsort(kept, kind="stable")
-    ot = torch.as_tensor(order, device=dev)
-    boxes, status = torch.cat(box_all)[ot], torch.cat(st_all)[ot]
-    kept = kept[order]
-    return ([annotations[i]["bbox"] for i in kept], kept, [annotations[i]["category_id"] for i in kept], boxes, status)
+    boxes_c = box_all[0] if len(box_all) == 1 else torch.cat(box_all)
+    status_c = st_all[0] if len(st_all) == 1 else torch.cat(st_all)
+    st_host = status_c.cpu().numpy()                      # the one synchronisation of the call
+    sel_c = np.concatenate(sels)
+    pos = np.nonzero(st_host != 6)[0]                     # kept rows of the concatenated results ...
+    pos = pos[np.argsort(sel_c[pos], kind="stable")]      # ... in annotation order
+    kept = sel_c[pos]
+    pt = torch.as_tensor(pos, device=dev)
+    return ([annotations[i]["bbox"] for i in kept], kept, [annotations[i]["category_id"] for i in kept],
+            boxes_c.index_select(0, pt), status_c.index_select(0, pt))
 
 
 def segmentations_to_masks(segmentations, H: int, W: int, device=None) -> torch.Tensor:
@@ -349,7 +374,10 @@ def fit_instances_poly(depth, polys, K, ground=None, sample_idx=None, image_inde
     branch: height = last row - first row + 1) into the same launch: dropped instances get status 6 and a NaN record and cost no
     passes; a fourth return value holds the (B,4) statistics (area, rows, span, edge pixels) as ``mask_stats_poly`` gives them."""
     dev = _dev(device)
-    xy, ro, ir, H, W = _poly_dev(polys, dev)
+    pxy, pro, pir, H, W = polys
+    pxy, pro, pir, ground, image_index, sample_idx = _bulk(dev, (pxy, torch.int32), (pro, torch.int64), (pir, torch.int64), (ground, torch.float64),
+                                                           (image_index, torch.int32), (sample_idx, torch.int32))
+    xy, ro, ir, H, W = _poly_dev((pxy, pro, pir, H, W), dev)
     B = ir.numel() - 1
     d, k, P, ii, g, si = _fit_common(depth, K, H, W, B, ground, sample_idx, image_index, dev, "polygon")
     stats = None
@@ -401,6 +429,8 @@ def fit_instances_rle(depth, rles, K, ground=None, sample_idx=None, image_index=
     holding a pixel, src/util.py:368-369)."""
     counts, offsets, H, W = pack_rle(rles)
     dev = _dev(device)
+    counts, offsets, ground, image_index, sample_idx = _bulk(dev, (counts, torch.int32), (offsets, torch.int64), (ground, torch.float64),
+                                                             (image_index, torch.int32), (sample_idx, torch.int32))
     c, o = _as_dev(counts, torch.int32, dev), _as_dev(offsets, torch.int64, dev)
     B = o.numel() - 1
     d, k, P, ii, g, si = _fit_common(depth, K, H, W, B, ground, sample_idx, image_index, dev, "RLE")
