@@ -274,7 +274,7 @@ def fit_instances(depth, masks, K, ground=None, sample_idx=None, image_index=Non
         return out
 
 
-def fit_points(clouds, ground=None, sample_idx=None, method: str = "pca", stream=None, device=None, small_clouds=None):
+def fit_points(clouds, ground=None, sample_idx=None, method: str = "pca", stream=None, device=None, small_clouds=None, _packed=False):
     """estimate_bbox for a list of (N_i,3) clouds in one launch (reference src/util_3dbox.py:106-178).
 
     clouds: list of arrays/tensors, or a tuple (points (T,3) f64, offsets (B+1,) i64).
@@ -292,24 +292,35 @@ def fit_points(clouds, ground=None, sample_idx=None, method: str = "pca", stream
         lens = [int(len(c)) for c in clouds]
         if small_clouds is None:
             small_clouds = sample_idx is not None or max(lens, default=0) <= 4096
-        off = torch.as_tensor(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64), device=dev)
-        if sum(lens):
-            pts = torch.cat([_as_dev(c, torch.float64, dev).reshape(-1, 3) for c in clouds if len(c)])
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        if not any(isinstance(c, torch.Tensor) for c in clouds):
+            # host clouds (the reference's calling pattern): points, offsets and the other small host arguments in ONE copy
+            hp = (np.concatenate([np.asarray(c, dtype=np.float64).reshape(-1, 3) for c in clouds if len(c)]) if sum(lens)
+                  else np.zeros((1, 3)))
+            pts, off, ground, sample_idx = _bulk(dev, (hp, torch.float64), (offs, torch.int64), (ground, torch.float64), (sample_idx, torch.int32))
         else:
-            pts = torch.zeros((1, 3), dtype=torch.float64, device=dev)
+            off = torch.as_tensor(offs, device=dev)
+            if sum(lens):
+                pts = torch.cat([_as_dev(c, torch.float64, dev).reshape(-1, 3) for c in clouds if len(c)])
+            else:
+                pts = torch.zeros((1, 3), dtype=torch.float64, device=dev)
     B = off.numel() - 1
     meth = {"pca": _lib.METHOD_PCA, "convex_hull": _lib.METHOD_CONVEX_HULL}.get(method)
     if meth is None:
         raise ValueError(f"Unknown method: {method}. Use 'pca' or 'convex_hull'")  # reference :151
     g = None if ground is None else _as_dev(ground, torch.float64, dev)
     si = None if sample_idx is None else _as_dev(sample_idx, torch.int32, dev)
-    boxes = torch.empty((B, REC), dtype=torch.float64, device=dev)
-    status = torch.empty(B, dtype=torch.int32, device=dev)
-    aux = torch.empty((B, AUX), dtype=torch.float64, device=dev)
+    # one output buffer (records | aux | status): a caller that wants everything on the host reads it back in one copy
+    packed = torch.empty(B * (REC + AUX) + (B + 1) // 2, dtype=torch.float64, device=dev)
+    boxes = packed[:B * REC].view(B, REC)
+    aux = packed[B * REC:B * (REC + AUX)].view(B, AUX)
+    status = packed[B * (REC + AUX):].view(torch.int32)[:B]
     with torch.cuda.device(dev):
         check(lib.la3d_fit_points(_ptr(pts), _ptr(off), _ptr(g), _ptr(si), meth | (_lib.HINT_SMALL_CLOUDS if small_clouds else 0), B, _ptr(boxes), _ptr(status),
                                   _ptr(aux), _stream(stream)), "la3d_fit_points")
-    _record(stream, pts, off, g, si, boxes, status, aux)
+    _record(stream, pts, off, g, si, packed)
+    if _packed:
+        return boxes, status, aux, packed
     return boxes, status, aux
 
 

@@ -79,20 +79,22 @@ def _fit_one(in_pc, ground_equ, method, subsample=True):
         raise ValueError(f"Unknown method: {method}. Use 'pca' or 'convex_hull'")  # reference :151
     pc = np.asarray(in_pc)
     pc = pc.reshape(-1, 3) if pc.size else np.zeros((0, 3))
-    idx = None
     if subsample and pc.shape[0] > _lib.NSAMPLE:  # reference :123-125 — global stream, with replacement
-        idx = np.random.randint(0, pc.shape[0], _lib.NSAMPLE).astype(np.int32)[None]
+        # the draw happens here exactly as there (in_pc = in_pc[idx]); only the 500 drawn rows travel to the GPU
+        pc = pc[np.random.randint(0, pc.shape[0], _lib.NSAMPLE)]
     ground = None if ground_equ is None else np.asarray(ground_equ, dtype=np.float64).reshape(-1)[:4][None]
     if ground is not None and ground.shape[1] < 4:
         ground = np.concatenate([ground, np.zeros((1, 4 - ground.shape[1]))], axis=1)  # only [:3] is used (:129)
-    boxes, status, aux = fit_points([pc.astype(np.float64, copy=False)], ground, idx, method)
-    st = int(status[0])
+    # one upload (points | offsets | ground), one launch, one read-back (record | aux | status)
+    *_, packed = fit_points([pc.astype(np.float64, copy=False)], ground, None, method, _packed=True)
+    host = packed.cpu().numpy()
+    rec, aux = host[:_lib.REC], host[_lib.REC:_lib.REC + _lib.AUX]
+    st = int(host[_lib.REC + _lib.AUX:].view(np.int32)[0])
     if st != _lib.BOX_OK:
         raise ValueError(_MESSAGES[st])
-    aux = aux[0].cpu().numpy()
     if method == "convex_hull" and aux[3] >= 0:  # no 2-D hull: the kernel took the reference's PCA fallback (:222-224)
         print("ConvexHull failed: degenerate footprint (fewer than 3 hull vertices), falling back to PCA")
-    return boxes[0].cpu().numpy(), aux
+    return rec, aux
 
 
 def estimate_bbox(in_pc, cat_name=None, ground_equ=None, method="pca"):
