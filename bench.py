@@ -543,6 +543,19 @@ def main():
                 traffic, traffic_src = ent.get("hbm_bytes_per_step"), ent.get("source")
                 traffic_kernel_ns = ent.get("dominant_kernel_avg_ns")
                 traffic_stale = tj.get("kernel_source_sha256") != kernel_source_sha256()
+        # shader-side counters of the same profile set (profiles/make_valu_json.py): how busy the fp64 VALU - the path's second roof - is
+        valu = None
+        try:
+            vj = json.load(open(os.path.join(ROOT, "profiles", "valu_per_launch.json")))
+            ve = vj["modes"].get(mode)
+            if ve is not None:
+                valu = {"busy_us_per_simd_per_step": ve["valu_busy_us_per_simd"], "frac_of_step": ve["valu_busy_us_per_simd"] / (kern_ms * 1e3),
+                        "wave_instructions_per_step": ve["wave_instructions_valu"], "utilisation_in_the_profiled_kernel": ve["valu_utilisation"],
+                        "stale": vj.get("kernel_source_sha256") != kernel_source_sha256(),
+                        "source": f"rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU of the same bench command ({ve['summary']}): "
+                                  "SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs / 2.4 GHz"}
+        except Exception:   # the file is optional
+            valu = None
         if args.config3:
             workload = (f"BASELINE config-3 stand-in: {args.config3} images with a SHARED 480x640 depth plane each, {B} instances "
                         "(~Poisson(7) per image, elliptical u8 masks, log-uniform area 400..100k px) in one call per step")
@@ -607,6 +620,7 @@ def main():
                 "traffic_frac_of_peak": (traffic / step_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                 "traffic_source": traffic_src,
                 "traffic_stale": traffic_stale,
+                "valu": valu,
                 "traffic_mode": mode,
                 "traffic_kernel_avg_ns_under_rocprof": traffic_kernel_ns,
                 "note": "frac = required bytes (byte_model) / avg_launch_ms / 8 TB/s, where avg_launch_ms is the HIP-EVENT time per step on "
@@ -618,7 +632,8 @@ def main():
                         "algorithmic_GBps is SURVEY 8d's H*W*5+312 B/box figure (the kernel never loads depth lines without a mask "
                         "pixel, so that figure exceeds the physical peak and is NOT a roofline fraction). traffic = PMC-measured "
                         "HBM bytes per launch of the profiled build (profiles/, TCC_EA0_RDREQ x 128 B + WRITE_SIZE); "
-                        "traffic_stale = the kernel sources changed since that profile.",
+                        "traffic_stale = the kernel sources changed since that profile. valu = the second roof: the time one SIMD spends issuing this "
+                        "step's VALU instructions (fp64 ~5.2 cycles per wave-instruction), from the shader-side counters of the same profile set.",
             },
         }
         if pipelined is not None:

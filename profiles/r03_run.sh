@@ -25,6 +25,12 @@ LA3D_RETAIN=0 python bench.py --no-cpu-baseline > $O/bench_config2_plain.json 2>
 LA3D_RETAIN=0 LIGHT=1 bash profiles/run_profile.sh r03_config2_plain > /dev/null 2>&1
 cp $REPO/gpurun_out/profile_r03_config2_plain.md $O/profile_config2_plain.md
 python profiles/make_traffic_json.py r03
+# shader-side counters of the run-length / polygon / B = 8192 commands (the headline has them from its full profile above)
+for m in "config2_rle|--rle" "config2_poly|--poly" "config2_B8192|--batch 8192"; do
+  tag=${m%%|*}; args=${m#*|}
+  LIGHT=0 bash profiles/run_profile.sh r03sq_$tag $args > /dev/null 2>&1
+  cp $REPO/gpurun_out/profile_r03sq_$tag.md $O/profile_${tag}_sq.md
+done
 python profiles/bench_aux.py > $O/bench_aux_mi355x.json 2>/dev/null
 # re-run the headline with the fresh traffic table in place (traffic_stale must read false)
 cp $REPO/gpurun_out/traffic_per_launch.json $REPO/profiles/traffic_per_launch.json

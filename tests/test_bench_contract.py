@@ -54,6 +54,8 @@ def test_bench_prints_one_contract_line():
     assert r["required_bytes_per_launch"] < r["algorithmic_bytes_per_launch"] and "byte_model" in r
     assert abs(r["achieved"] - r["required_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     assert r["traffic_stale"] in (True, False, None)
+    v = r["valu"]                                                 # the second roof (profiles/valu_per_launch.json), optional
+    assert v is None or (0.0 < v["frac_of_step"] < 1.0 and v["stale"] in (True, False) and v["wave_instructions_per_step"] > 1e6)
     assert abs(d["value"] - 5 * 1024 / (d["ms_per_step"] * 5e-3)) / d["value"] < 1e-6
     assert d["value"] > 2.08e6   # BASELINE target: 40 % of the HBM-read roofline
 
