@@ -456,7 +456,7 @@ def main():
     for _ in range(warmup):
         fitter.run(depth, masks, K, slot=0, stream=stream)
     if dist is not None:  # warm the communicator outside the timed region
-        gather_boxes(fitter.boxes[:1].reshape(-1, 39), fitter.status[:1].reshape(-1), dst=0)
+        gather_boxes(fitter.boxes[:1].reshape(-1, 39), fitter.status[:1].reshape(-1), dst=0, counts=[B] * world)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     t0 = time.perf_counter()
@@ -474,7 +474,9 @@ def main():
     ev1.record(stream)
     gathered = None
     if dist is not None:
-        gathered = gather_boxes(fitter.boxes.reshape(-1, 39), fitter.status.reshape(-1), dst=0)
+        # (every rank fits steps x B instances: the counts are known, so the timed region holds exactly ONE collective)
+        gathered = gather_boxes(fitter.boxes.reshape(-1, 39), fitter.status.reshape(-1), dst=0,
+                                counts=[fitter.boxes.shape[0] * B] * world)
     barrier()
     t1 = time.perf_counter()
 

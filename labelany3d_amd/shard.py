@@ -86,36 +86,37 @@ def _is_gloo(group) -> bool:
         return False
 
 
-def gather_boxes(boxes: torch.Tensor, status: torch.Tensor, dst: int = 0, group=None):
+def gather_boxes(boxes: torch.Tensor, status: torch.Tensor, dst: int = 0, group=None, counts=None):
     """Gather every rank's (n_i, 39) float64 records and (n_i,) int32 status to ``dst`` in rank order.
 
-    Ranks may hold different n_i: counts are exchanged first (one tiny all_gather), payloads are padded
-    to the maximum and gathered with a single ``dist.gather`` each.  Returns ``(boxes, status, counts)``
-    on ``dst`` and ``None`` elsewhere.  ~312 B per box: 860k boxes over 8 GPUs is 33 MB per rank —
-    irrelevant next to the compute, so the simplest correct collective is used.  With the gloo backend (CPU tests,
-    two ranks on one GPU) device tensors are staged through the host.
+    ONE payload collective: the status rides as a 40th float64 column of the records (int32 -> float64 is exact), padded to the
+    largest shard, one ``dist.gather``.  Ranks may hold different n_i: the counts are exchanged first (one tiny all_gather and
+    the host read of its result) unless the caller already knows them - ``counts`` (a sequence of world_size ints, the same
+    on every rank; what ``plan_shards`` or a fixed batch size gives) skips that round trip.  Returns ``(boxes, status, counts)``
+    on ``dst`` and ``None`` elsewhere.  ~320 B per box: 860k boxes over 8 GPUs is 34 MB per rank - irrelevant next to the
+    compute, so the simplest correct collective is used.  With the gloo backend (CPU tests, two ranks on one GPU) device
+    tensors are staged through the host.
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if _is_gloo(group) and boxes.is_cuda:
         boxes, status = boxes.cpu(), status.cpu()
-    n = torch.tensor([boxes.shape[0]], dtype=torch.int64, device=boxes.device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
-    counts = [int(c) for c in counts]
+    if counts is None:
+        n = torch.tensor([boxes.shape[0]], dtype=torch.int64, device=boxes.device)
+        cl = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(cl, n, group=group)
+        counts = [int(c) for c in cl]
+    else:
+        counts = [int(c) for c in counts]
+        if len(counts) != world or counts[rank] != boxes.shape[0]:
+            raise ValueError("gather_boxes: counts must list every rank's row count (this rank's does not match its tensor)")
     nmax = max(counts)
-    pb = boxes if boxes.shape[0] == nmax else torch.cat(
-        [boxes, boxes.new_zeros((nmax - boxes.shape[0], boxes.shape[1]))])
-    ps = status if status.shape[0] == nmax else torch.cat([status, status.new_zeros(nmax - status.shape[0])])
-    pb, ps = pb.contiguous(), ps.contiguous()
+    payload = boxes.new_zeros((nmax, boxes.shape[1] + 1))
+    payload[:boxes.shape[0], :boxes.shape[1]] = boxes
+    payload[:boxes.shape[0], boxes.shape[1]] = status.to(boxes.dtype)
     try:
-        if rank == dst:
-            gb = [torch.empty_like(pb) for _ in range(world)]
-            gs = [torch.empty_like(ps) for _ in range(world)]
-        else:
-            gb = gs = None
-        dist.gather(pb, gb, dst=dst, group=group)
-        dist.gather(ps, gs, dst=dst, group=group)
+        gp = [torch.empty_like(payload) for _ in range(world)] if rank == dst else None
+        dist.gather(payload, gp, dst=dst, group=group)
     except (RuntimeError, NotImplementedError) as e:
         # ONLY a backend that has no gather at all: every rank collects, dst keeps.  Anything else (a failed RCCL call, a
         # mismatched shape) must surface - falling back would hide the error and double the traffic.
@@ -123,13 +124,12 @@ def gather_boxes(boxes: torch.Tensor, status: torch.Tensor, dst: int = 0, group=
         if not (isinstance(e, NotImplementedError) or "not supported" in msg or "not implemented" in msg or
                 "does not support" in msg or "no backend" in msg):
             raise
-        gb = [torch.empty_like(pb) for _ in range(world)]
-        gs = [torch.empty_like(ps) for _ in range(world)]
-        dist.all_gather(gb, pb, group=group)
-        dist.all_gather(gs, ps, group=group)
+        gp = [torch.empty_like(payload) for _ in range(world)]
+        dist.all_gather(gp, payload, group=group)
     if rank != dst:
         return None
-    return (torch.cat([g[:c] for g, c in zip(gb, counts)]), torch.cat([g[:c] for g, c in zip(gs, counts)]), counts)
+    allp = torch.cat([g[:c] for g, c in zip(gp, counts)])
+    return allp[:, :boxes.shape[1]].contiguous(), allp[:, boxes.shape[1]].to(status.dtype), counts
 
 
 def fit_instances_sharded(depth, masks, K, image_index, ground=None, sample_idx=None, areas=None, dst: int = 0, group=None,
@@ -154,7 +154,8 @@ def fit_instances_sharded(depth, masks, K, image_index, ground=None, sample_idx=
         P, H, W = (int(v) for v in depth)
     else:
         P, H, W = depth.shape
-    sh = plan_shards(img, P, world, areas=areas, frame_pixels=H * W)[rank]
+    plan = plan_shards(img, P, world, areas=areas, frame_pixels=H * W)
+    sh = plan[rank]
     local_img = (img[sh.inst_lo:sh.inst_hi] - sh.img_lo).astype(np.int32)
     if load_fn is not None:
         d, m, k, g, si = load_fn(sh)
@@ -172,4 +173,5 @@ def fit_instances_sharded(depth, masks, K, image_index, ground=None, sample_idx=
         dev = m.device if isinstance(m, torch.Tensor) else torch.device("cpu")
         boxes = torch.zeros((0, 39), dtype=torch.float64, device=dev)
         status = torch.zeros((0,), dtype=torch.int32, device=dev)
-    return gather_boxes(boxes, status, dst=dst, group=group)
+    # every rank knows every shard's size from the plan: no count exchange
+    return gather_boxes(boxes, status, dst=dst, group=group, counts=[p.inst_hi - p.inst_lo for p in plan])
