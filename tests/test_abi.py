@@ -222,3 +222,31 @@ def test_omni3d_category_table_is_data():
     assert len(cats) == 80 and len({c["id"] for c in cats}) == 80 and len({c["name"] for c in cats}) == 80
     by = {c["name"]: c["id"] for c in cats}
     assert by["person"] == 7 and by["car"] == 1 and by["teddy bear"] == 151 and all(set(c) == {"supercategory", "id", "name"} for c in cats)
+
+
+def test_upload_many_packs_host_arrays_into_one_buffer():
+    """batched._upload_many / _bulk (host logic of the per-image wrappers): several small host arrays -> views of ONE buffer (one
+    host-to-device copy), dtype conversion, 16-byte aligned pieces, None and empty arrays, tensors passed through untouched."""
+    import torch
+
+    from labelany3d_amd.batched import _bulk, _upload_many
+
+    cpu = torch.device("cpu")
+    xy = np.arange(14, dtype=np.int64).reshape(7, 2)            # converted to int32
+    ro = np.array([0, 3, 7], np.int64)
+    g = np.array([[0.1, -0.9, 0.2, 1.0]], np.float32)           # converted to float64
+    empty = np.zeros((0, 4))
+    out = _upload_many([(xy, torch.int32), (ro, torch.int64), (None, torch.int32), (g, torch.float64), (empty, torch.float64)], cpu)
+    assert out[2] is None
+    assert out[0].dtype == torch.int32 and out[0].shape == (7, 2) and np.array_equal(out[0].numpy(), xy)
+    assert out[1].dtype == torch.int64 and np.array_equal(out[1].numpy(), ro)
+    assert out[3].dtype == torch.float64 and np.allclose(out[3].numpy(), g) and out[4].shape == (0, 4)
+    base = out[0].untyped_storage().data_ptr()
+    for t in (out[0], out[1], out[3]):
+        assert t.untyped_storage().data_ptr() == base and (t.data_ptr() - base) % 16 == 0        # one buffer, aligned pieces
+    keep = torch.arange(3)
+    a, b, c, d = _bulk(cpu, (xy, torch.int32), (keep, torch.int64), (None, torch.float64), (ro, torch.int64))
+    assert b is keep and c is None and isinstance(a, torch.Tensor) and isinstance(d, torch.Tensor)
+    assert a.untyped_storage().data_ptr() == d.untyped_storage().data_ptr()
+    one = _bulk(cpu, (xy, torch.int32), (None, torch.int64))
+    assert one[0] is xy and one[1] is None                                                      # a single host array is left to _as_dev
