@@ -755,7 +755,7 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
           for (int rr = 0; rr < 8; ++rr) {
             const unsigned w = bw[min(rr, rmax) * p.ntx];
             any |= w;
-            if (LK) wrd[k][rr] = rr <= rmax ? w : 0u;
+            if constexpr (LK) wrd[k][rr] = rr <= rmax ? w : 0u;
           }
         }
         bal[k] = __ballot(any != 0);
@@ -781,7 +781,7 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
           }
           off += __popcll(bal[k]);
         }
-        if (LK && nactive * 32 <= p.mask_lds_bytes) {   // uniform
+        if constexpr (LK) if (nactive * 32 <= p.mask_lds_bytes) {   // uniform
           // every wave read its row words before the barrier above: the image region can be overwritten in place
           compact = 1;
           off = base;

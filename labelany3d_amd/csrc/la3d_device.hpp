@@ -449,7 +449,7 @@ struct FitParams {
   double* aux;
 };
 
-// per-instance geometry in the workspace (20 doubles = 160 B), written by the split engine's geo_kernel
+// per-instance geometry in the workspace (20 doubles = 160 B), written by the split engine's plan_kernel (geo_one)
 // (the instance engine keeps it in LDS)
 constexpr int GEO_D = 20;  // M[9] (= Rg^T Kinv : p' = d * (M @ [u,v,1])), Rg[9], bad_ground, pad
 

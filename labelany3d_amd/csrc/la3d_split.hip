@@ -9,7 +9,7 @@
 //                    (128 px x 8 rows = 1 KB per wave-load, non-temporal), packs it to a TILE-MAJOR bit
 //                    image in the workspace (32 B per 32x8-px tile; only tiles with a set bit are written),
 //                    and emits the band's compacted list of active tiles + mask pixel count.
-//   plan_kernel      one workgroup: prefix of the tile counts + every walking wave's start position.
+//   plan_kernel      one workgroup: the per-instance geometry (K^-1, Rg, M), prefix of the tile counts + every walking wave's start position.
 //   moments_kernel   every wave of the grid walks an EQUAL range of the batch's concatenated active-tile
 //                    list (4 tiles = 4 depth lines in flight per step), flushing one partial per instance
 //                    it touches into slot (global wave index + instance index) — unique, ordered, static.
@@ -59,11 +59,10 @@ struct SplitParams {
   double* axis;         // [B][4] = cos yaw, sin yaw, status, pad
 };
 
-// per-instance geometry (reference src/util.py:56, src/util_3dbox.py:128-134): one thread per instance,
-// kept out of the scan kernel so that its 3x3 elimination does not cost the streaming waves registers
-__global__ __launch_bounds__(64) void geo_kernel(const FitParams p) {
-  const int inst = blockIdx.x * 64 + threadIdx.x;
-  if (inst >= p.B) return;
+// per-instance geometry (reference src/util.py:56, src/util_3dbox.py:128-134): one thread per instance.  Runs inside plan_kernel
+// (round 3: it was a launch of its own at the head of the chain - one dependent launch less per call, ~3 us at small batches);
+// kept out of the scan kernels so that its 3x3 elimination does not cost the streaming waves registers
+__device__ inline void geo_one(const FitParams& p, int inst) {
   const int img = p.image_index ? p.image_index[inst] : inst;
   double Kinv[9], Rg[9];
   inv3(p.K + (long long)img * p.k_stride, Kinv);
@@ -263,6 +262,7 @@ __global__ __launch_bounds__(PNT) void plan_kernel(const SplitParams sp) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: lives in an SGPR
   const int nseg = sp.nb * sp.nband;
   const int* cnt = sp.tcount + (long long)sp.b0 * sp.nband;
+  for (int i = tid; i < sp.nb; i += PNT) geo_one(sp.f, sp.b0 + i);   // this sub-batch's geometry: read by the walks that follow
   for (int i = tid; i < nseg; i += PNT) prefix[i] = cnt[i];
   __syncthreads();
   const int per = (nseg + PNT - 1) / PNT;
@@ -678,8 +678,6 @@ int split_fit(const FitParams& pin, void* workspace, hipStream_t s) {
   }
   const bool single = nsub == 1;
   hipStream_t scan_s = s;
-  hipLaunchKernelGGL(geo_kernel, dim3((B + 63) / 64), dim3(64), 0, s, sp.f);
-  if (int rc = check_launch("geo_kernel")) return rc;
   if (!single) {
     if (hipEventRecord(st.fork, s) != hipSuccess) return LA3D_ERR_HIP;
     for (int i = 0; i < 2; ++i)
