@@ -1055,17 +1055,56 @@ __device__ inline bool hull_yaw(SharedHull* hs, SharedP* sh, int tid, double* ya
       }
       __syncthreads();
     }
-  if (tid == 0) {  // monotone chain: lower hull left->right, then upper hull right->left (counter-clockwise)
+  // Andrew's monotone chain is serial (every step depends on the stack the previous one left) and each of its cross products is a
+  // chain of dependent LDS reads - one lane needed ~150 us for 500 points.  Round 3: (1) sixteen lanes each run the chain over a
+  // sixteenth of the sorted points and mark what survives in their chunk (a point inside its chunk's hull cannot be a vertex of the
+  // whole hull; collinear points drop out either way), (2) the survivors are compacted in sorted order, (3) one lane runs the SAME
+  // chain over the survivors only.  The vertex sequence - hence every edge, area and the winning yaw - is the one the chain over
+  // all points gives.
+  constexpr int HCH = 16;
+  unsigned short* cl = reinterpret_cast<unsigned short*>(hs->yaw);   // survivors in sorted order (yaw[] is written after the chain)
+  auto cross = [&](int o, int a, int b) {
+    return (hs->x[a] - hs->x[o]) * (hs->z[b] - hs->z[o]) - (hs->z[a] - hs->z[o]) * (hs->x[b] - hs->x[o]);
+  };
+  for (int i = tid; i < n; i += NTP) hs->area[i] = 0.0;              // survivor flags (area[] is written after the chain)
+  __syncthreads();
+  if (tid < HCH) {
+    const int lo = (int)((long long)n * tid / HCH), hi = (int)((long long)n * (tid + 1) / HCH);
+    unsigned short* S = hs->hull + lo;                               // this lane's stack: as many slots as its chunk has points
+    for (int pass = 0; pass < 2; ++pass) {                           // lower hull left -> right, then upper hull right -> left
+      int k = 0;
+      for (int q = 0; q < hi - lo; ++q) {
+        const int i = pass == 0 ? lo + q : hi - 1 - q;
+        while (k >= 2 && cross(S[k - 2], S[k - 1], i) <= 0) --k;
+        S[k++] = (unsigned short)i;
+      }
+      for (int q = 0; q < k; ++q) hs->area[S[q]] = 1.0;
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {                                                    // compaction of the survivors, ascending (one wave)
+    int base = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      const int i = i0 + tid;
+      const bool on = i < n && hs->area[i] != 0.0;
+      const unsigned long long bal = __ballot(on);
+      if (on) cl[base + __popcll(bal & ((1ull << tid) - 1ull))] = (unsigned short)i;
+      base += __popcll(bal);
+    }
+    if (tid == 0) sh->hull_n = base;                                 // (number of survivors, until the chain below replaces it)
+  }
+  __syncthreads();
+  if (tid == 0) {  // monotone chain over the survivors: lower hull left->right, then upper hull right->left (counter-clockwise)
+    const int m = sh->hull_n;
     unsigned short* H = hs->hull;
     int k = 0;
-    auto cross = [&](int o, int a, int b) {
-      return (hs->x[a] - hs->x[o]) * (hs->z[b] - hs->z[o]) - (hs->z[a] - hs->z[o]) * (hs->x[b] - hs->x[o]);
-    };
-    for (int i = 0; i < n; ++i) {
+    for (int q = 0; q < m; ++q) {
+      const int i = cl[q];
       while (k >= 2 && cross(H[k - 2], H[k - 1], i) <= 0) --k;
       H[k++] = (unsigned short)i;
     }
-    for (int i = n - 2, t = k + 1; i >= 0; --i) {
+    for (int q = m - 2, t = k + 1; q >= 0; --q) {
+      const int i = cl[q];
       while (k >= t && cross(H[k - 2], H[k - 1], i) <= 0) --k;
       H[k++] = (unsigned short)i;
     }
@@ -1074,18 +1113,24 @@ __device__ inline bool hull_yaw(SharedHull* hs, SharedP* sh, int tid, double* ya
   __syncthreads();
   const int h = sh->hull_n;
   if (h < 3) return false;
-  for (int e = tid; e < h; e += NTP) {
+  // one hull edge per wave at a time, lanes over the points (min / max are order independent: the areas are those of a serial sweep)
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int e = wave; e < h; e += NTP / 64) {
     const int i0 = hs->hull[e], i1 = hs->hull[(e + 1 == h) ? 0 : e + 1];
     const double yaw = atan2(hs->z[i1] - hs->z[i0], hs->x[i1] - hs->x[i0]);
     const double cs = cos(yaw), sn = sin(yaw);
     double xlo = INFINITY, xhi = -INFINITY, zlo = INFINITY, zhi = -INFINITY;
-    for (int j = 0; j < n; ++j) {
+    for (int j = lane; j < n; j += 64) {
       const double px = hs->x[j], pz = hs->z[j];
       const double rx = cs * px - sn * pz, rz = sn * px + cs * pz;
       xlo = fmin(xlo, rx); xhi = fmax(xhi, rx); zlo = fmin(zlo, rz); zhi = fmax(zhi, rz);
     }
-    hs->area[e] = (xhi - xlo) * (zhi - zlo);
-    hs->yaw[e] = yaw;
+    xlo = wave_min(xlo); xhi = wave_max(xhi); zlo = wave_min(zlo); zhi = wave_max(zhi);
+    if (lane == 0) {
+      // (area[] / yaw[] slots below h: the survivor flags and the survivor list are dead by now - the barrier above)
+      hs->area[e] = (xhi - xlo) * (zhi - zlo);
+      hs->yaw[e] = yaw;
+    }
   }
   __syncthreads();
   if (tid == 0) {
