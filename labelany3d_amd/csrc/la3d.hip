@@ -1032,6 +1032,31 @@ struct alignas(16) SharedHull {
   unsigned short hull[2 * HULL_MAX + 2];
 };
 
+// One pass of Andrew's monotone chain: visits cnt entries of the candidate list cl starting at position q0 in direction dq, pushes
+// point indices on the stack S (k0 entries on entry; a pop needs at least t), returns the stack size.  The coordinates of the two
+// stack tops are carried in registers, so a step that pops nothing waits for no dependent LDS read.  The turn test is the textbook
+// cross(o, a, b) = (xa - xo)(zb - zo) - (za - zo)(xb - xo) <= 0 -> pop.
+__device__ inline int chain_pass(const SharedHull* hs, const unsigned short* cl, int q0, int dq, int cnt, unsigned short* S, int k0, int t) {
+  int k = k0;
+  double ox = 0, oz = 0, ax = 0, az = 0;
+  if (k >= 1) { const int a = S[k - 1]; ax = hs->x[a]; az = hs->z[a]; }
+  if (k >= 2) { const int o = S[k - 2]; ox = hs->x[o]; oz = hs->z[o]; }
+  for (int c = 0, q = q0; c < cnt; ++c, q += dq) {
+    const int i = cl[q];
+    const double px = hs->x[i], pz = hs->z[i];
+    while (k >= t) {
+      const double cr = (ax - ox) * (pz - oz) - (az - oz) * (px - ox);
+      if (!(cr <= 0)) break;
+      --k;
+      ax = ox; az = oz;
+      if (k >= 2) { const int o = S[k - 2]; ox = hs->x[o]; oz = hs->z[o]; }
+    }
+    S[k++] = (unsigned short)i;
+    ox = ax; oz = az; ax = px; az = pz;
+  }
+  return k;
+}
+
 // Minimum-area enclosing rectangle over hull-edge directions — reference src/util_3dbox.py:189-224
 // (SciPy/Qhull there; here: bitonic sort in LDS, Andrew's monotone chain, one thread per hull edge).
 // Reproduces the reference's conventions: yaw = atan2(edge_z, edge_x); points rotated by
@@ -1058,56 +1083,46 @@ __device__ inline bool hull_yaw(SharedHull* hs, SharedP* sh, int tid, double* ya
   // Andrew's monotone chain is serial (every step depends on the stack the previous one left) and each of its cross products is a
   // chain of dependent LDS reads - one lane needed ~150 us for 500 points.  Round 3: (1) sixteen lanes each run the chain over a
   // sixteenth of the sorted points and mark what survives in their chunk (a point inside its chunk's hull cannot be a vertex of the
-  // whole hull; collinear points drop out either way), (2) the survivors are compacted in sorted order, (3) one lane runs the SAME
-  // chain over the survivors only.  The vertex sequence - hence every edge, area and the winning yaw - is the one the chain over
-  // all points gives.
-  constexpr int HCH = 16;
-  unsigned short* cl = reinterpret_cast<unsigned short*>(hs->yaw);   // survivors in sorted order (yaw[] is written after the chain)
-  auto cross = [&](int o, int a, int b) {
-    return (hs->x[a] - hs->x[o]) * (hs->z[b] - hs->z[o]) - (hs->z[a] - hs->z[o]) * (hs->x[b] - hs->x[o]);
-  };
-  for (int i = tid; i < n; i += NTP) hs->area[i] = 0.0;              // survivor flags (area[] is written after the chain)
-  __syncthreads();
-  if (tid < HCH) {
-    const int lo = (int)((long long)n * tid / HCH), hi = (int)((long long)n * (tid + 1) / HCH);
-    unsigned short* S = hs->hull + lo;                               // this lane's stack: as many slots as its chunk has points
-    for (int pass = 0; pass < 2; ++pass) {                           // lower hull left -> right, then upper hull right -> left
-      int k = 0;
-      for (int q = 0; q < hi - lo; ++q) {
-        const int i = pass == 0 ? lo + q : hi - 1 - q;
-        while (k >= 2 && cross(S[k - 2], S[k - 1], i) <= 0) --k;
-        S[k++] = (unsigned short)i;
+  // whole hull; collinear points drop out either way), the survivors are compacted in sorted order; (2) four lanes do the same
+  // over quarters of the survivors; (3) one lane runs the SAME chain over what is left.  The vertex sequence - hence every edge,
+  // area and the winning yaw - is the one the chain over all points gives.  The two stack tops live in registers (chain_pass).
+  unsigned short* cl = reinterpret_cast<unsigned short*>(hs->yaw);   // current candidates in sorted order (yaw[] is written after the chain)
+  for (int i = tid; i < n; i += NTP) cl[i] = (unsigned short)i;
+  int m = n;
+  for (int level = 0; level < 2; ++level) {
+    const int nch = level == 0 ? 16 : 4;
+    if (m <= 4 * nch) continue;                                      // uniform
+    for (int i = tid; i < n; i += NTP) hs->area[i] = 0.0;            // survivor flags by point (area[] is written after the chain)
+    __syncthreads();
+    if (tid < nch) {
+      const int lo = (int)((long long)m * tid / nch), hi = (int)((long long)m * (tid + 1) / nch);
+      unsigned short* S = hs->hull + lo;                             // this lane's stack: as many slots as its chunk has entries
+      for (int pass = 0; pass < 2; ++pass) {                         // lower hull left -> right, then upper hull right -> left
+        const int k = chain_pass(hs, cl, pass == 0 ? lo : hi - 1, pass == 0 ? 1 : -1, hi - lo, S, 0, 2);
+        for (int q = 0; q < k; ++q) hs->area[S[q]] = 1.0;
       }
-      for (int q = 0; q < k; ++q) hs->area[S[q]] = 1.0;
     }
-  }
-  __syncthreads();
-  if (tid < 64) {                                                    // compaction of the survivors, ascending (one wave)
-    int base = 0;
-    for (int i0 = 0; i0 < n; i0 += 64) {
-      const int i = i0 + tid;
-      const bool on = i < n && hs->area[i] != 0.0;
-      const unsigned long long bal = __ballot(on);
-      if (on) cl[base + __popcll(bal & ((1ull << tid) - 1ull))] = (unsigned short)i;
-      base += __popcll(bal);
+    __syncthreads();
+    if (tid < 64) {                                                  // in-place compaction of the survivors, ascending (one wave:
+      int base = 0;                                                  // a block's reads precede its writes, and it writes behind itself)
+      for (int i0 = 0; i0 < m; i0 += 64) {
+        const int i = i0 + tid;
+        const unsigned short id = i < m ? cl[i] : (unsigned short)0;
+        const bool on = i < m && hs->area[id] != 0.0;
+        const unsigned long long bal = __ballot(on);
+        if (on) cl[base + __popcll(bal & ((1ull << tid) - 1ull))] = id;
+        base += __popcll(bal);
+      }
+      if (tid == 0) sh->hull_n = base;                               // (number of survivors, until the chain below replaces it)
     }
-    if (tid == 0) sh->hull_n = base;                                 // (number of survivors, until the chain below replaces it)
+    __syncthreads();
+    m = sh->hull_n;
+    __syncthreads();
   }
-  __syncthreads();
   if (tid == 0) {  // monotone chain over the survivors: lower hull left->right, then upper hull right->left (counter-clockwise)
-    const int m = sh->hull_n;
     unsigned short* H = hs->hull;
-    int k = 0;
-    for (int q = 0; q < m; ++q) {
-      const int i = cl[q];
-      while (k >= 2 && cross(H[k - 2], H[k - 1], i) <= 0) --k;
-      H[k++] = (unsigned short)i;
-    }
-    for (int q = m - 2, t = k + 1; q >= 0; --q) {
-      const int i = cl[q];
-      while (k >= t && cross(H[k - 2], H[k - 1], i) <= 0) --k;
-      H[k++] = (unsigned short)i;
-    }
+    int k = chain_pass(hs, cl, 0, 1, m, H, 0, 2);
+    k = chain_pass(hs, cl, m - 2, -1, m - 1, H, k, k + 1);
     sh->hull_n = k - 1;  // last vertex repeats the first
   }
   __syncthreads();
