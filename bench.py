@@ -284,6 +284,50 @@ def cpu_baseline(depth, masks, budget_s=8.0, max_inst=256):
     return out
 
 
+class StepRunner:
+    """One step = ONE la3d_fit_instances_ex call on a pre-built argument block (the steady-state call is a pure enqueue: no
+    allocation, no Python work beyond the ctypes call).  Exactly one of masks / rle / poly gives the masks; the scheduling of a
+    call travels in the block (opt_launch_order), never in process state."""
+
+    def __init__(self, fitter, depth, K, masks=None, rle=None, poly=None, image_index=None, sample_idx=None, area_hint=None,
+                 one_slot=False):
+        self.f, self.depth, self.K, self.masks, self.rle, self.poly = fitter, depth, K, masks, rle, poly
+        self.image_index, self.sample_idx, self.area_hint, self.one_slot = image_index, sample_idx, area_hint, one_slot
+        self.blocks = {}
+
+    def __call__(self, slot=0, stream=None, ws_slot=0, launch_order=None):
+        import ctypes as C
+
+        from labelany3d_amd import options
+        from labelany3d_amd._lib import FitArgs, check, lib
+        if self.one_slot:
+            slot = 0
+        key = (slot, ws_slot, stream.cuda_stream, launch_order)
+        a = self.blocks.get(key)
+        if a is None:
+            f, d, k = self.f, self.depth, self.K
+            a = FitArgs()
+            a.struct_size = C.sizeof(FitArgs)
+            a.B, a.H, a.W = f.B, f.H, f.W
+            a.depth, a.depth_plane_stride = d.data_ptr(), (f.H * f.W if (d.dim() == 3 and d.shape[0] > 1) else 0)
+            a.image_index = None if self.image_index is None else self.image_index.data_ptr()
+            if self.rle is not None:
+                a.rle_counts, a.rle_offsets = self.rle[0].data_ptr(), self.rle[1].data_ptr()
+            elif self.poly is not None:
+                a.poly_xy, a.ring_offsets, a.inst_rings = (t.data_ptr() for t in self.poly)
+            else:
+                a.mask = self.masks.data_ptr()
+            a.K, a.k_stride = k.data_ptr(), (9 if (k.dim() == 3 and k.shape[0] > 1) else 0)
+            a.filter_boundary = -1
+            a.sample_idx = None if self.sample_idx is None else self.sample_idx.data_ptr()
+            a.area_hint = None if self.area_hint is None else self.area_hint.data_ptr()
+            a.out, a.status, a.aux = f.boxes[slot].data_ptr(), f.status[slot].data_ptr(), f.aux[slot].data_ptr()
+            a.workspace, a.stream = f.workspace[ws_slot].data_ptr(), stream.cuda_stream
+            a.opt_launch_order = options.ORDER[launch_order]
+            self.blocks[key] = a
+        check(lib.la3d_fit_instances_ex(C.byref(a)), "la3d_fit_instances_ex")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -356,93 +400,36 @@ def main():
     else:
         depth, masks, K, n_masked, rects = make_inputs(B, device, 1234 + rank)
     fitter = InstanceFitter(B, H, W, device, slots=(1 if args.config3 else max(steps, 1)), ws_slots=max(args.streams, 2))
-    if args.config3:
-        _run = fitter.run
-        fitter.run = lambda d, m, k, slot=0, stream=None, ws_slot=0: _run(d, m, k, image_index=image_index, slot=0, stream=stream, ws_slot=ws_slot)
     sample_idx = None
     if args.subsample:
         from labelany3d_amd import draw_sample_idx
         counts = masks.reshape(B, -1).sum(1, dtype=torch.int64)
         sample_idx = torch.as_tensor(draw_sample_idx(counts, np.random.RandomState(99 + rank)), device=device)
-        _run_s = fitter.run
-        fitter.run = lambda d, m, k, slot=0, stream=None, ws_slot=0: _run_s(d, m, k, sample_idx=sample_idx, image_index=image_index,
-                                                                            slot=(0 if args.config3 else slot), stream=stream, ws_slot=ws_slot)
     stream = torch.cuda.current_stream()
     streams = [stream] + [torch.cuda.Stream(device=device) for _ in range(max(args.streams, 1) - 1)]
-
+    rle_c = rle_o = pxy = pro = pir = None
     if args.rle:
-        import ctypes as C
-
-        from labelany3d_amd._lib import check, lib
+        if rects is None:
+            raise SystemExit("--rle needs the rectangle masks of the default workload (not --config3)")
         rc_np, ro_np = rect_rle(rects)
         rle_c, rle_o = torch.as_tensor(rc_np, device=device), torch.as_tensor(ro_np, device=device)
-        kfull = K[None].expand(B, 3, 3).contiguous()
-
-        def run_rle(slot, st, ws_slot=0):
-            check(lib.la3d_fit_instances_rle(C.c_void_p(depth.data_ptr()), H * W, None, C.c_void_p(rle_c.data_ptr()),
-                                             C.c_void_p(rle_o.data_ptr()), C.c_void_p(kfull.data_ptr()), 9, None, None, B, H, W,
-                                             C.c_void_p(fitter.boxes[slot].data_ptr()), C.c_void_p(fitter.status[slot].data_ptr()),
-                                             C.c_void_p(fitter.aux[slot].data_ptr()), C.c_void_p(fitter.workspace[ws_slot].data_ptr()),
-                                             C.c_void_p(st.cuda_stream)), "la3d_fit_instances_rle")
-
-        fitter.run = lambda d, m, k, slot=0, stream=None, ws_slot=0: run_rle(slot, stream, ws_slot)
-
     if args.poly:
-        import ctypes as C
-
         if rects is None:
             raise SystemExit("--poly needs the rectangle masks of the default workload (not --config3 / --config5)")
         from labelany3d_amd import pack_polygons
-        from labelany3d_amd._lib import check, lib
         r0_, c0_, hh_, ww_ = rects
         segs = [[[int(b), int(a), int(b + w - 1), int(a), int(b + w - 1), int(a + h - 1), int(b), int(a + h - 1)]]
                 for a, b, h, w in zip(r0_, c0_, hh_, ww_)]
         pxy, pro, pir, _, _ = pack_polygons(segs, H, W)
         pxy, pro, pir = (torch.as_tensor(x, device=device) for x in (pxy, pro, pir))
-        kfull = K[None].expand(B, 3, 3).contiguous()
-
-        def run_poly(slot, st, ws_slot=0):
-            check(lib.la3d_fit_instances_poly(C.c_void_p(depth.data_ptr()), H * W, None, C.c_void_p(pxy.data_ptr()),
-                                              C.c_void_p(pro.data_ptr()), C.c_void_p(pir.data_ptr()), C.c_void_p(kfull.data_ptr()), 9,
-                                              None, None, B, H, W, C.c_void_p(fitter.boxes[slot].data_ptr()),
-                                              C.c_void_p(fitter.status[slot].data_ptr()), C.c_void_p(fitter.aux[slot].data_ptr()),
-                                              C.c_void_p(fitter.workspace[ws_slot].data_ptr()), C.c_void_p(st.cuda_stream)),
-                  "la3d_fit_instances_poly")
-
-        fitter.run = lambda d, m, k, slot=0, stream=None, ws_slot=0: run_poly(slot, stream, ws_slot)
-
+    areas = None
     if args.area_hint:
-        import ctypes as C
-
-        from labelany3d_amd._lib import FitArgs, check, lib
         if args.config3 or args.subsample:
             raise SystemExit("--area-hint: private depth planes, full-mask mode only")
         areas = masks.reshape(B, -1).sum(1, dtype=torch.int32)     # what the annotation's "area" field holds
-        kfull_h = K[None].expand(B, 3, 3).contiguous()
-        blocks = {}
-
-        def run_hinted(d, m, k, slot=0, stream=None, ws_slot=0):
-            key = (slot, ws_slot, stream.cuda_stream)
-            a = blocks.get(key)
-            if a is None:
-                a = FitArgs()
-                a.struct_size = C.sizeof(FitArgs)
-                a.B, a.H, a.W = B, H, W
-                a.depth, a.depth_plane_stride = d.data_ptr(), H * W
-                if args.rle:
-                    a.rle_counts, a.rle_offsets = rle_c.data_ptr(), rle_o.data_ptr()
-                elif args.poly:
-                    a.poly_xy, a.ring_offsets, a.inst_rings = pxy.data_ptr(), pro.data_ptr(), pir.data_ptr()
-                else:
-                    a.mask = m.data_ptr()
-                a.K, a.k_stride, a.filter_boundary = kfull_h.data_ptr(), 9, -1
-                a.area_hint = areas.data_ptr()
-                a.out, a.status, a.aux = fitter.boxes[slot].data_ptr(), fitter.status[slot].data_ptr(), fitter.aux[slot].data_ptr()
-                a.workspace, a.stream = fitter.workspace[ws_slot].data_ptr(), stream.cuda_stream
-                blocks[key] = a
-            check(lib.la3d_fit_instances_ex(C.byref(a)), "la3d_fit_instances_ex")
-
-        fitter.run = run_hinted
+    run = StepRunner(fitter, depth, K, masks=None if (args.rle or args.poly) else masks, rle=(rle_c, rle_o) if args.rle else None,
+                     poly=(pxy, pro, pir) if args.poly else None, image_index=image_index, sample_idx=sample_idx, area_hint=areas,
+                     one_slot=bool(args.config3))
 
     def barrier():
         torch.cuda.synchronize()
@@ -454,7 +441,7 @@ def main():
     # a 20-step timed region entered from an idle chip reads ~5 % slower, profiles/r03/exp_step_ramp.py)
     stream_GBps, _ = measured_stream_ceiling(masks)
     for _ in range(warmup):
-        fitter.run(depth, masks, K, slot=0, stream=stream)
+        run(slot=0, stream=stream)
     if dist is not None:  # warm the communicator outside the timed region
         gather_boxes(fitter.boxes[:1].reshape(-1, 39), fitter.status[:1].reshape(-1), dst=0, counts=[B] * world)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -463,54 +450,56 @@ def main():
     ev0.record(stream)
     if len(streams) == 1:
         for k in range(steps):
-            fitter.run(depth, masks, K, slot=k, stream=stream)
+            run(slot=k, stream=stream)
     else:
         for st in streams[1:]:
             st.wait_stream(stream)
         for k in range(steps):
-            fitter.run(depth, masks, K, slot=k, stream=streams[k % len(streams)], ws_slot=k % len(streams))
+            run(slot=k, stream=streams[k % len(streams)], ws_slot=k % len(streams))
         for st in streams[1:]:
             stream.wait_stream(st)
     ev1.record(stream)
-    gathered = None
-    if dist is not None:
-        # (every rank fits steps x B instances: the counts are known, so the timed region holds exactly ONE collective)
-        gathered = gather_boxes(fitter.boxes.reshape(-1, 39), fitter.status.reshape(-1), dst=0,
-                                counts=[fitter.boxes.shape[0] * B] * world)
     barrier()
     t1 = time.perf_counter()
+    # the job's one collective: every rank's (steps x B, 39) records + status to rank 0.  Timed on its own (round 4): at
+    # 20 steps it is 8 x 6.5 MB into one GPU inside a 2.3 ms window and would read as scaling loss; `value` / ms_per_step are
+    # the K fit steps between the two barriers above, `gather_ms` stands beside them, `value_incl_gather` has both.
+    gathered, gather_s = None, 0.0
+    if dist is not None:
+        # (every rank fits steps x B instances: the counts are known, so there is exactly ONE collective)
+        gathered = gather_boxes(fitter.boxes.reshape(-1, 39), fitter.status.reshape(-1), dst=0,
+                                counts=[fitter.boxes.shape[0] * B] * world)
+        barrier()
+        gather_s = time.perf_counter() - t1
 
     # secondary figure, same run: the same K steps PIPELINED - issued round-robin on two HIP streams (batch k+1 is enqueued
-    # while batch k runs), launch order off (it assumes an idle chip).  What a caller streaming many batches gets; the headline
-    # above stays the strictly serial form.
+    # while batch k runs), launch order off FOR THESE CALLS (it assumes an idle chip; la3d_fit_args::opt_launch_order).  What a
+    # caller streaming many batches gets; the headline above stays the strictly serial form.
     pipelined = None
     if len(streams) == 1 and not args.no_pipelined and not args.config3 and not args.subsample:   # (config 3 is one multi-round call already)
-        from labelany3d_amd import set_launch_order
         s2 = [stream, torch.cuda.Stream(device=device)]
-        set_launch_order(False)
-        try:
-            for k in range(max(4, warmup // 4)):
-                fitter.run(depth, masks, K, slot=0, stream=s2[k % 2], ws_slot=k % 2)
-            barrier()
-            p0 = time.perf_counter()
-            s2[1].wait_stream(stream)
-            for k in range(steps):
-                fitter.run(depth, masks, K, slot=k, stream=s2[k % 2], ws_slot=k % 2)
-            stream.wait_stream(s2[1])
-            barrier()
-            pel = torch.tensor([time.perf_counter() - p0], dtype=torch.float64, device=red_dev)
-            if dist is not None:
-                dist.all_reduce(pel, op=dist.ReduceOp.MAX)
-            pipelined = float(pel)
-        finally:
-            set_launch_order(None)
+        for k in range(max(4, warmup // 4)):
+            run(slot=0, stream=s2[k % 2], ws_slot=k % 2, launch_order=False)
+        barrier()
+        p0 = time.perf_counter()
+        s2[1].wait_stream(stream)
+        for k in range(steps):
+            run(slot=k, stream=s2[k % 2], ws_slot=k % 2, launch_order=False)
+        stream.wait_stream(s2[1])
+        barrier()
+        pel = torch.tensor([time.perf_counter() - p0], dtype=torch.float64, device=red_dev)
+        if dist is not None:
+            dist.all_reduce(pel, op=dist.ReduceOp.MAX)
+        pipelined = float(pel)
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=red_dev)
     kern_ms = torch.tensor([ev0.elapsed_time(ev1) / steps], dtype=torch.float64, device=red_dev)
+    gather_t = torch.tensor([gather_s], dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
         dist.all_reduce(kern_ms, op=dist.ReduceOp.MAX)
-    elapsed, kern_ms = float(elapsed), float(kern_ms)
+        dist.all_reduce(gather_t, op=dist.ReduceOp.MAX)
+    elapsed, kern_ms, gather_s = float(elapsed), float(kern_ms), float(gather_t)
 
     ok = int((fitter.status == 0).sum())
     if rank == 0:
@@ -581,6 +570,8 @@ def main():
             "steps": steps,
             "warmup": warmup,
             "ms_per_step": elapsed / steps * 1e3,
+            "gather_ms": (gather_s * 1e3) if dist is not None else None,
+            "value_incl_gather": (world * steps * B / (elapsed + gather_s)) if dist is not None else None,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -643,7 +634,7 @@ def main():
                 "value": world * steps * B / pipelined, "unit": "boxes/s", "ms_per_step": pipelined / steps * 1e3, "streams": 2,
                 "required_GBps": req_bytes / (pipelined / steps) / 1e9, "frac": req_bytes / (pipelined / steps) / 1e9 / HBM_PEAK_GBPS,
                 "note": "secondary: the same K steps issued round-robin on two HIP streams (independent batches overlap their "
-                        "memory-bound mask stream and their passes), size-balanced launch order off (la3d_set_launch_order(0)); "
+                        "memory-bound mask stream and their passes), size-balanced launch order off for these calls (la3d_fit_args::opt_launch_order); "
                         "wall clock over K steps between the same barriers; not the headline",
             }
         if world == 1 and not args.no_cpu_baseline:

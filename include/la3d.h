@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LA3D_ABI_VERSION 1
+#define LA3D_ABI_VERSION 2
 #define LA3D_REC 39      /* doubles per box: center_cam[3] dimensions[3]=(dz,dy,dx) R_cam[9] bbox3D_cam[8][3] */
 #define LA3D_AUX 4       /* doubles per box: yaw, n_valid, n_in (mask pixels / cloud points), eigen-gap (l1-l2)/l1;
                             with LA3D_METHOD_CONVEX_HULL aux[3] = -(hull vertices) when the hull decided the yaw
@@ -78,14 +78,21 @@ int la3d_unproject_batch(const float* depth, const double* K, int32_t k_stride, 
  * counts: dev i32 [B].  The host needs it to draw np.random.randint(0, N, 500). */
 int la3d_mask_counts(const uint8_t* mask, int B, int H, int W, int32_t* counts, void* stream);
 
-/* Process-wide switch for the size-balanced launch order of la3d_fit_instances* (256 < B <= 3 resident sets): mode 1 = on,
- * 0 = off, -1 = default (on; LA3D_BALANCE=0 in the environment turns it off).  The order assumes the call finds an idle
- * GPU.  A caller that pipelines independent batches on several streams (batch k+1 enqueued while batch k runs) should turn
- * it off: the batches then overlap their memory-bound and compute-bound phases by themselves (measured +20 %), and an
- * order computed for an idle chip only gets in the way.  Records never depend on it. */
-int la3d_set_launch_order(int mode);
-/* The mode la3d_set_launch_order last set (-1 / 0 / 1), so that a scoped user can restore it. */
-int la3d_get_launch_order(void);
+/* The library keeps NO mutable process state (re-entrant, no global state).  How a call is scheduled - which
+ * engine, whether the size-balanced launch order runs, which build of the instance kernel - is decided per call from its
+ * arguments; the three `opt_*` fields of la3d_fit_args override the decision for one call (0 = the library's choice).  The
+ * LA3D_* environment variables the measurement scripts use (LA3D_ENGINE, LA3D_BALANCE, LA3D_RETAIN, ...) are read ONCE, at
+ * the first call, into an immutable table of process defaults; they never change records, only speed.
+ * (ABI 2: la3d_set_launch_order / la3d_get_launch_order of ABI 1 - a process-wide switch - are gone; use opt_launch_order.) */
+#define LA3D_ENGINE_DEFAULT 0
+#define LA3D_ENGINE_INSTANCE 1        /* one workgroup per instance */
+#define LA3D_ENGINE_SPLIT 2           /* band scan + tile-range-balanced passes (falls back to the instance engine where it does not apply) */
+#define LA3D_ORDER_DEFAULT 0          /* size-balanced launch order for 256 < B <= 3 resident sets */
+#define LA3D_ORDER_OFF 1              /* a caller pipelining independent batches on several streams wants it off (measured +20 %) */
+#define LA3D_ORDER_ON 2
+#define LA3D_BUILD_DEFAULT 0
+#define LA3D_BUILD_PLAIN 1            /* 64 VGPRs, four workgroups per CU, pass-B tile culling */
+#define LA3D_BUILD_RETAINING 2        /* 128 VGPRs, two workgroups per CU, depth tiles kept in registers between the passes */
 
 /* Bytes of device scratch la3d_fit_instances needs for (B,H,W); may be 0. */
 size_t la3d_workspace_bytes(int B, int H, int W);
@@ -205,6 +212,11 @@ typedef struct la3d_fit_args {
   const int32_t* area_hint;   /* dev i32 [B] | NULL: mask areas in pixels the caller already knows (annotation "area", the statistics of
                                  a preceding filter): the size-balanced launch order then needs no estimate pass over the masks.  A
                                  hint only orders the work - wrong values cost speed, never correctness. */
+  /* --- ABI 2: per-call scheduling overrides (speed only, never records; 0 = the library's choice) --- */
+  int32_t opt_engine;         /* LA3D_ENGINE_* */
+  int32_t opt_launch_order;   /* LA3D_ORDER_* */
+  int32_t opt_build;          /* LA3D_BUILD_* */
+  int32_t opt_reserved;       /* must be 0 */
 } la3d_fit_args;
 int la3d_fit_instances_ex(const la3d_fit_args* args);
 

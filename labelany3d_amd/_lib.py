@@ -27,15 +27,14 @@ class FitArgs(C.Structure):
                 ("proj", C.c_void_p), ("image_width", C.c_double), ("image_height", C.c_double),
                 ("out", C.c_void_p), ("status", C.c_void_p), ("aux", C.c_void_p),
                 ("workspace", C.c_void_p), ("stream", C.c_void_p),
-                ("area_hint", C.c_void_p)]
+                ("area_hint", C.c_void_p),
+                ("opt_engine", C.c_int32), ("opt_launch_order", C.c_int32), ("opt_build", C.c_int32), ("opt_reserved", C.c_int32)]
 
 
 _SIGS = {
     "la3d_fit_instances_ex": (C.c_int, [C.POINTER(FitArgs)]),
     "la3d_version": (C.c_int, []),
     "la3d_last_error": (C.c_char_p, []),
-    "la3d_set_launch_order": (C.c_int, [C.c_int]),
-    "la3d_get_launch_order": (C.c_int, []),
     "la3d_unproject": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_int,
                                  C.c_void_p, C.c_int, C.c_void_p]),
     "la3d_unproject_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int,

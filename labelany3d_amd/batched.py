@@ -16,8 +16,8 @@ from typing import Optional
 import numpy as np
 import torch
 
-from . import _lib
-from ._lib import AUX, NSAMPLE, REC, check, lib
+from . import _lib, options
+from ._lib import AUX, NSAMPLE, REC, FitArgs, check, lib
 
 
 def _dev(device=None) -> torch.device:
@@ -136,15 +136,6 @@ def _record(stream, *tensors):
             t.record_stream(stream)
 
 
-def set_launch_order(mode):
-    """Size-balanced launch order of the batched fit (see include/la3d.h): ``True`` / ``False`` / ``None`` (= default: on).
-    Turn it off when independent batches are pipelined on several streams.  Returns the previous setting (same encoding), so a
-    scoped user can put it back."""
-    prev = int(lib.la3d_get_launch_order())
-    check(lib.la3d_set_launch_order(-1 if mode is None else int(bool(mode))), "la3d_set_launch_order")
-    return None if prev < 0 else bool(prev)
-
-
 def unpack_boxes(rec):
     """(B,39) record -> dict of center_cam (B,3), dimensions (B,3) = [dz,dy,dx], R_cam (B,3,3),
     bbox3D_cam (B,8,3): the four return values of the reference's estimate_bbox and the keys of its
@@ -200,12 +191,27 @@ class InstanceFitter:
         self.workspace = self._arena[o_ws:].view(ws_slots, wsz)
 
     def run(self, depth: torch.Tensor, masks: torch.Tensor, K: torch.Tensor, ground=None, sample_idx=None,
-            image_index=None, slot: int = 0, stream=None, ws_slot: int = 0):
-        """All arguments already on the device with the ABI's dtypes (f32 / u8 / f64 / f64 / i32 / i32)."""
+            image_index=None, slot: int = 0, stream=None, ws_slot: int = 0, engine=None, launch_order=None, build=None,
+            area_hint=None):
+        """All arguments already on the device with the ABI's dtypes (f32 / u8 / f64 / f64 / i32 / i32).
+        ``engine`` / ``launch_order`` / ``build``: scheduling of THIS call (labelany3d_amd.options; speed only)."""
         B, H, W = self.B, self.H, self.W
         planes = depth.shape[0] if depth.dim() == 3 else 1
         dstride = H * W if planes > 1 else 0
         kstride = 9 if (K.dim() == 3 and K.shape[0] > 1) else 0
+        oe, oo, ob = options.codes(engine, launch_order, build)
+        if oe or oo or ob or area_hint is not None:   # per-call options travel in the argument block
+            a = FitArgs()
+            a.struct_size = C.sizeof(FitArgs)
+            a.B, a.H, a.W = B, H, W
+            a.depth, a.depth_plane_stride, a.image_index = _ptr(depth), dstride, _ptr(image_index)
+            a.mask, a.K, a.k_stride = _ptr(masks), _ptr(K), kstride
+            a.ground, a.sample_idx, a.area_hint = _ptr(ground), _ptr(sample_idx), _ptr(area_hint)
+            a.out, a.status, a.aux = _ptr(self.boxes[slot]), _ptr(self.status[slot]), _ptr(self.aux[slot])
+            a.workspace, a.stream = _ptr(self.workspace[ws_slot]), _stream(stream, raw=True)
+            a.opt_engine, a.opt_launch_order, a.opt_build = oe, oo, ob
+            check(lib.la3d_fit_instances_ex(C.byref(a)), "la3d_fit_instances_ex")
+            return self.boxes[slot], self.status[slot], self.aux[slot]
         rc = lib.la3d_fit_instances(_ptr(depth), dstride, _ptr(image_index), _ptr(masks), _ptr(K), kstride,
                                     _ptr(ground), _ptr(sample_idx), B, H, W, _ptr(self.boxes[slot]),
                                     _ptr(self.status[slot]), _ptr(self.aux[slot]), _ptr(self.workspace[ws_slot]),

@@ -34,6 +34,34 @@
 
 namespace la3d {
 thread_local char g_err[256] = "";
+// the ONE place that reads the environment: a function-local static, initialised once (thread-safe since C++11)
+const Config& config() {
+  static const Config c = [] {
+    Config k;
+    const char* e = getenv("LA3D_ENGINE");
+    k.engine = (e && !strcmp(e, "instance")) ? LA3D_ENGINE_INSTANCE : ((e && !strcmp(e, "split")) ? LA3D_ENGINE_SPLIT : LA3D_ENGINE_DEFAULT);
+    e = getenv("LA3D_BALANCE");
+    k.balance = !(e && e[0] == '0');
+    e = getenv("LA3D_BALANCE_ROUNDS");
+    k.balance_rounds = (e && atoi(e) > 0) ? atoi(e) : 3;
+    e = getenv("LA3D_RETAIN");
+    k.retain = e ? (atoi(e) > 0 ? LA3D_BUILD_RETAINING : LA3D_BUILD_PLAIN) : LA3D_BUILD_DEFAULT;
+    e = getenv("LA3D_RETAIN_MAXB");
+    k.retain_maxb = e ? atoi(e) : -1;
+    e = getenv("LA3D_RETAIN_NOMASK");
+    k.retain_nomask = (e && e[0] == '1') ? 1 : 0;
+    e = getenv("LA3D_LDSKEEP");
+    k.ldskeep = !(e && e[0] == '0');
+    e = getenv("LA3D_STAGGER_US");
+    k.stagger_us = e ? atof(e) : -1.0;
+    e = getenv("LA3D_SPLIT_GRID");
+    k.split_grid = (e && atoi(e) > 0) ? atoi(e) : 0;
+    e = getenv("LA3D_SPLIT_SUB");
+    k.split_sub = (e && atoi(e) > 0) ? atoi(e) : 0;
+    return k;
+  }();
+  return c;
+}
 // split engine (la3d_split.hip)
 bool split_eligible(const FitParams& p, bool vec, bool ldsmask);
 int split_fit(const FitParams& p, void* workspace, hipStream_t s);
@@ -150,6 +178,9 @@ constexpr int TG = LA3D_TG;
 #ifndef LA3D_LDSKEEP0
 #define LA3D_LDSKEEP0 1
 #endif
+#ifndef LA3D_CULL
+#define LA3D_CULL 1      // pass-B tile culling (plain build; see cull_plan)
+#endif
 
 // Depth tiles kept on chip between the two passes (RET > 0: the "retaining" build of the kernel, 128 VGPRs, two workgroups
 // per CU).  The first RET steps of every wave (RET x TG tiles, i.e. RET x TG x NWAVE tiles per instance) keep their depth
@@ -167,12 +198,22 @@ struct TileCtx {
   // region, and the depth quads of list entries < keepn stay in the LDS that frees (1 KiB per tile) between the passes
   int compact, keepn;
   uint4* keep;
+  // pass-B tile culling (plain build): pass A leaves the [min, max] of the valid depths of list entry e in rng[2e], rng[2e + 1]
+  // (bit patterns: see tile_range); pass B then walks only the survivors, surv[j] = list entry
+  unsigned* rng;
+  const unsigned short* surv;
   double a00, a01, a02, a10, a11, a12, a20, a21, a22;
 };
 
 // list entry j of this walk -> tile coordinates (wave-uniform, in SGPRs)
+template <bool SURV = false>
 __device__ inline void tile_coords(const TileCtx& c, const unsigned short* list, bool dense, int j, int rev_base, int* tx, int* ty) {
-  if (dense) { *ty = j / c.ntx; *tx = j - *ty * c.ntx; }
+  if (SURV) {
+    const int e = __builtin_amdgcn_readfirstlane((int)c.surv[j]);
+    const unsigned t = __builtin_amdgcn_readfirstlane((unsigned)list[e]);
+    *tx = (int)(t & 0xffu); *ty = (int)(t >> 8);
+  }
+  else if (dense) { *ty = j / c.ntx; *tx = j - *ty * c.ntx; }
   else {
     // rev_base >= 0: pass B walks the not-retained part of the list backwards - the tiles pass A read last are re-read
     // first (L2 reuse; extents are order independent)
@@ -183,7 +224,7 @@ __device__ inline void tile_coords(const TileCtx& c, const unsigned short* list,
 
 // stage 1 of a step (TG consecutive list entries of one wave): bit-image nibbles, then all depth loads back to back.
 // Returns the TG nibbles packed into one word.
-template <int PASS, bool LK>
+template <int PASS, bool LK, bool SURV = false>
 __device__ inline unsigned tile_fetch(const TileCtx& c, const float* __restrict__ dpl, const unsigned* bits,
                                       const unsigned short* list, int nsteps, bool dense, int j0, int rev_base, uint4* dq) {
   unsigned nib[TG];
@@ -194,9 +235,9 @@ __device__ inline unsigned tile_fetch(const TileCtx& c, const float* __restrict_
     nib[g] = 0; txs[g] = 0; tys[g] = 0; ent[g] = 0x7fffffff;
     dq[g] = make_uint4(0u, 0u, 0u, 0u);
     if (j < nsteps) {
-      tile_coords(c, list, dense, j, rev_base, &txs[g], &tys[g]);
+      tile_coords<SURV>(c, list, dense, j, rev_base, &txs[g], &tys[g]);
       if (LK && c.compact) {   // uniform
-        ent[g] = rev_base >= 0 ? rev_base - j : j;
+        ent[g] = SURV ? __builtin_amdgcn_readfirstlane((int)c.surv[j]) : (rev_base >= 0 ? rev_base - j : j);
         nib[g] = (bits[ent[g] * 8 + c.r] >> (c.cq * 4)) & 0xFu;   // rows past the frame were stored as zeros
       } else {
         const int row = tys[g] * 8 + c.r;
@@ -214,8 +255,35 @@ __device__ inline unsigned tile_fetch(const TileCtx& c, const float* __restrict_
   return pk;
 }
 
+// Depth range of one tile for pass-B culling: [min, max] over the VALID pixels of the wave's tile, as bit patterns.  Non-negative
+// floats order like unsigned integers, so the minimum is an unsigned min over (bits | ~valid) (invalid -> 0xffffffff) and the
+// maximum an unsigned max over (bits & valid) (invalid -> 0).  A negative, infinite or NaN depth makes the maximum >= 0x7f800000,
+// which cull_bound1's caller reads as "unbounded: never cull".  Six DPP steps per value leave the wave's result in lane 63, which stores it.
+constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+template <bool CHK>
+__device__ inline void tile_range(const TileCtx& c, int e, unsigned nib, const unsigned* db) {
+  unsigned lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int m = -(int)((nib >> k) & 1u);
+    if (CHK) m &= ((int)(db[k] & 0x7fffffffu) - 0x7f800000) >> 31;
+    lo = min(lo, db[k] | ~(unsigned)m);
+    hi = max(hi, db[k] & (unsigned)m);
+  }
+  lo = min(lo, (unsigned)dpp_i32<DPP_XOR1>((int)lo)); hi = max(hi, (unsigned)dpp_i32<DPP_XOR1>((int)hi));
+  lo = min(lo, (unsigned)dpp_i32<DPP_XOR2>((int)lo)); hi = max(hi, (unsigned)dpp_i32<DPP_XOR2>((int)hi));
+  lo = min(lo, (unsigned)dpp_i32<DPP_HALF_MIRROR>((int)lo)); hi = max(hi, (unsigned)dpp_i32<DPP_HALF_MIRROR>((int)hi));
+  lo = min(lo, (unsigned)dpp_i32<DPP_MIRROR>((int)lo)); hi = max(hi, (unsigned)dpp_i32<DPP_MIRROR>((int)hi));
+  // rows 1 and 3 take in lane 15 of the row before them, then rows 2 and 3 lane 31: row 3 holds the wave's result
+  lo = min(lo, (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, DPP_ROW_BCAST15, 0xa, 0xf, false));
+  hi = max(hi, (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, DPP_ROW_BCAST15, 0xa, 0xf, false));
+  lo = min(lo, (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, DPP_ROW_BCAST31, 0xc, 0xf, false));
+  hi = max(hi, (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, DPP_ROW_BCAST31, 0xc, 0xf, false));
+  if (c.r * 8 + c.cq == 63) *reinterpret_cast<uint2*>(c.rng + 2 * e) = make_uint2(lo, hi);
+}
+
 // stage 2: the pixel math of a step on quads dq / nibbles pk (all lanes; unmasked lanes carry zeros / NaNs)
-template <int PASS, bool CHK, bool LK = false>
+template <int PASS, bool CHK, bool LK = false, bool SURV = false, bool RNG = false>
 __device__ inline void tile_compute(const TileCtx& c, const unsigned short* list, int nsteps, bool dense, int j0, int rev_base,
                                     const uint4* dq, unsigned pk, double* sv, int* n) {
 #pragma unroll
@@ -226,7 +294,7 @@ __device__ inline void tile_compute(const TileCtx& c, const unsigned short* list
     const unsigned nib = (pk >> (4 * g)) & 0xFu;
     if (dense && __ballot(nib != 0) == 0) continue;
     int tx, ty;
-    tile_coords(c, list, dense, j, rev_base, &tx, &ty);
+    tile_coords<SURV>(c, list, dense, j, rev_base, &tx, &ty);
     const unsigned db[4] = {dq[g].x, dq[g].y, dq[g].z, dq[g].w};
     const double vd = (double)(ty * 8 + c.r), ud = (double)(tx * 32 + c.cq * 4);
     const double r0 = fma(c.a00, ud, fma(c.a01, vd, c.a02));
@@ -234,23 +302,38 @@ __device__ inline void tile_compute(const TileCtx& c, const unsigned short* list
     double r1 = 0;
     if (PASS == 1) r1 = fma(c.a10, ud, fma(c.a11, vd, c.a12));
     quad_math<PASS, CHK>(nib, db, r0, r1, r2, c.a00, c.a10, c.a20, sv, n);
+    if (RNG && PASS == 0) tile_range<CHK>(c, j, nib, db);
   }
 }
 
 constexpr int LDS_KEEP_WAVE = TG * 1024 + 256;   // bytes of the LDS-kept step per wave
 // lds_keep (RET > 0 builds with LDS to spare): one more step per wave kept in LDS (TG x 1 KiB per wave) instead of registers
-template <int PASS, bool CHK, int RET>
+// words of the image region that pass-B culling takes behind the compacted entries: the depth ranges (two words per tile; the
+// survivor list overwrites them later), 16-byte granules, then CULL_SCRATCH_WORDS for the champion search of cull_plan
+// (kept out of `Shared`: every byte there comes off the tile list's capacity, i.e. off the mask size up to which the plain
+// and the retaining build group their partial sums alike)
+constexpr int CULL_SCRATCH_WORDS = NWAVE * 6 * 2;   // per wave and direction: value (f32), list entry (u32)
+__device__ inline int cull_rng_words(int nactive) { return ((2 * nactive + 3) & ~3) + CULL_SCRATCH_WORDS; }
+
+// RNG (pass A, plain build, compact image): also leave every tile's depth range for pass-B culling (rng_words > 0 then).
+// nsurv >= 0 (pass B): walk only the culling survivors surv[0 .. nsurv) (fit_instances_kernel builds the list).
+template <int PASS, bool CHK, int RET, bool RNG = false>
 __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__ dpl, const unsigned* bits,
                                    const unsigned short* list, int nactive, const double* A0, const double* A1,
                                    const double* A2, int wave, int lane, double* acc, int* cnt, Keep<RET>& keep,
-                                   uint4* lds_keep = nullptr, unsigned* qhead = nullptr, int compact = 0) {
+                                   uint4* lds_keep = nullptr, unsigned* qhead = nullptr, int compact = 0, int rng_words = 0,
+                                   int nsurv = -1) {
   constexpr bool LK = LA3D_LDSKEEP0 && RET == 0;
   TileCtx c;
   c.W = p.W; c.H = p.H; c.ntx = p.ntx; c.r = lane >> 3; c.cq = lane & 7;
   c.compact = LK ? compact : 0; c.keepn = 0; c.keep = nullptr;
+  c.rng = nullptr; c.surv = nullptr;
   if (LK && compact) {   // uniform: the image region behind the compacted entries holds depth tiles between the passes
-    c.keepn = (p.mask_lds_bytes - nactive * 32) >> 10;
-    c.keep = const_cast<uint4*>(reinterpret_cast<const uint4*>(bits + nactive * 8));
+    const int k = (p.mask_lds_bytes - nactive * 32 - rng_words * 4) >> 10;
+    c.keepn = k > 0 ? k : 0;
+    c.keep = const_cast<uint4*>(reinterpret_cast<const uint4*>(bits + nactive * 8 + rng_words));
+    c.rng = const_cast<unsigned*>(bits + nactive * 8);
+    c.surv = reinterpret_cast<const unsigned short*>(bits + nactive * 8);   // (the survivors overwrite the ranges)
   }
   c.a00 = A0[0]; c.a01 = A0[1]; c.a02 = A0[2];
   c.a20 = A2[0]; c.a21 = A2[1]; c.a22 = A2[2];
@@ -306,7 +389,18 @@ __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__
     }
   }
   const int rev_base = (PASS == 1 && !dense) ? kept + nsteps - 1 : -1;
-  if (PASS == 1 && qhead != nullptr && !dense) {
+  if (LK && PASS == 1 && nsurv >= 0) {   // uniform: pass B of the plain build - the survivor list through an LDS work queue
+    while (true) {
+      unsigned off = 0;
+      if (lane == 0) off = atomicAdd(qhead, (unsigned)TG);
+      const int j0 = __builtin_amdgcn_readfirstlane((int)off);
+      if (j0 >= nsurv) break;
+      uint4 dq[TG];
+      const unsigned pk = tile_fetch<PASS, LK, true>(c, dpl, bits, list, nsurv, false, j0, -1, dq);
+      tile_compute<PASS, CHK, LK, true>(c, list, nsurv, false, j0, -1, dq, pk, sv, &n);
+    }
+  } else
+  if (!(LA3D_CULL && LK) && PASS == 1 && qhead != nullptr && !dense) {
     // pass B: the not-retained tiles are an LDS WORK QUEUE - a wave that is done pulls the next TG tiles (one ds_add_rtn per
     // step) instead of walking a fixed stride, so no wave waits for a slower neighbour at the end of the pass.  Extents are
     // min / max: exact whatever the order, so the records stay bit-identical (pass A, whose fp64 sums depend on the grouping,
@@ -324,7 +418,7 @@ __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__
     for (int j0 = jstart; j0 < nsteps; j0 += NWAVE * TG) {
       uint4 dq[TG];
       const unsigned pk = tile_fetch<PASS, LK>(c, dpl, bits, list, nsteps, dense, j0, rev_base, dq);
-      tile_compute<PASS, CHK, LK>(c, list, nsteps, dense, j0, rev_base, dq, pk, sv, &n);
+      tile_compute<PASS, CHK, LK, false, RNG && LK>(c, list, nsteps, dense, j0, rev_base, dq, pk, sv, &n);
     }
   }
 #pragma unroll
@@ -531,6 +625,188 @@ __device__ inline int order_select(const FitParams& p, int b, Shared* sh, int wa
   __syncthreads();
   const int inst = __builtin_amdgcn_readfirstlane(sh->order_inst);
   return inst < 0 ? 0 : (inst >= p.B ? p.B - 1 : inst);
+}
+
+// ------------------------------------------------------------------------------------------
+// pass-B tile culling (plain build, round 4).  The six extents are min / max over the points, so a tile that provably cannot
+// move any of them need not be visited - the records stay bit-identical.  Pass A leaves [dlo, dhi], the range of the valid
+// depths of every active tile (tile_range).  A coordinate of the yaw frame is q = d * rho(u, v) with rho affine in the pixel,
+// so over a tile q lies between the extremes of the four products {dlo, dhi} x {rho_min, rho_max} (rho at the tile corners),
+// widened by a slack far above the rounding of the pixel math (2^-40 of the largest product the tile could form; the pixel
+// math differs from the corner evaluation by a few ulp).  Stage 1 picks, per direction, the tile with the most extreme bound
+// (six "champions": where the true extreme most likely sits, interior tiles included - the nearest point of a convex object
+// is not on its silhouette) and runs the exact pixel math on them: their extents E are achieved values.  Stage 2 keeps the
+// tiles whose bounds reach beyond E in some direction (ties cannot change a min / max) and compacts them into the survivor
+// list the work queue of pass B walks.  Config 2 (random depth): 40 % of the active tiles survive (26 % of the large
+// instances', which are the launch's critical path); smooth depth: 15-30 %.
+// ------------------------------------------------------------------------------------------
+#ifndef LA3D_CULL_MIN
+#define LA3D_CULL_MIN 224     // active tiles below which the plan costs more than it saves (measured: profiles/r04/r04_cull.txt)
+#endif
+constexpr int CULL_MIN = LA3D_CULL_MIN;
+constexpr int CULL_MAXT = 2 * NT;   // tiles the plan handles (two per thread)
+
+// bounds L <= q <= U of one yaw-frame coordinate q = d * rho, rho = a[0] u + a[1] v + a[2], over tile (tx, ty) for depths in
+// [dlo, dhi] >= 0 (a negative / infinite / NaN depth makes the tile unbounded).  rho over the tile = centre +- radius; the
+// slack (2^-40 of the largest product the tile could form) is far above the rounding of the pixel math.
+__device__ inline void cull_bound1(double u0, double v0, double dlo, double dhi, bool unbounded, const double* a, double* L, double* U) {
+  const double rc = fma(a[0], u0 + 15.5, fma(a[1], v0 + 3.5, a[2]));
+  const double rad = fabs(a[0]) * 15.5 + fabs(a[1]) * 3.5;
+  const double rmin = rc - rad, rmax = rc + rad;
+  const double slack = dhi * 9.094947017729282e-13 * fma(fabs(a[0]), u0 + 32.0, fma(fabs(a[1]), v0 + 8.0, fabs(a[2])));
+  *L = unbounded ? -INFINITY : fmin(dlo * rmin, dhi * rmin) - slack;
+  *U = unbounded ? INFINITY : fmax(dlo * rmax, dhi * rmax) + slack;
+}
+
+// Every thread of the workgroup calls it (four barriers).  On return ext[] holds the champions' extents (the start values of
+// pass B, the same in every lane) and the survivor list sits in the range area; returns the number of survivors (uniform).
+template <bool CHK>
+__device__ inline int cull_plan(Shared* sh, const FitParams& p, const float* __restrict__ dpl, unsigned* bits,
+                                const unsigned short* list, int nactive, int rng_words, const double* N0, const double* M1,
+                                const double* N2, int tid, int wave, int lane, double* ext) {
+  const unsigned* rng = bits + nactive * 8;
+  unsigned short* surv = reinterpret_cast<unsigned short*>(bits + nactive * 8);
+  float* cval = reinterpret_cast<float*>(bits + nactive * 8 + rng_words - CULL_SCRATCH_WORDS);   // [NWAVE][6]
+  unsigned* cidx = reinterpret_cast<unsigned*>(cval + NWAVE * 6);                                 // [NWAVE][6]
+  // ---- stage 1: champions ----
+  float bv[6];
+  int bi[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { bv[k] = -INFINITY; bi[k] = 0; }
+  for (int t = tid; t < nactive; t += NT) {
+    const unsigned tt = list[t];
+    const uint2 rg = *reinterpret_cast<const uint2*>(rng + 2 * t);
+    const bool unbounded = rg.y >= 0x7f800000u;
+    const double dlo = (double)__uint_as_float(rg.x), dhi = (double)__uint_as_float(rg.y);
+    const double u0 = (double)((tt & 0xffu) * 32u), v0 = (double)((tt >> 8) * 8u);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {   // directions 2k: the minimum (as -L), 2k + 1: the maximum
+      double L, U;
+      cull_bound1(u0, v0, dlo, dhi, unbounded, k == 0 ? N0 : (k == 1 ? M1 : N2), &L, &U);
+      const float a = -(float)L, b = (float)U;
+      if (a > bv[2 * k]) { bv[2 * k] = a; bi[2 * k] = t; }
+      if (b > bv[2 * k + 1]) { bv[2 * k + 1] = b; bi[2 * k + 1] = t; }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    float m = bv[k];
+    m = fmaxf(m, __int_as_float(dpp_i32<DPP_XOR1>(__float_as_int(m))));
+    m = fmaxf(m, __int_as_float(dpp_i32<DPP_XOR2>(__float_as_int(m))));
+    m = fmaxf(m, __int_as_float(dpp_i32<DPP_HALF_MIRROR>(__float_as_int(m))));
+    m = fmaxf(m, __int_as_float(dpp_i32<DPP_MIRROR>(__float_as_int(m))));
+    const float w = fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 0)),
+                                __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 16))),
+                          fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 32)),
+                                __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 48))));
+    const unsigned long long hit = __ballot(bv[k] == w);
+    const int src = hit ? (int)__builtin_ctzll(hit) : 0;
+    const int idx = __builtin_amdgcn_readlane(bi[k], src);
+    if (lane == 0) { cval[wave * 6 + k] = w; cidx[wave * 6 + k] = (unsigned)idx; }
+  }
+  __syncthreads();
+  int champ[6];
+  {
+    float v = -INFINITY;
+    int i = 0;
+    if (lane < 6) {
+#pragma unroll
+      for (int w = 0; w < NWAVE; ++w) {
+        const float cv = cval[w * 6 + lane];
+        if (cv > v) { v = cv; i = (int)cidx[w * 6 + lane]; }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) champ[k] = __builtin_amdgcn_readlane(i, k);
+  }
+  // the exact pixel math on the champions: wave w < 6 takes champion w, all lanes over its pixels
+  TileCtx c;
+  c.W = p.W; c.H = p.H; c.ntx = p.ntx; c.r = lane >> 3; c.cq = lane & 7;
+  c.compact = 1;
+  {
+    const int k = (p.mask_lds_bytes - nactive * 32 - rng_words * 4) >> 10;
+    c.keepn = k > 0 ? k : 0;
+  }
+  c.keep = reinterpret_cast<uint4*>(bits + nactive * 8 + rng_words);
+  c.rng = nullptr; c.surv = nullptr;
+  c.a00 = N0[0]; c.a01 = N0[1]; c.a02 = N0[2];
+  c.a10 = M1[0]; c.a11 = M1[1]; c.a12 = M1[2];
+  c.a20 = N2[0]; c.a21 = N2[1]; c.a22 = N2[2];
+  if (wave < 6) {
+    int e = champ[0];
+#pragma unroll
+    for (int k = 1; k < 6; ++k) e = wave == k ? champ[k] : e;
+    const unsigned tt = __builtin_amdgcn_readfirstlane((unsigned)list[e]);
+    const int tx = (int)(tt & 0xffu), ty = (int)(tt >> 8);
+    const unsigned nib = (bits[e * 8 + c.r] >> (c.cq * 4)) & 0xFu;
+    uint4 dq = make_uint4(0u, 0u, 0u, 0u);
+    if (e < c.keepn) dq = c.keep[e * 64 + lane];
+    else if (nib) dq = *reinterpret_cast<const uint4*>(dpl + (long long)(ty * 8 + c.r) * c.W + tx * 32 + c.cq * 4);
+    const unsigned db[4] = {dq.x, dq.y, dq.z, dq.w};
+    const double vd = (double)(ty * 8 + c.r), ud = (double)(tx * 32 + c.cq * 4);
+    const double r0 = fma(c.a00, ud, fma(c.a01, vd, c.a02));
+    const double r1 = fma(c.a10, ud, fma(c.a11, vd, c.a12));
+    const double r2 = fma(c.a20, ud, fma(c.a21, vd, c.a22));
+    int dummy = 0;
+    double cx[6] = {INFINITY, -INFINITY, INFINITY, -INFINITY, INFINITY, -INFINITY};
+    quad_math<1, CHK>(nib, db, r0, r1, r2, c.a00, c.a10, c.a20, cx, &dummy);
+    const double e0 = wave_min(cx[0]), e1 = wave_max(cx[1]), e2 = wave_min(cx[2]), e3 = wave_max(cx[3]),
+                 e4 = wave_min(cx[4]), e5 = wave_max(cx[5]);
+    if (lane == 0) {
+      double* pp = sh->part[wave];
+      pp[0] = e0; pp[1] = e1; pp[2] = e2; pp[3] = e3; pp[4] = e4; pp[5] = e5;
+    }
+  }
+  __syncthreads();
+  // ---- stage 2: survivors ----
+  // E = the champions' extents (achieved values), combined per wave like stage_extents_to_box does and moved to SGPRs
+  double Elo[3], Ehi[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    double lo = lane < 6 ? sh->part[lane][2 * k] : INFINITY, hi = lane < 6 ? sh->part[lane][2 * k + 1] : -INFINITY;
+    lo = fmin(lo, dpp_f64<DPP_XOR1>(lo)); lo = fmin(lo, dpp_f64<DPP_XOR2>(lo)); lo = fmin(lo, dpp_f64<DPP_HALF_MIRROR>(lo));
+    hi = fmax(hi, dpp_f64<DPP_XOR1>(hi)); hi = fmax(hi, dpp_f64<DPP_XOR2>(hi)); hi = fmax(hi, dpp_f64<DPP_HALF_MIRROR>(hi));
+    Elo[k] = readlane_f64(lo, 0); Ehi[k] = readlane_f64(hi, 0);
+    ext[2 * k] = Elo[k]; ext[2 * k + 1] = Ehi[k];   // every lane starts pass B from the champions' extents
+  }
+  bool sv[2] = {false, false};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int t = tid + h * NT;
+    if (t < nactive) {
+      const unsigned tt = list[t];
+      const uint2 rg = *reinterpret_cast<const uint2*>(rng + 2 * t);
+      const bool unbounded = rg.y >= 0x7f800000u;
+      const double dlo = (double)__uint_as_float(rg.x), dhi = (double)__uint_as_float(rg.y);
+      const double u0 = (double)((tt & 0xffu) * 32u), v0 = (double)((tt >> 8) * 8u);
+      bool inside = true;   // (written so that a NaN bound keeps the tile)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        double L, U;
+        cull_bound1(u0, v0, dlo, dhi, unbounded, k == 0 ? N0 : (k == 1 ? M1 : N2), &L, &U);
+        inside = inside && (L >= Elo[k]) && (U <= Ehi[k]);
+      }
+      bool is_champ = false;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) is_champ = is_champ || (t == champ[k]);
+      sv[h] = !inside && !is_champ && rg.x <= rg.y;   // (rg.x > rg.y: the tile has no valid pixel)
+    }
+  }
+  const unsigned long long b0 = __ballot(sv[0]), b1 = __ballot(sv[1]);
+  if (lane == 0) sh->scan[wave] = (unsigned)(__popcll(b0) + __popcll(b1));
+  __syncthreads();   // (every thread has also read its ranges by now: the survivors may overwrite them)
+  int base = 0, nsurv = 0;
+#pragma unroll
+  for (int w = 0; w < NWAVE; ++w) {
+    const int cw = (int)sh->scan[w];
+    if (w < wave) base += cw;
+    nsurv += cw;
+  }
+  const unsigned long long below = (1ull << lane) - 1ull;
+  if (sv[0]) surv[base + __popcll(b0 & below)] = (unsigned short)tid;
+  if (sv[1]) surv[base + __popcll(b0) + __popcll(b1 & below)] = (unsigned short)(tid + NT);
+  __syncthreads();
+  return nsurv;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -781,7 +1057,8 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
           }
           off += __popcll(bal[k]);
         }
-        if constexpr (LK) if (nactive * 32 <= p.mask_lds_bytes) {   // uniform
+        // (with pass-B culling the compact image also holds the survivor list / the depth ranges behind the entries)
+        if constexpr (LK) if (nactive * 32 + (LA3D_CULL ? cull_rng_words(nactive) * 4 : 0) <= p.mask_lds_bytes) {   // uniform
           // every wave read its row words before the barrier above: the image region can be overwritten in place
           compact = 1;
           off = base;
@@ -827,6 +1104,21 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
       }
     }
     __syncthreads();
+  }
+
+  // pass-B tile culling (see cull_plan): instances with enough active tiles record every tile's depth range in pass A
+  bool cull = false;
+  int rng_words = 0;
+  if constexpr (LA3D_CULL && LK) {
+    // (every compact instance reserves the area: pass B always walks a survivor list - the identity when nothing is culled)
+    if (compact) {   // uniform
+      rng_words = cull_rng_words(nactive);
+      cull = nactive >= CULL_MIN && nactive <= CULL_MAXT;
+      if (!cull) {
+        unsigned short* surv = reinterpret_cast<unsigned short*>(bits + nactive * 8);
+        for (int t = tid; t < nactive; t += NT) surv[t] = (unsigned short)t;   // (visible after the barriers of the axis stage)
+      }
+    }
   }
 
   LA3D_STAMP(2);
@@ -933,7 +1225,8 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
 #ifndef LA3D_ABL_NO_PASSA
   if (!sampled) {
     if (TILED) {
-      sweep_tiled<0, false, RET>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, lds_keep, nullptr, compact);
+      if (LA3D_CULL && LK && cull) sweep_tiled<0, false, RET, true>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, lds_keep, nullptr, compact, rng_words);
+      else sweep_tiled<0, false, RET>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, lds_keep, nullptr, compact, rng_words);
       cnt = nmask;   // the optimistic pass does not count: with every masked depth finite, valid pixels = mask pixels
     }
     else sweep<VEC, LDSMASK, 0>(p, dpl, mpl, bits, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, &nmask);
@@ -950,7 +1243,8 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
     for (int i = 0; i < 5; ++i) acc[i] = 0;
     cnt = 0;
     checked = true;
-    sweep_tiled<0, true, RET>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, lds_keep, nullptr, compact);
+    if (LA3D_CULL && LK && cull) sweep_tiled<0, true, RET, true>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, lds_keep, nullptr, compact, rng_words);
+    else sweep_tiled<0, true, RET>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, lds_keep, nullptr, compact, rng_words);
     stage_moments_to_axis(sh, p, inst_p, acc, cnt, nmask, tid, wave, lane, false);
   }
   LA3D_STAMP(4);
@@ -978,9 +1272,20 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
       // (plain build only: in the retaining build the queue covers just the not-retained remainder and measured 3 us SLOWER at
       // B = 1024; plain build: run-length input 74.8 -> 71.3 us, B = 512 88.7 -> 85.5, config 5 at 16 k 945 -> 927;
       // profiles/r03/r03_pass_b_queue.txt)
-      unsigned* qh = (LA3D_QUEUE && RET == 0) ? &sh->qhead : nullptr;
-      if (checked) sweep_tiled<1, true, RET>(p, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0, keep, lds_keep, qh, compact);
-      else sweep_tiled<1, false, RET>(p, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0, keep, lds_keep, qh, compact);
+      unsigned* qh = ((LA3D_QUEUE || LA3D_CULL) && RET == 0) ? &sh->qhead : nullptr;
+      int nsurv = -1;
+      if constexpr (LA3D_CULL && LK) {
+        if (compact) nsurv = nactive;   // the identity list written before the axis stage
+        if (cull) {   // uniform
+          nsurv = checked ? cull_plan<true>(sh, p, dpl, bits, list, nactive, rng_words, N0, Mg + 3, N2, tid, wave, lane, ext)
+                          : cull_plan<false>(sh, p, dpl, bits, list, nactive, rng_words, N0, Mg + 3, N2, tid, wave, lane, ext);
+        }
+      }
+#ifdef LA3D_CULL_STATS   // measurement build (profiles/r04/cull_stats.py): active tiles / tiles pass B walks, per instance
+      if (tid == 0) { int* cs = reinterpret_cast<int*>(p.geo) + p.B + 2 * inst_p; cs[0] = nactive; cs[1] = cull ? nsurv + 6 : (nsurv >= 0 ? nsurv : nactive); }
+#endif
+      if (checked) sweep_tiled<1, true, RET>(p, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0, keep, lds_keep, qh, compact, rng_words, nsurv);
+      else sweep_tiled<1, false, RET>(p, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0, keep, lds_keep, qh, compact, rng_words, nsurv);
     }
     else sweep<VEC, LDSMASK, 1>(p, dpl, mpl, bits, N0, Mg + 3, N2, wave, lane, ext, &d0, &d1);
 #else
@@ -2450,19 +2755,15 @@ __global__ __launch_bounds__(256) void size_estimate_kernel(const unsigned char*
 std::atomic<const int*> g_debug_perm{nullptr};   // measurement build only: a caller-supplied block -> instance table
 std::atomic<int> g_debug_perm_n{0};
 #endif
-std::atomic<int> g_launch_order{-1};   // la3d_set_launch_order: -1 = default (on, unless LA3D_BALANCE=0), 0 = off, 1 = on
-
-inline bool balance_enabled() {
-  const int m = g_launch_order.load(std::memory_order_relaxed);
-  if (m >= 0) return m != 0;
-  const char* e = getenv("LA3D_BALANCE");  // measurement / test switch: 0 = plain XCD-strided order
-  return !(e && e[0] == '0');
+// size-balanced launch order on for this call?  (per-call opt_order, else the process default)
+inline bool balance_enabled(const FitParams& p) {
+  if (p.opt_order == LA3D_ORDER_OFF) return false;
+  if (p.opt_order == LA3D_ORDER_ON) return true;
+  return config().balance != 0;
 }
 
 inline int balance_max_rounds() {
-  const char* e = getenv("LA3D_BALANCE_ROUNDS");  // measurement switch: batches up to this many resident sets are ordered
-  const int v = e ? atoi(e) : 0;
-  return v > 0 ? v : 3;  // measured: +21 % at one resident set, +9 % at two, +3 % at three, none at four, negative beyond
+  return config().balance_rounds;  // measured: +21 % at one resident set, +9 % at two, +3 % at three, none at four, negative beyond
 }
 
 template <bool VEC, bool LDSMASK, bool SAMPLE, bool TILED, int SRC, int RET = 0>
@@ -2473,7 +2774,7 @@ int launch_fit_inst(const FitParams& p_in, size_t lds, hipStream_t s, void* work
   p.order_nch = 0; p.order_keys = nullptr; p.order_resident = 0; p.order_shift = 0;
   // size-balanced launch order: needs the 16-byte mask groups (VEC), more than one workgroup per CU, and a batch
   // the O(B^2) ranking is cheap for
-  if (workspace && VEC && !SAMPLE && p.B > 256 && p.B <= ORDER_MAX_B && balance_enabled()) {
+  if (workspace && VEC && !SAMPLE && p.B > 256 && p.B <= ORDER_MAX_B && balance_enabled(p)) {
     const int max_rounds = balance_max_rounds();
     int wg_per_cu = (RET > 0 ? 1024 : 2048) / NT;  // wave slots: 32 per CU at 64 VGPRs, 16 at 128 (the retaining build)
     const int by_lds = (int)((160 * 1024) / (lds ? lds : 1));
@@ -2519,20 +2820,22 @@ int launch_fit(const FitParams& p, size_t lds, hipStream_t s, void* workspace = 
 #ifndef LA3D_RET
 #define LA3D_RET 4
 #endif
-inline int retain_steps(int B) {
+constexpr int RETAIN_MAXB_DEFAULT = 1280;
+inline int retain_steps(const FitParams& p) {
   // The 128-VGPR build keeps up to 160 depth tiles per instance on chip between the passes: two
   // workgroups per CU instead of four, the second one of every CU staggered by the time a mask plane takes to stream.
   // Measured (u8 planes, us per call, retaining vs plain build): config-2 masks B = 384 / 512 / 768 / 1024 / 1280: 78 / 82 / 91 /
   // 108 / 128 vs 86 / 91 / 100 / 111 / 131; config-5 masks B = 512 / 768 / 1024 / 1280: 84 / 86 / 90 / 110 vs 95 / 101 / 110 / 116;
-  // beyond ~1.5 k instances the plain build's four workgroups per CU win (10 % at B >= 2048).  LA3D_RETAIN=0 / 1 pins the
+  // beyond ~1.5 k instances the plain build's four workgroups per CU win (10 % at B >= 2048).  opt_build / LA3D_RETAIN pin the
   // choice, LA3D_RETAIN_MAXB moves the threshold.
-  const char* e = getenv("LA3D_RETAIN");
-  if (e) return atoi(e) > 0 ? LA3D_RET : 0;
-  // a caller that has switched the launch order off is pipelining batches on several streams (la3d_set_launch_order): that
-  // regime behaves like one large batch, where the plain build wins (81.6 vs 87.0 us per 1024-instance call)
-  if (!balance_enabled()) return 0;
-  const char* m = getenv("LA3D_RETAIN_MAXB");
-  return B <= (m ? atoi(m) : 1280) ? LA3D_RET : 0;
+  const Config& c = config();
+  const int pin = p.opt_build != LA3D_BUILD_DEFAULT ? p.opt_build : c.retain;
+  if (pin == LA3D_BUILD_PLAIN) return 0;
+  if (pin == LA3D_BUILD_RETAINING) return LA3D_RET;
+  // a caller that has switched the launch order off is pipelining batches on several streams: that regime behaves like one
+  // large batch, where the plain build wins (81.6 vs 87.0 us per 1024-instance call)
+  if (!balance_enabled(p)) return 0;
+  return p.B <= (c.retain_maxb >= 0 ? c.retain_maxb : RETAIN_MAXB_DEFAULT) ? LA3D_RET : 0;
 }
 
 }  // namespace
@@ -2554,17 +2857,6 @@ int la3d_debug_set_block_order(const int32_t* perm_dev, int n) {   // measuremen
   return LA3D_SUCCESS;
 }
 #endif
-
-int la3d_get_launch_order(void) { return g_launch_order.load(std::memory_order_relaxed); }
-
-int la3d_set_launch_order(int mode) {
-  if (mode < -1 || mode > 1) {
-    set_err("la3d_set_launch_order: mode must be -1 (default), 0 (off) or 1 (on)");
-    return LA3D_ERR_ARG;
-  }
-  g_launch_order.store(mode, std::memory_order_relaxed);
-  return LA3D_SUCCESS;
-}
 
 // Workspace layout (one per concurrently running call; contents need not be initialised or preserved):
 //   instance engine: [B] u32 sort keys of the size-balanced launch order (4*B bytes)
@@ -2636,13 +2928,14 @@ int la3d_mask_counts(const uint8_t* mask, int B, int H, int W, int32_t* counts, 
 struct PolyArgs { const int32_t* xy; const int64_t* ring_off; const int64_t* inst_rings; };
 struct FilterArgs { int boundary, min_area, max_edge; int32_t* stats; };
 struct ProjArgs { double* out; double width, height; };
+struct CallOpts { int engine, order, build; };
 
 static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const int32_t* image_index, const uint8_t* mask,
                         const int32_t* rle_counts, const int64_t* rle_offsets, const double* K, int32_t k_stride,
                         const double* ground, const int32_t* sample_idx, int B, int H, int W, double* out,
                         int32_t* status, double* aux, void* workspace, void* stream, const char* who,
                         const PolyArgs* poly = nullptr, const FilterArgs* filter = nullptr, const ProjArgs* proj = nullptr,
-                        const int32_t* area_hint = nullptr) {
+                        const int32_t* area_hint = nullptr, const CallOpts* opts = nullptr) {
   const bool rle = rle_counts != nullptr || poly != nullptr;   // "no u8 plane": the mask is decoded into the LDS bit image
   if (!depth || (!mask && !rle) || (rle_counts && !rle_offsets) || (poly && (!poly->ring_off || !poly->inst_rings)) || !K ||
       !out || !status || B < 0 || H <= 0 || W <= 0 ||
@@ -2676,6 +2969,7 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   p.filter_boundary = -1; p.filter_min_area = 0; p.filter_max_edge = 0; p.filter_stats = nullptr;
   p.proj = proj ? proj->out : nullptr; p.proj_w = proj ? proj->width : 0; p.proj_h = proj ? proj->height : 0;
   p.area_hint = area_hint;
+  p.opt_engine = opts ? opts->engine : 0; p.opt_order = opts ? opts->order : 0; p.opt_build = opts ? opts->build : 0;
   if (filter) {
     if (!rle || filter->boundary < 0) {
       snprintf(g_err, sizeof(g_err), "%s: the fused filter needs run-length or polygon masks and boundary >= 0", who);
@@ -2751,8 +3045,7 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
     // u8 planes only: run-length / polygon input has no mask stream to overlap, and with nothing to stream the plain build's four
     // workgroups per CU hide the passes' latency better (LA3D_RETAIN_NOMASK=1 forces the retaining build for measurements:
     // profiles/r03/r03_rle_poly.txt)
-    const char* rn = getenv("LA3D_RETAIN_NOMASK");
-    const int ret = (mask != nullptr || (rn && rn[0] == '1')) ? retain_steps(p.B) : 0;
+    const int ret = (mask != nullptr || config().retain_nomask || p.opt_build == LA3D_BUILD_RETAINING) ? retain_steps(p) : 0;
     for (int wg_per_cu = ret > 0 ? 2 : 4; wg_per_cu >= 1 && cap < want; --wg_per_cu) {
       const long budget = (160 * 1024 / wg_per_cu) & ~15L;
       cap = (budget - (long)fixed) / 2;
@@ -2764,11 +3057,10 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
         // one more kept step per wave in LDS when two workgroups per CU leave the room (NWAVE x LDS_KEEP_WAVE bytes)
         size_t tot = (fixed + ((size_t)cap * 2 > poly_stage ? (size_t)cap * 2 : poly_stage) + 15) & ~(size_t)15;
         const size_t keep_bytes = (size_t)NWAVE * LDS_KEEP_WAVE;
-        const char* e = getenv("LA3D_LDSKEEP");
-        if (!(e && e[0] == '0') && tot + keep_bytes <= 80 * 1024) { p.lds_keep_off = (int)tot; tot += keep_bytes; }
+        if (config().ldskeep && tot + keep_bytes <= 80 * 1024) { p.lds_keep_off = (int)tot; tot += keep_bytes; }
         if (mask != nullptr && B > 256) {   // u8 planes: 256 workgroups stream 256 x H*W bytes at ~6 TB/s
           double us = 0.9 * 256.0 * (double)p.HW / 6.0e6;
-          if (const char* d = getenv("LA3D_STAGGER_US")) us = atof(d);
+          if (config().stagger_us >= 0) us = config().stagger_us;
           p.stagger_ticks = (int)(us * 100.0);
         }
         return launch_fit<true, true, false, true, LA3D_RET>(p, tot, s, workspace);
@@ -2871,9 +3163,15 @@ int la3d_fit_instances_ex(const la3d_fit_args* args) {
   const bool filter_on = a.filter_boundary >= 0 && a.filter_max_edge > 0;
   const FilterArgs fa{a.filter_boundary, a.filter_min_area, a.filter_max_edge, a.stats};
   const ProjArgs pr{a.proj, a.image_width, a.image_height};
+  if (a.opt_engine < 0 || a.opt_engine > LA3D_ENGINE_SPLIT || a.opt_launch_order < 0 || a.opt_launch_order > LA3D_ORDER_ON ||
+      a.opt_build < 0 || a.opt_build > LA3D_BUILD_RETAINING || a.opt_reserved != 0) {
+    set_err("la3d_fit_instances_ex: bad opt_engine / opt_launch_order / opt_build (or opt_reserved != 0)");
+    return LA3D_ERR_ARG;
+  }
+  const CallOpts co{a.opt_engine, a.opt_launch_order, a.opt_build};
   return fit_dispatch(a.depth, a.depth_plane_stride, a.image_index, a.mask, a.rle_counts, a.rle_offsets, a.K, a.k_stride, a.ground,
                       a.sample_idx, a.B, a.H, a.W, a.out, a.status, a.aux, a.workspace, a.stream, "la3d_fit_instances_ex",
-                      a.poly_xy ? &pa : nullptr, filter_on ? &fa : nullptr, a.proj ? &pr : nullptr, a.area_hint);
+                      a.poly_xy ? &pa : nullptr, filter_on ? &fa : nullptr, a.proj ? &pr : nullptr, a.area_hint, &co);
 }
 
 int la3d_rle_from_string_host(const char* s, int64_t len, int32_t* counts, int cap) {

@@ -26,6 +26,23 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // native vecto
 extern thread_local char g_err[256];
 inline void set_err(const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
 
+// Process defaults of the scheduling decisions, read from the environment ONCE (config(), la3d.hip) and immutable afterwards:
+// the hot path of the C-ABI never calls getenv.  Measurement scripts set the variables before the first call; a caller that
+// wants a different decision for one call uses la3d_fit_args::opt_*.  Speed only - records never depend on any of it.
+struct Config {
+  int engine;          // LA3D_ENGINE=instance|split -> LA3D_ENGINE_*
+  int balance;         // LA3D_BALANCE=0 -> launch order off by default
+  int balance_rounds;  // LA3D_BALANCE_ROUNDS: batches up to this many resident sets are ordered (default 3)
+  int retain;          // LA3D_RETAIN=0|1 -> LA3D_BUILD_PLAIN / LA3D_BUILD_RETAINING (0 = by batch size)
+  int retain_maxb;     // LA3D_RETAIN_MAXB (default RETAIN_MAXB_DEFAULT)
+  int retain_nomask;   // LA3D_RETAIN_NOMASK=1: retaining build for run-length / polygon input too
+  int ldskeep;         // LA3D_LDSKEEP=0: retaining build without its LDS-kept step
+  double stagger_us;   // LA3D_STAGGER_US (< 0: the computed default)
+  int split_grid;      // LA3D_SPLIT_GRID (0: by batch size)
+  int split_sub;       // LA3D_SPLIT_SUB (0: by batch size)
+};
+const Config& config();
+
 // ------------------------------------------------------------------------------------------
 // float64 -> float16 (round to nearest even, overflow to inf, gradual underflow) -> float64.
 // Mirrors numpy's astype(float16) applied to the 8 corners at reference src/util_3dbox.py:165.
@@ -49,33 +66,55 @@ __host__ __device__ inline double f16_round(double x) {
 // small fp64 algebra, done by one thread per box
 // ------------------------------------------------------------------------------------------
 // 3x3 inverse by Gaussian elimination with partial pivoting on [A | I] (np.linalg.inv is LAPACK
-// gesv: same elimination order; reference src/util.py:56).
+// gesv: same elimination order, same pivot rule - the first row of largest magnitude; reference src/util.py:56).
+// Straight-line code (round 4): the pivot row is swapped in with selects and every index is a compile-time constant, so the
+// rows stay in registers - the dynamically indexed form cost plan_kernel and unproject_batch_kernel 160 B of scratch per lane.
 __device__ inline void inv3(const double* A, double* X) {
   double a[3][6];
+#pragma unroll
   for (int i = 0; i < 3; ++i)
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
       a[i][j] = A[i * 3 + j];
       a[i][3 + j] = (i == j) ? 1.0 : 0.0;
     }
-  for (int c = 0; c < 3; ++c) {
-    int piv = c;
-    for (int r = c + 1; r < 3; ++r)
-      if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
-    if (piv != c)
-      for (int j = 0; j < 6; ++j) {
-        double t = a[c][j];
-        a[c][j] = a[piv][j];
-        a[piv][j] = t;
-      }
-    const double inv = 1.0 / a[c][c];
-    for (int r = c + 1; r < 3; ++r) {
-      const double f = a[r][c] * inv;
-      for (int j = c; j < 6; ++j) a[r][j] -= f * a[c][j];
+  {   // column 0: pivot among rows 0, 1, 2 (strict > keeps the first maximum, like idamax)
+    const bool p1 = fabs(a[1][0]) > fabs(a[0][0]);
+    const bool p2 = fabs(a[2][0]) > (p1 ? fabs(a[1][0]) : fabs(a[0][0]));
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const double r0 = a[0][j], r1 = a[1][j], r2 = a[2][j];
+      a[0][j] = p2 ? r2 : (p1 ? r1 : r0);
+      a[1][j] = (p1 && !p2) ? r0 : r1;
+      a[2][j] = p2 ? r0 : r2;
+    }
+    const double inv = 1.0 / a[0][0];
+#pragma unroll
+    for (int r = 1; r < 3; ++r) {
+      const double f = a[r][0] * inv;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) a[r][j] -= f * a[0][j];
     }
   }
+  {   // column 1: pivot among rows 1, 2
+    const bool q = fabs(a[2][1]) > fabs(a[1][1]);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const double r1 = a[1][j], r2 = a[2][j];
+      a[1][j] = q ? r2 : r1;
+      a[2][j] = q ? r1 : r2;
+    }
+    const double inv = 1.0 / a[1][1];
+    const double f = a[2][1] * inv;
+#pragma unroll
+    for (int j = 1; j < 6; ++j) a[2][j] -= f * a[1][j];
+  }
+#pragma unroll
   for (int j = 0; j < 3; ++j) {  // back substitution per right-hand side
+#pragma unroll
     for (int r = 2; r >= 0; --r) {
       double s = a[r][3 + j];
+#pragma unroll
       for (int k = r + 1; k < 3; ++k) s -= a[r][k] * X[k * 3 + j];
       X[r * 3 + j] = s / a[r][r];
     }
@@ -444,6 +483,7 @@ struct FitParams {
   double* proj;
   double proj_w, proj_h;
   const int* area_hint;   // [B] mask areas known to the caller (launch order without the estimate pass), or null
+  int opt_engine, opt_order, opt_build;   // per-call overrides (la3d_fit_args::opt_*; host side only), 0 = the library's choice
   double* out;
   int* status;
   double* aux;

@@ -556,8 +556,7 @@ int walk_waves(int nb) {
   int g = nb * 4;
   if (g < 256) g = 256;
   if (g > 1024) g = 1024;
-  const char* e = getenv("LA3D_SPLIT_GRID");
-  if (e && atoi(e) > 0) g = atoi(e);
+  if (config().split_grid > 0) g = config().split_grid;
   return g * SNW;
 }
 
@@ -631,14 +630,14 @@ bool split_eligible(const FitParams& p, bool vec, bool ldsmask) {
   // 81 vs 40 / 52 / 57 / 58 / 62 / 75 / 72 / 71 / 76; run lengths B = 1 / 16 / 64 / 160 / 256 / 288 / 304: 36 / 40 / 46 / 53 / 59 / 65 / 66 vs
   // 47 / 57 / 59 / 66 / 64 / 66 / 65 (polygons ~1 us below both).  A lone 60-90 k-px instance keeps ONE CU's fp64 VALU busy for ~40 us
   // in the instance engine; the split engine spreads its tiles over the chip at the price of six dependent launches.
-  const char* e = getenv("LA3D_ENGINE");  // experiments only
-  if (e && !strcmp(e, "instance")) return false;
+  const int e = p.opt_engine != LA3D_ENGINE_DEFAULT ? p.opt_engine : config().engine;   // per-call pin, else the process default
+  if (e == LA3D_ENGINE_INSTANCE) return false;
   if (p.mask == nullptr) {   // run lengths / polygon parts (scan_bits_kernel): the bit image must fit the decode workgroup's LDS
     if (p.mask_lds_bytes <= 0 || (size_t)p.mask_lds_bytes + 64 + DEC_SCRATCH_BYTES > 160 * 1024 - 256 || p.filter_boundary >= 0) return false;
-    if (e && !strcmp(e, "split")) return true;
+    if (e == LA3D_ENGINE_SPLIT) return true;
     return p.B <= LA3D_SPLIT_MAXB_NOMASK;
   }
-  if (e && !strcmp(e, "split")) return true;
+  if (e == LA3D_ENGINE_SPLIT) return true;
   return p.B <= 272;
 }
 
@@ -668,8 +667,7 @@ int split_fit(const FitParams& pin, void* workspace, hipStream_t s) {
   int nsub = B / 256;
   if (nsub < 1) nsub = 1;
   if (nsub > 4) nsub = 4;
-  const char* e = getenv("LA3D_SPLIT_SUB");
-  if (e && atoi(e) > 0) nsub = atoi(e);
+  if (config().split_sub > 0) nsub = config().split_sub;
   while ((B + nsub - 1) / nsub * L.nband > MAX_SEG && nsub < MAX_SUB) ++nsub;
   if (nsub > MAX_SUB) nsub = MAX_SUB;
   if ((B + nsub - 1) / nsub * L.nband > MAX_SEG) {

@@ -26,6 +26,7 @@ import ctypes as C
 import numpy as np
 import torch
 
+from . import options
 from ._lib import AUX, REC, check, lib
 from .batched import InstanceFitter, _as_dev, _bulk, _dev, _ptr, _record, _stream, _upload_many
 
@@ -271,6 +272,7 @@ def fit_instances_ex(depth, K, masks=None, rles=None, polys=None, ground=None, s
             a.area_hint = _ptr(ah); keep.append(ah)
         a.out, a.status, a.aux = _ptr(f.boxes[0]), _ptr(f.status[0]), _ptr(f.aux[0])
         a.workspace, a.stream = _ptr(f.workspace[0]), _stream(stream)
+        a.opt_engine, a.opt_launch_order, a.opt_build = options.codes()
         check(lib.la3d_fit_instances_ex(C.byref(a)), "la3d_fit_instances_ex")
     _record(stream, d, k, ii, g, si, *keep, f.workspace, *out.values())
     return out
@@ -355,6 +357,33 @@ def segmentations_to_masks(segmentations, H: int, W: int, device=None) -> torch.
     return out
 
 
+def _fit_block(f, d, P, ii, k, g, si, B, H, W, stream, filt, stats, opts, rle=None, poly=None):
+    """The argument block of la3d_fit_instances_ex for the run-length / polygon wrappers: used when a scheduling option
+    (labelany3d_amd.options) is active for the call - the plain entry points carry none."""
+    import ctypes as C
+
+    from ._lib import FitArgs
+
+    a = FitArgs()
+    a.struct_size = C.sizeof(FitArgs)
+    a.B, a.H, a.W = B, H, W
+    a.depth, a.depth_plane_stride, a.image_index = _ptr(d), (H * W if P > 1 else 0), _ptr(ii)
+    if rle is not None:
+        a.rle_counts, a.rle_offsets = _ptr(rle[0]), _ptr(rle[1])
+    else:
+        a.poly_xy, a.ring_offsets, a.inst_rings = _ptr(poly[0]), _ptr(poly[1]), _ptr(poly[2])
+    a.K, a.k_stride = _ptr(k), (9 if k.shape[0] > 1 else 0)
+    a.ground, a.sample_idx = _ptr(g), _ptr(si)
+    a.filter_boundary = -1
+    if filt is not None:
+        a.filter_boundary, a.filter_min_area, a.filter_max_edge = filt
+        a.stats = _ptr(stats)
+    a.out, a.status, a.aux = _ptr(f.boxes[0]), _ptr(f.status[0]), _ptr(f.aux[0])
+    a.workspace, a.stream = _ptr(f.workspace[0]), _stream(stream)
+    a.opt_engine, a.opt_launch_order, a.opt_build = opts
+    return lib.la3d_fit_instances_ex(C.byref(a))
+
+
 def _filter_args(filter):
     """``filter`` of fit_instances_rle / fit_instances_poly: True or a dict with the reference's three thresholds
     (src/util.py:291-326, :375): boundary strip width (10), minimum area (100), boundary pixels that make a mask "truncated" (10)."""
@@ -387,7 +416,10 @@ def fit_instances_poly(depth, polys, K, ground=None, sample_idx=None, image_inde
             stats = torch.zeros((B, 4), dtype=torch.int32, device=dev)
         if B == 0:
             return (f.boxes[0], f.status[0], f.aux[0]) + ((stats,) if filter else ())
-        if filter:
+        opts = options.codes()
+        if any(opts):
+            rc = _fit_block(f, d, P, ii, k, g, si, B, H, W, stream, _filter_args(filter) if filter else None, stats, opts, poly=(xy, ro, ir))
+        elif filter:
             b, a, e = _filter_args(filter)
             rc = lib.la3d_fit_instances_poly_filtered(_ptr(d), H * W if P > 1 else 0, _ptr(ii), _ptr(xy), _ptr(ro), _ptr(ir), _ptr(k),
                                                       9 if k.shape[0] > 1 else 0, _ptr(g), _ptr(si), B, H, W, b, a, e,
@@ -441,7 +473,10 @@ def fit_instances_rle(depth, rles, K, ground=None, sample_idx=None, image_index=
             stats = torch.zeros((B, 4), dtype=torch.int32, device=dev)
         if B == 0:
             return (f.boxes[0], f.status[0], f.aux[0]) + ((stats,) if filter else ())
-        if filter:
+        opts = options.codes()
+        if any(opts):
+            rc = _fit_block(f, d, P, ii, k, g, si, B, H, W, stream, _filter_args(filter) if filter else None, stats, opts, rle=(c, o))
+        elif filter:
             b, a, e = _filter_args(filter)
             rc = lib.la3d_fit_instances_rle_filtered(_ptr(d), H * W if P > 1 else 0, _ptr(ii), _ptr(c), _ptr(o), _ptr(k),
                                                      9 if k.shape[0] > 1 else 0, _ptr(g), _ptr(si), B, H, W, b, a, e, _ptr(f.boxes[0]),

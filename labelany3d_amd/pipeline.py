@@ -1,5 +1,5 @@
 """Pipelined issue of independent batches: batch k+1 is enqueued on a second HIP stream while batch k
-runs, the size-balanced launch order is switched off for the duration (it assumes an idle chip), and the results come back
+runs, the size-balanced launch order is switched off for these calls (it assumes an idle chip), and the results come back
 in order.  On an MI355X this turns 110 us per 1024-instance call into 81-92 us.
 
     for boxes, status, aux in fit_batches(batches):        # batches: iterable of dicts / tuples for InstanceFitter.run
@@ -14,7 +14,7 @@ from typing import Iterable, Iterator, Tuple
 
 import torch
 
-from .batched import InstanceFitter, set_launch_order
+from .batched import InstanceFitter
 
 
 def fit_batches(batches: Iterable, streams: int = 2, copy: bool = True) -> Iterator[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
@@ -29,40 +29,36 @@ def fit_batches(batches: Iterable, streams: int = 2, copy: bool = True) -> Itera
     ``copy=True`` (default) hands out clones: results stay valid for as long as the caller keeps them (``list(fit_batches(..))``
     is safe).  ``copy=False`` hands out views of internal buffers (``streams + 1`` rotating sets per batch shape): a result is
     overwritten once the generator has been advanced TWICE more - use it before asking for the result after next.
-    The process-wide launch-order setting is saved and put back at the end."""
+    The size-balanced launch order is switched off PER CALL (``la3d_fit_args::opt_launch_order``): no process state is touched."""
     dev = None
     pool, fitters = [], {}
     pending = []          # (event, result) in issue order
     nbuf = max(1, streams) + 1
-    prev_order = set_launch_order(False)
-    try:
-        for k, b in enumerate(batches):
-            kw = dict(b) if isinstance(b, dict) else dict(zip(("depth", "masks", "K"), b))
-            masks = kw["masks"]
-            if masks.dtype == torch.bool:
-                kw["masks"] = masks.view(torch.uint8)
-            if dev is None:
-                dev = masks.device
-                pool = [torch.cuda.Stream(device=dev) for _ in range(max(1, streams))]
-            st = pool[k % len(pool)]
-            st.wait_stream(torch.cuda.current_stream(dev))   # this batch's tensors were produced on the stream current NOW
-            for t in kw.values():
-                if isinstance(t, torch.Tensor) and t.is_cuda:
-                    t.record_stream(st)
-            B, H, W = kw["masks"].shape
-            key = (B, H, W, k % nbuf)
-            if key not in fitters:
-                fitters[key] = InstanceFitter(B, H, W, dev)
-            while len(pending) >= len(pool):    # keep at most `streams` batches in flight: hand out the oldest result
-                ev, res = pending.pop(0)
-                ev.synchronize()
-                yield tuple(t.clone() for t in res) if copy else res
-            res = fitters[key].run(stream=st, **kw)
-            ev = torch.cuda.Event()
-            ev.record(st)
-            pending.append((ev, res))
-        for ev, res in pending:
+    for k, b in enumerate(batches):
+        kw = dict(b) if isinstance(b, dict) else dict(zip(("depth", "masks", "K"), b))
+        masks = kw["masks"]
+        if masks.dtype == torch.bool:
+            kw["masks"] = masks.view(torch.uint8)
+        if dev is None:
+            dev = masks.device
+            pool = [torch.cuda.Stream(device=dev) for _ in range(max(1, streams))]
+        st = pool[k % len(pool)]
+        st.wait_stream(torch.cuda.current_stream(dev))   # this batch's tensors were produced on the stream current NOW
+        for t in kw.values():
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(st)
+        B, H, W = kw["masks"].shape
+        key = (B, H, W, k % nbuf)
+        if key not in fitters:
+            fitters[key] = InstanceFitter(B, H, W, dev)
+        while len(pending) >= len(pool):    # keep at most `streams` batches in flight: hand out the oldest result
+            ev, res = pending.pop(0)
             ev.synchronize()
             yield tuple(t.clone() for t in res) if copy else res
-    finally:
-        set_launch_order(prev_order)
+        res = fitters[key].run(stream=st, launch_order=False, **kw)
+        ev = torch.cuda.Event()
+        ev.record(st)
+        pending.append((ev, res))
+    for ev, res in pending:
+        ev.synchronize()
+        yield tuple(t.clone() for t in res) if copy else res

@@ -21,3 +21,11 @@ def golden():
         return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
     return load
+
+
+def SCHED():
+    """The per-thread scheduling options of the batched fit (labelany3d_amd.options.sched): tests pin an engine / launch order /
+    kernel build through it (round 4: the library reads the LA3D_* environment once, so per-test switches are per-call options)."""
+    from labelany3d_amd.options import sched
+
+    return sched

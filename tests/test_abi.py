@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(_lib.lib, name), f"{name} declared in la3d.h but not exported by libla3d.so"
     assert sorted(_lib.EXPORTS) == declared
-    assert _lib.lib.la3d_version() == 1
+    assert _lib.lib.la3d_version() == 2   # ABI 2 (round 4): per-call opt_* fields, no process-wide launch-order switch
     assert _lib.lib.la3d_workspace_bytes(1024, 480, 640) >= 1024 * 160  # >= per-instance geometry; + split-engine buffers
     assert _lib.lib.la3d_workspace_bytes(1024, 37, 53) == 1024 * 160  # frames the split engine does not take
     assert _lib.lib.la3d_workspace_bytes(0, 480, 640) == 0
@@ -250,3 +250,73 @@ def test_upload_many_packs_host_arrays_into_one_buffer():
     assert a.untyped_storage().data_ptr() == d.untyped_storage().data_ptr()
     one = _bulk(cpu, (xy, torch.int32), (None, torch.int64))
     assert one[0] is xy and one[1] is None                                                      # a single host array is left to _as_dev
+
+
+@pytest.mark.gpu
+def test_scheduling_is_per_call_not_process_state():
+    """SURVEY 8b 're-entrant ... no global state': two threads issue fits with DIFFERENT per-call scheduling (launch order on / off,
+    plain / retaining build of the instance kernel) at the same time, each on its own stream and workspace; both get the records
+    a lone default call gets, bit for bit.  (ABI 1 had a process-wide la3d_set_launch_order; ABI 2 carries the choice in
+    la3d_fit_args::opt_*.)"""
+    import threading
+
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import bench
+    from labelany3d_amd import InstanceFitter, scheduling
+
+    dev = torch.device("cuda", 0)
+    B = 600
+    depth, masks, K, _, _ = bench.make_inputs(B, dev, 77)
+    ref_f = InstanceFitter(B, bench.H, bench.W, dev)
+    with scheduling(engine="instance"):
+        want = tuple(t.clone() for t in ref_f.run(depth, masks, K))
+    torch.cuda.synchronize()
+    results, errors = {}, []
+
+    def worker(name, order, build):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            f = InstanceFitter(B, bench.H, bench.W, dev)
+            st.wait_stream(torch.cuda.current_stream(dev))
+            with scheduling(engine="instance", launch_order=order, build=build):   # thread-local
+                for _ in range(20):
+                    out = f.run(depth, masks, K, stream=st)
+            st.synchronize()
+            results[name] = tuple(t.clone() for t in out)
+        except Exception as e:  # noqa: BLE001
+            errors.append((name, e))
+
+    ths = [threading.Thread(target=worker, args=("a", True, "retaining")), threading.Thread(target=worker, args=("b", False, "plain"))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+    for name in ("a", "b"):
+        for g, w in zip(results[name], want):
+            assert torch.equal(torch.nan_to_num(g.double(), nan=-7.0), torch.nan_to_num(w.double(), nan=-7.0)), name
+
+
+@pytest.mark.gpu
+def test_bad_scheduling_options_are_rejected():
+    import ctypes as C
+
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from labelany3d_amd import _lib, options
+
+    a = _lib.FitArgs()
+    a.struct_size = C.sizeof(_lib.FitArgs)
+    a.B, a.H, a.W = 1, 8, 32
+    a.opt_engine = 7
+    assert _lib.lib.la3d_fit_instances_ex(C.byref(a)) != 0
+    with pytest.raises(ValueError):
+        options.codes(engine="warp")
+    with pytest.raises(ValueError):
+        with options.scheduling(build="huge"):
+            pass

@@ -1,0 +1,139 @@
+"""Pass-B tile culling of the instance engine's plain build (round 4): the extents are min / max
+over the points, so skipping tiles that provably cannot move them must leave the records BIT-identical.  Checked two ways on
+480x640 frames whose masks have enough active tiles for the culling plan to run: against the CPU oracle (the stated 1e-9), and
+bit for bit against the retaining build of the same kernel, which has no culling and walks every tile."""
+import numpy as np
+import pytest
+
+from .conftest import SCHED
+
+from oracle import la3d_oracle as O
+
+from .test_gpu_parity import K640, assert_records, np_
+
+pytestmark = pytest.mark.gpu
+
+H, W = 480, 640
+
+
+@pytest.fixture(scope="module")
+def la():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import labelany3d_amd
+
+    return labelany3d_amd
+
+
+def _shapes(rs, B):
+    """rectangles, ellipses, rings and a mask with a hole band - all large enough for the plan (>= 96 active tiles mostly)"""
+    vv, uu = np.mgrid[0:H, 0:W]
+    masks = np.zeros((B, H, W), bool)
+    for i in range(B):
+        h, w = rs.randint(120, 420), rs.randint(160, 600)
+        r0, c0 = rs.randint(0, H - h + 1), rs.randint(0, W - w + 1)
+        kind = i % 4
+        e = ((vv + 0.5 - r0 - h / 2) / (h / 2)) ** 2 + ((uu + 0.5 - c0 - w / 2) / (w / 2)) ** 2
+        if kind == 0:
+            masks[i, r0:r0 + h, c0:c0 + w] = True
+        elif kind == 1:
+            masks[i] = e <= 1.0
+        elif kind == 2:
+            masks[i] = (e <= 1.0) & (e >= 0.45)
+        else:
+            masks[i, r0:r0 + h, c0:c0 + w] = True
+            masks[i, r0 + h // 3:r0 + h // 2, :] = False
+    return masks
+
+
+def _depths(rs, B, kind):
+    vv, uu = np.mgrid[0:H, 0:W]
+    if kind == "random":
+        return rs.uniform(0.5, 10, (B, H, W)).astype(np.float32)
+    if kind == "sphere":   # nearest point in the interior of the mask
+        d = np.empty((B, H, W), np.float32)
+        for i in range(B):
+            cy, cx = rs.uniform(100, 380), rs.uniform(150, 490)
+            rr = np.clip(1 - ((vv - cy) / 260.0) ** 2 - ((uu - cx) / 340.0) ** 2, 0, 1)
+            d[i] = (6.0 - 2.5 * np.sqrt(rr) + 0.002 * rs.randn(H, W)).astype(np.float32)
+        return d
+    if kind == "plane":
+        return (3.0 + 0.004 * uu[None] + 0.002 * vv[None] + 0.003 * rs.randn(B, H, W)).astype(np.float32)
+    if kind == "constant":
+        return np.full((B, H, W), 2.5, np.float32)
+    if kind == "signed":   # negative and zero depths under the mask: tiles holding them are never culled
+        d = rs.uniform(0.5, 10, (B, H, W)).astype(np.float32)
+        d[:, 100:140, 200:330] *= -1.0
+        d[:, 300:310, :] = 0.0
+        return d
+    if kind == "tiny":     # huge dynamic range: the slack must scale with the tile, not the frame
+        return (10.0 ** rs.uniform(-6, 3, (B, H, W))).astype(np.float32)
+    raise ValueError(kind)
+
+
+def _fit(la, monkeypatch, depth, masks, K, ground, retain):
+    monkeypatch.setattr(SCHED(), "engine", "instance")
+    monkeypatch.setattr(SCHED(), "build", {"0": "plain", "1": "retaining"}[retain])
+    b, s, a = la.fit_instances(depth, masks, K, ground=ground)
+    return np_(b), np_(s), np_(a)
+
+
+@pytest.mark.parametrize("kind", ["random", "sphere", "plane", "constant", "signed", "tiny"])
+def test_culled_pass_b_is_exact(la, monkeypatch, kind):
+    rs = np.random.RandomState({"random": 1, "sphere": 2, "plane": 3, "constant": 4, "signed": 5, "tiny": 6}[kind])
+    B = 12
+    masks = _shapes(rs, B)
+    depth = _depths(rs, B, kind)
+    ground = np.array([[0.05, -0.97, 0.1, 1.2]] * B) + 0.03 * rs.randn(B, 4)
+    ground[::3, 0] = np.nan   # every third instance without a ground plane
+    K = K640 + np.array([[0, 0.7, 0], [0, 0, 0], [0, 0, 0]]) if kind == "plane" else K640
+    got = _fit(la, monkeypatch, depth, masks, K, ground, "0")      # plain build: culling on
+    full = _fit(la, monkeypatch, depth, masks, K, ground, "1")     # retaining build: every tile walked
+    assert (got[1] == full[1]).all()
+    np.testing.assert_array_equal(got[0], full[0], err_msg=f"{kind}: culled pass B changed a record")
+    np.testing.assert_array_equal(got[2], full[2])
+    ground_o = [None if np.isnan(g[0]) else g for g in ground]   # (the batched API reads a NaN first entry as "no ground")
+    ref, rst, _, _ = O.fit_instances(depth, masks, np.broadcast_to(K, (B, 3, 3)), ground=ground_o)
+    assert got[1].tolist() == list(rst)
+    ok = got[1] == 0
+    if kind != "constant":   # (constant depth: exact eigen-ties are the documented don't-care for R_cam)
+        assert_records(got[0][ok], ref[ok], f"cull/{kind}", gap=got[2][ok, 3])
+
+
+def test_culling_with_nonfinite_depth(la, monkeypatch):
+    """inf / NaN under the mask: the optimistic pass A is re-run in its checked form, the depth ranges with it; a tile whose
+    only valid pixels are gone must not poison the bounds."""
+    rs = np.random.RandomState(11)
+    B = 8
+    masks = _shapes(rs, B)
+    depth = rs.uniform(0.5, 10, (B, H, W)).astype(np.float32)
+    depth[0, 200:208, 320:352] = np.inf      # one whole tile without a valid pixel
+    depth[1, 100:300, 100:500:7] = np.nan
+    depth[2, 240, 320] = -np.inf
+    depth[3, :, :] = np.where(rs.rand(H, W) < 0.5, np.nan, depth[3])
+    got = _fit(la, monkeypatch, depth, masks, K640, None, "0")
+    full = _fit(la, monkeypatch, depth, masks, K640, None, "1")
+    np.testing.assert_array_equal(got[0], full[0])
+    ref, rst, _, _ = O.fit_instances(depth, masks, np.broadcast_to(K640, (B, 3, 3)))
+    assert got[1].tolist() == list(rst)
+    assert_records(got[0], ref, "cull/nonfinite", gap=got[2][:, 3])
+
+
+def test_culling_rle_and_polygon_input_match_planes(la, monkeypatch):
+    """run-length and polygon input take the plain build by default: same records as the u8 planes, bit for bit"""
+    from labelany3d_amd.masks import fit_instances_rle
+
+    rs = np.random.RandomState(5)
+    B = 10
+    masks = _shapes(rs, B)
+    depth = _depths(rs, B, "sphere")
+    monkeypatch.setattr(SCHED(), "engine", "instance")
+    monkeypatch.setattr(SCHED(), "build", "plain")
+    b0, s0, _ = la.fit_instances(depth, masks, K640)
+    b1, s1, _ = fit_instances_rle(depth, [O.rle_encode(m) for m in masks], K640)
+    np.testing.assert_array_equal(np_(b0), np_(b1))
+    assert np_(s0).tolist() == np_(s1).tolist()
+    ref, rst, _, _ = O.fit_instances(depth, masks, np.broadcast_to(K640, (B, 3, 3)))
+    assert_records(np_(b1), ref, "cull/rle")

@@ -3,6 +3,8 @@ fed with run lengths — against the oracle and the reference's own encoder / fi
 import numpy as np
 import pytest
 
+from .conftest import SCHED
+
 from oracle import la3d_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -106,11 +108,11 @@ def test_fit_from_rle_equals_fit_from_planes(la):
     np.testing.assert_array_equal(np_(a_r)[:, 2], masks.reshape(B, -1).sum(1))
     # bit-identical to the u8-plane entry point of the same engine
     import os
-    os.environ["LA3D_ENGINE"] = "instance"
+    SCHED().engine = "instance"
     try:
         b_p, s_p, a_p = la.fit_instances(depth, masks, K, ground=ground)
     finally:
-        del os.environ["LA3D_ENGINE"]
+        SCHED().engine = None
     assert np.array_equal(np_(s_p), np_(s_r))
     ok = np_(s_r) == 0      # same kernel after phase 0: equal (to the last bits today; asserted to rounding)
     np.testing.assert_allclose(np_(b_p)[ok][:, :15], got[ok][:, :15], rtol=1e-12, atol=1e-12)
@@ -147,7 +149,7 @@ def test_run_lengths_through_both_engines_ragged_frames(la, monkeypatch):
         ref, rst, _, _ = O.fit_instances(depth[img], masks, K[None].repeat(B, 0), ground=ground)
         got = {}
         for eng in ("split", "instance"):
-            monkeypatch.setenv("LA3D_ENGINE", eng)
+            monkeypatch.setattr(SCHED(), "engine", eng)
             b_r, s_r, a_r = la.fit_instances_rle(depth, rles, K, ground=ground, image_index=img)
             b_p, s_p, a_p = la.fit_instances(depth, masks, K, ground=ground, image_index=img)
             np.testing.assert_array_equal(np_(s_r), rst)
@@ -158,7 +160,7 @@ def test_run_lengths_through_both_engines_ragged_frames(la, monkeypatch):
             scale = np.maximum(1, np.abs(ref[ok][:, :6]).max(1))[:, None]
             assert (np.abs(np_(b_r)[ok][:, :15] - ref[ok][:, :15]) <= 1e-9 * scale).all(), (H, W, eng)
             got[eng] = np_(b_r)
-        monkeypatch.delenv("LA3D_ENGINE")
+        monkeypatch.setattr(SCHED(), "engine", None)
         ok = rst == 0
         np.testing.assert_allclose(got["split"][ok][:, :15], got["instance"][ok][:, :15], rtol=1e-10, atol=1e-11)
 
@@ -188,7 +190,7 @@ def test_run_lengths_and_polygons_large_frames_both_engines(la, monkeypatch, H, 
     ref, rst, _, _ = O.fit_instances(depth, masks, K[None].repeat(B, 0))
     assert (rst == 0).all()
     for eng in ("split", "instance"):
-        monkeypatch.setenv("LA3D_ENGINE", eng)
+        monkeypatch.setattr(SCHED(), "engine", eng)
         b_u, s_u, _ = la.fit_instances(depth, masks, K)
         b_r, s_r, a_r = la.fit_instances_rle(depth, rles, K)
         b_p, s_p, a_p = la.fit_instances_poly(depth, polys, K)
@@ -199,7 +201,7 @@ def test_run_lengths_and_polygons_large_frames_both_engines(la, monkeypatch, H, 
             assert (np.abs(np_(b)[:, :15] - ref[:, :15]) <= 1e-9 * scale).all(), (H, W, eng)
         np.testing.assert_array_equal(np_(a_r)[:, 2], masks.reshape(B, -1).sum(1))
         np.testing.assert_array_equal(np_(a_p)[:, 2], masks.reshape(B, -1).sum(1))
-    monkeypatch.delenv("LA3D_ENGINE")
+    monkeypatch.setattr(SCHED(), "engine", None)
 
 
 def test_box_consumers_vs_reference(la, golden):

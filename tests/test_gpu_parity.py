@@ -16,6 +16,8 @@ import io
 import numpy as np
 import pytest
 
+from .conftest import SCHED
+
 from oracle import la3d_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -237,7 +239,7 @@ def test_g5_composed_path(la, golden):
 def engine(request, monkeypatch):
     """la3d_fit_instances has two engines (one workgroup per instance / band scan + balanced tile walk);
     the library picks by batch size, LA3D_ENGINE pins one.  Parity tests run through both."""
-    monkeypatch.setenv("LA3D_ENGINE", request.param)
+    monkeypatch.setattr(SCHED(), "engine", request.param)
     return request.param
 
 
@@ -630,14 +632,14 @@ def test_config1_single_image_single_instance(la, golden, monkeypatch):
             si = g["sample_idx"][i, j][None] if n > 500 else None
             for eng in (None, "split", "instance"):
                 if eng is None:
-                    monkeypatch.delenv("LA3D_ENGINE", raising=False)
+                    monkeypatch.setattr(SCHED(), "engine", None)
                 else:
-                    monkeypatch.setenv("LA3D_ENGINE", eng)
+                    monkeypatch.setattr(SCHED(), "engine", eng)
                 boxes, status, aux = la.fit_instances(depth[None], masks[i:i + 1], K, ground=None if gr is None else gr[None],
                                                       sample_idx=si)
                 assert np_(status).tolist() == [0] and int(np_(aux)[0, 2]) == n
                 assert_records(np_(boxes), want, f"config1 B=1 engine={eng} mask{i} ground{j}")
-    monkeypatch.delenv("LA3D_ENGINE", raising=False)
+    monkeypatch.setattr(SCHED(), "engine", None)
 
 
 def test_g15_near_tie_sweep_on_gpu(la, golden):
@@ -674,7 +676,7 @@ def test_launch_order_is_invisible(la, B, monkeypatch):
     from labelany3d_amd.masks import fit_instances_rle
     from oracle import la3d_oracle as O2
 
-    monkeypatch.setenv("LA3D_ENGINE", "instance")
+    monkeypatch.setattr(SCHED(), "engine", "instance")
     rs = np.random.RandomState(B)
     H, W = 96, 128
     depth = torch.as_tensor(rs.uniform(0.5, 10, (B, H, W)).astype(np.float32), device="cuda")
@@ -688,7 +690,7 @@ def test_launch_order_is_invisible(la, B, monkeypatch):
     K = np.array([[100.0, 0, 64], [0, 100.0, 48], [0, 0, 1]])
     out = {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("LA3D_BALANCE", flag)
+        monkeypatch.setattr(SCHED(), "launch_order", flag == "1")
         f = InstanceFitter(B, H, W, torch.device("cuda", 0))
         f.workspace.zero_()
         # poison the outputs: the order is decided inside the fit kernel (every workgroup ranks the keys of its chunk, round 3),
@@ -710,7 +712,7 @@ def test_launch_order_is_invisible(la, B, monkeypatch):
     rles = [O2.rle_encode(m[i] != 0) for i in range(B)]
     res = {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("LA3D_BALANCE", flag)
+        monkeypatch.setattr(SCHED(), "launch_order", flag == "1")
         b, s, a = fit_instances_rle(depth, rles, K)
         res[flag] = (b.clone(), s.clone())
     assert torch.equal(torch.nan_to_num(res["0"][0], nan=-7.0), torch.nan_to_num(res["1"][0], nan=-7.0))
@@ -805,7 +807,7 @@ def test_randomized_differential_sweep(la, seed, monkeypatch):
         tag = f"seed{seed}/case{case} {masks.shape}"
         outs = {}
         for eng in ("instance", "split"):
-            monkeypatch.setenv("LA3D_ENGINE", eng)
+            monkeypatch.setattr(SCHED(), "engine", eng)
             b, s, a = la.fit_instances(depth, masks, K, ground=ground)
             assert np_(s).tolist() == rst, f"{tag} {eng} status"
             ok = np_(s) == 0
@@ -813,7 +815,7 @@ def test_randomized_differential_sweep(la, seed, monkeypatch):
             assert np.isnan(np_(b)[~ok]).all()
             np.testing.assert_array_equal(np_(a)[ok, 1], np.array([r[2]["n_valid"] for r in ref])[ok])  # (the oracle reports 0 for rejects)
             outs[eng] = np_(b)
-        monkeypatch.setenv("LA3D_ENGINE", "instance")
+        monkeypatch.setattr(SCHED(), "engine", "instance")
         b, s, a = fit_instances_rle(depth, [O.rle_encode(m) for m in masks], K, ground=ground)
         assert np_(s).tolist() == rst, f"{tag} rle status"
         np.testing.assert_allclose(np.nan_to_num(np_(b), nan=-7.0), np.nan_to_num(outs["instance"], nan=-7.0), rtol=1e-12, atol=1e-12,

@@ -7,6 +7,8 @@ rasteriser must agree with that restatement bit for bit on every polygon below."
 import numpy as np
 import pytest
 
+from .conftest import SCHED
+
 from oracle import la3d_oracle as O
 from oracle import poly_oracle as P
 
@@ -29,7 +31,7 @@ def np_(t):
 
 
 class _engine:
-    """Pin one engine for the calls inside (LA3D_ENGINE): up to 288 instances of polygon / run-length input and up to 272 of u8 planes
+    """Pin one engine for the calls inside (labelany3d_amd.options): up to 288 instances of polygon / run-length input and up to 272 of u8 planes
     take the split engine, whose partial sums are grouped differently from the instance engine's - comparisons "bit for bit" are
     between calls of the SAME engine."""
 
@@ -37,16 +39,11 @@ class _engine:
         self.name = name
 
     def __enter__(self):
-        import os
-        self.prev = os.environ.get("LA3D_ENGINE")
-        os.environ["LA3D_ENGINE"] = self.name
+        self.prev = SCHED().engine
+        SCHED().engine = self.name
 
     def __exit__(self, *a):
-        import os
-        if self.prev is None:
-            del os.environ["LA3D_ENGINE"]
-        else:
-            os.environ["LA3D_ENGINE"] = self.prev
+        SCHED().engine = self.prev
 
 
 _instance_engine = _engine
@@ -263,10 +260,10 @@ def test_the_reference_converters_own_polygons(la, monkeypatch):
         # polygon input takes the plain build; pin it for the planes too: the 107 k-px blob has more active tiles (> 912) than the
         # plain build's list holds and is walked densely there, which groups the partial sums differently from the retaining
         # build's longer list (last-ulp differences; checked to rounding below)
-        monkeypatch.setenv("LA3D_RETAIN", "0")
+        monkeypatch.setattr(SCHED(), "build", "plain")
         with _instance_engine():
             b2, s2, a2 = la.fit_instances(depth, np.stack(want), K)
-        monkeypatch.delenv("LA3D_RETAIN")
+        monkeypatch.setattr(SCHED(), "build", None)
         with _instance_engine():
             b3, s3, _ = la.fit_instances(depth, np.stack(want), K)
         np.testing.assert_array_equal(np_(s1), np_(s2))
@@ -400,13 +397,13 @@ def test_fit_instances_ex_projection_in_the_epilogue(la, monkeypatch):
         bad = np_(res["status"]) != 0
         assert bad.any() and np.isnan(np_(res["boxes2d"])[bad]).all() and np.isfinite(np_(res["boxes2d"])[~bad]).all()
 
-    monkeypatch.setenv("LA3D_ENGINE", "instance")
+    monkeypatch.setattr(SCHED(), "engine", "instance")
     b0, s0, _ = la.fit_instances(depth, masks, Ks, ground=ground, image_index=img)
     check(la.fit_instances_ex(depth, Ks, masks=masks, ground=ground, image_index=img, image_size=size), b0, s0)
-    monkeypatch.setenv("LA3D_ENGINE", "split")
+    monkeypatch.setattr(SCHED(), "engine", "split")
     b1, s1, _ = la.fit_instances(depth, masks, Ks, ground=ground, image_index=img)
     check(la.fit_instances_ex(depth, Ks, masks=masks, ground=ground, image_index=img, image_size=size), b1, s1)
-    monkeypatch.delenv("LA3D_ENGINE")
+    monkeypatch.setattr(SCHED(), "engine", None)
     rles = [O.rle_encode(m) for m in masks]
     b2, s2, _ = la.fit_instances_rle(depth, rles, Ks, ground=ground, image_index=img)
     check(la.fit_instances_ex(depth, Ks, rles=rles, ground=ground, image_index=img, image_size=size), b2, s2)
@@ -471,7 +468,7 @@ def test_area_hint_orders_the_launch_without_the_estimate_pass(la, monkeypatch):
     import bench
 
     dev = torch.device("cuda", 0)
-    monkeypatch.setenv("LA3D_ENGINE", "instance")
+    monkeypatch.setattr(SCHED(), "engine", "instance")
     B = 1024
     depth, masks, K, _, rects = bench.make_inputs(B, dev, 3)
     ref = la.fit_instances_ex(depth, K, masks=masks)

@@ -12,6 +12,8 @@ import socket
 import numpy as np
 import pytest
 
+from .conftest import SCHED
+
 from oracle import la3d_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -134,24 +136,24 @@ def test_config5_size_distribution(la, B):
     depth, masks, K, n_masked, _ = bench.make_config5(B, dev, 77)
     area = masks.reshape(B, -1).sum(1, dtype=torch.int64).cpu().numpy()
     assert area.min() >= 4 and area.max() <= 110000 and np.median(area) < 3000     # log-uniform: mostly small, a few huge
-    os.environ["LA3D_ENGINE"] = "instance"
+    SCHED().engine = "instance"
     try:
         b1, s1, a1 = la.fit_instances(depth, masks, K)
-        os.environ["LA3D_BALANCE"] = "0"
+        SCHED().launch_order = False
         b0, s0, _ = la.fit_instances(depth, masks, K)
     finally:
-        os.environ.pop("LA3D_ENGINE", None)
-        os.environ.pop("LA3D_BALANCE", None)
+        SCHED().engine = None
+        SCHED().launch_order = None
     torch.cuda.synchronize()
     assert int((s1 != 0).sum()) == 0
     assert torch.equal(b1, b0) and torch.equal(s1, s0)            # the launch order is invisible in the records
     assert torch.equal(a1[:, 2].long().cpu(), torch.as_tensor(area))  # n_masked
     # split engine on the first 256 (its batch range): same records to rounding
-    os.environ["LA3D_ENGINE"] = "split"
+    SCHED().engine = "split"
     try:
         bs, ss, _ = la.fit_instances(depth[:256], masks[:256], K)
     finally:
-        os.environ.pop("LA3D_ENGINE", None)
+        SCHED().engine = None
     assert int((ss != 0).sum()) == 0
     np.testing.assert_allclose(bs[:, :15].cpu().numpy(), b1[:256, :15].cpu().numpy(), rtol=0, atol=1e-9)
     # oracle on the smallest, the largest and a spread of instances
@@ -174,7 +176,7 @@ def test_pipelined_batches_and_retaining_build_give_the_same_records(la, monkeyp
     import bench
 
     dev = torch.device("cuda", 0)
-    monkeypatch.setenv("LA3D_ENGINE", "instance")
+    monkeypatch.setattr(SCHED(), "engine", "instance")
     batches, want = [], []
     for k in range(5):
         depth, masks, K, _, _ = bench.make_inputs(700 + 100 * k, dev, 40 + k)
@@ -200,7 +202,7 @@ def test_pipelined_batches_and_retaining_build_give_the_same_records(la, monkeyp
         assert la.set_launch_order(prev) is True      # fit_batches put the caller's explicit setting back
     finally:
         la.set_launch_order(prev)
-    monkeypatch.setenv("LA3D_RETAIN", "1")
+    monkeypatch.setattr(SCHED(), "build", "retaining")
     for (depth, masks, K), w in zip(batches[:2], want[:2]):
         b, s, a = la.fit_instances(depth, masks, K)
         assert torch.equal(b, w[0]) and torch.equal(s, w[1]) and torch.equal(a, w[2])
@@ -208,9 +210,9 @@ def test_pipelined_batches_and_retaining_build_give_the_same_records(la, monkeyp
     depth, masks, K, _, _ = bench.make_config5(600, dev, 9)
     depth[3, 200, 300] = float("inf")
     masks[3, 190:260, 280:400] = 1
-    monkeypatch.delenv("LA3D_RETAIN")
+    monkeypatch.setattr(SCHED(), "build", None)
     w = la.fit_instances(depth, masks, K)
-    monkeypatch.setenv("LA3D_RETAIN", "1")
+    monkeypatch.setattr(SCHED(), "build", "retaining")
     g = la.fit_instances(depth, masks, K)
     assert torch.equal(g[0], w[0]) and torch.equal(g[1], w[1])
 
@@ -237,12 +239,12 @@ def test_subsample_mode_on_config5_mix(la):
     counts = la.mask_counts(masks).cpu().numpy()
     assert (counts <= 500).sum() > 200 and (counts > 500).sum() > 200
     idx = la.draw_sample_idx(counts, np.random.RandomState(3))
-    os.environ["LA3D_ENGINE"] = "instance"
+    SCHED().engine = "instance"
     try:
         bs, ss, as_ = la.fit_instances(depth, masks, K, sample_idx=idx)
         bf, sf, af = la.fit_instances(depth, masks, K)
     finally:
-        os.environ.pop("LA3D_ENGINE", None)
+        SCHED().engine = None
     small = torch.as_tensor(counts <= 500, device=dev)
     assert torch.equal(bs[small], bf[small]) and torch.equal(ss[small], sf[small]) and torch.equal(as_[small], af[small])
     assert int((ss != 0).sum()) == 0
