@@ -328,6 +328,189 @@ class StepRunner:
         check(lib.la3d_fit_instances_ex(C.byref(a)), "la3d_fit_instances_ex")
 
 
+# ------------------------------------------------------------------------------------------------------------------------
+# --config4 IMAGES: the north_star partitioning - ONE global metadata list, per-image shards, one gather
+# ------------------------------------------------------------------------------------------------------------------------
+def config4_metadata(P, seed):
+    """What every rank knows about the whole job WITHOUT holding any of its tensors (BASELINE config 4: COCO-train sharded per
+    image): per image ~Poisson(7) instances, per instance an ellipse (centre, half axes) of log-uniform area 400..100k px.
+    Host NumPy, identical on every rank."""
+    rs = np.random.RandomState(seed)
+    per = np.maximum(1, rs.poisson(7, P))
+    img = np.repeat(np.arange(P), per).astype(np.int64)
+    B = len(img)
+    area = np.exp(rs.uniform(np.log(400), np.log(100000), B))
+    asp = np.exp(rs.uniform(-0.7, 0.7, B))
+    hh = np.clip(np.sqrt(area * asp), 8, H)
+    ww = np.clip(area / hh, 8, W)
+    r0 = rs.rand(B) * (H - hh)
+    c0 = rs.rand(B) * (W - ww)
+    return {"img": img, "hh": hh, "ww": ww, "r0": r0, "c0": c0, "area": np.pi / 4 * hh * ww, "P": P, "B": B, "seed": seed}
+
+
+def config4_materialize(meta, shard, device):
+    """ONLY this rank's tensors: the depth planes of images [img_lo, img_hi) - plane i is a function of (seed, i), so any rank
+    would build the same plane - and the u8 masks of instances [inst_lo, inst_hi).  Returns (depth, masks, K, None, None), the
+    load_fn contract of fit_instances_sharded."""
+    ilo, ihi, nlo, nhi = shard
+    depth = torch.empty((max(ihi - ilo, 1), H, W), dtype=torch.float32, device=device)
+    g = torch.Generator(device=device)
+    for i in range(ilo, ihi):
+        g.manual_seed(meta["seed"] * 1000003 + i)
+        depth[i - ilo].uniform_(0.5, 10.0, generator=g)
+    n = nhi - nlo
+    masks = torch.empty((max(n, 1), H, W), dtype=torch.uint8, device=device)
+    rows = torch.arange(H, device=device, dtype=torch.float32).view(1, H, 1)
+    cols = torch.arange(W, device=device, dtype=torch.float32).view(1, 1, W)
+    for a in range(0, n, 1024):
+        sl = slice(nlo + a, min(nhi, nlo + a + 1024))
+        t = lambda key: torch.as_tensor(meta[key][sl], device=device, dtype=torch.float32).view(-1, 1, 1)  # noqa: E731
+        masks[a:a + (sl.stop - sl.start)] = ((((rows - t("r0") - t("hh") / 2) / (t("hh") / 2)) ** 2 +
+                                              ((cols - t("c0") - t("ww") / 2) / (t("ww") / 2)) ** 2) < 1.0).to(torch.uint8)
+    K = torch.tensor(K640, dtype=torch.float64, device=device)
+    return depth[:ihi - ilo], masks[:n], K, None, None
+
+
+def run_config4(args, dist, rank, world, device, red_dev):
+    """bench.py --config4 IMAGES [--gpus N]: every rank derives the SAME plan from the metadata (plan_shards: contiguous image
+    ranges balanced by what the fit moves per image), materialises only its own range, fits it in one call
+    (fit_instances_sharded) and joins the ONE gather of (n_i, 39) records + status.  One step = the whole job; `value` =
+    all instances / max over ranks of (fit + gather) time; per-rank fit times and the gather's time stand beside it."""
+    from labelany3d_amd.shard import fit_instances_sharded, plan_shards
+
+    meta = config4_metadata(args.config4, 1234)
+    P, B = meta["P"], meta["B"]
+    dist_ = dist
+    plan = plan_shards(meta["img"], P, world, areas=meta["area"], frame_pixels=H * W)
+    loaded = {}
+
+    def load_fn(sh):   # materialised once, outside the timed steps (inputs resident in HBM, like the headline)
+        if "t" not in loaded:
+            loaded["t"] = config4_materialize(meta, sh, device)
+        return loaded["t"]
+
+    load_fn(plan[rank])
+    best = None
+    for it in range(args.warmup_jobs + args.jobs):
+        torch.cuda.synchronize()
+        tm = {}
+        if dist_ is None:   # one process: the same plan / load / fit, no collective to run
+            from labelany3d_amd import fit_instances
+            sh = plan[0]
+            d, m, k, _, _ = load_fn(sh)
+            t0 = time.perf_counter()
+            b, st, _ = fit_instances(d, m, k, image_index=(meta["img"][sh.inst_lo:sh.inst_hi] - sh.img_lo).astype(np.int32))
+            torch.cuda.synchronize()
+            tm.update(fit_s=time.perf_counter() - t0, gather_s=0.0)
+            out = (b, st, [B])
+        else:
+            dist_.barrier()
+            t0 = time.perf_counter()
+            out = fit_instances_sharded((P, H, W), None, None, meta["img"], areas=meta["area"], load_fn=load_fn, timings=tm)
+            torch.cuda.synchronize()
+            dist_.barrier()
+        tm["job_s"] = time.perf_counter() - t0
+        if it >= args.warmup_jobs and (best is None or tm["job_s"] < best["job_s"]):
+            best = tm
+            best_out = out
+    vals = torch.tensor([best["fit_s"], best["gather_s"], best["job_s"]], dtype=torch.float64, device=red_dev)
+    allv = [torch.zeros_like(vals) for _ in range(world)]
+    if dist_ is None:
+        allv = [vals]
+    else:
+        dist_.all_gather(allv, vals)
+    if rank == 0:
+        boxes, status, counts = best_out
+        assert boxes.shape == (B, 39) and int((status == 0).sum()) == B, (boxes.shape, int((status != 0).sum()))
+        if args.dump:   # tests: the gathered records in global instance order
+            np.save(args.dump, boxes.cpu().numpy())
+        fit = [float(v[0]) for v in allv]
+        gat = [float(v[1]) for v in allv]
+        job = max(float(v[2]) for v in allv)
+        print(json.dumps({
+            "metric": "fitted 3D boxes/sec @640x480", "value": B / job, "unit": "boxes/s", "n_gpus": world, "steps": args.jobs,
+            "warmup": args.warmup_jobs, "ms_per_step": job * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 4 partitioning: {P} images with a shared 480x640 depth plane each, {B} instances "
+                                   "(~Poisson(7) per image, elliptical u8 masks, log-uniform area 400..100k px), ONE global metadata list, "
+                                   "plan_shards -> every rank materialises and fits only its contiguous image range -> one gather of (n_i,39) records",
+                       "images": P, "instances": B, "instances_per_rank": [p[3] - p[2] for p in plan], "images_per_rank": [p[1] - p[0] for p in plan],
+                       "sharding": "per image, cost-balanced contiguous ranges (reference --start_index/--end_index, whole.py:25-27,42)"},
+            "per_rank_fit_ms": [f * 1e3 for f in fit], "fit_ms_max": max(fit) * 1e3, "fit_ms_min": min(fit) * 1e3,
+            "imbalance_max_over_mean": max(fit) / (sum(fit) / len(fit)), "gather_ms": max(gat) * 1e3,
+            "value_fit_only": B / max(fit),
+            "note": "one step = the whole job (best of --jobs); value = instances / (max over ranks of the wall time between two barriers "
+                    "around fit + gather); inputs resident in HBM before the clock starts; per_rank_fit_ms shows the balance of the plan",
+        }), flush=True)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# --end-to-end: host-resident scenes -> records on the host (labelany3d_amd.fit_scenes.ScenePipeline)
+# ------------------------------------------------------------------------------------------------------------------------
+def pinned_h2d_GBps(device, nbytes=256 << 20):
+    src = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+    dst = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    dst.copy_(src, non_blocking=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(4):
+        dst.copy_(src, non_blocking=True)
+    e1.record()
+    torch.cuda.synchronize()
+    return 4 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def run_end_to_end(args, device):
+    """bench.py --end-to-end IMAGES: what a caller holding HOST data gets (SURVEY section 7 'report end-to-end separately'): scenes
+    as in-memory dicts (pageable float32 depth planes, COCO-style polygon / run-length annotations) through the real-data
+    pipeline - copy into pinned memory, pack the segmentations, upload on a copy stream, decode + filter + fit in one launch per
+    segmentation kind and batch, download the records - to Python-side record lists.  Never the headline: the depth planes
+    alone (1.23 MB per image) bound it by the host link."""
+    from labelany3d_amd.fit_scenes import ScenePipeline, synthetic_scenes
+
+    n = args.end_to_end
+    scenes, data = synthetic_scenes(n, seed=3)
+    link = pinned_h2d_GBps(device)
+    warm = {}
+    list(ScenePipeline(device=device, batch_images=args.batch_images, write=False, timings=warm).run(scenes[:min(n, 2 * args.batch_images)]))
+    best = None
+    for _ in range(3):
+        tm = {}
+        pipe = ScenePipeline(device=device, batch_images=args.batch_images, write=False, timings=tm)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nb = sum(len(recs) for _, recs in pipe.run(scenes))
+        torch.cuda.synchronize()
+        tm["total_s"] = time.perf_counter() - t0
+        tm["boxes"] = nb
+        if best is None or tm["total_s"] < best["total_s"]:
+            best = tm
+    t = best
+    bytes_per_image = t["h2d_bytes"] / t["images"]
+    ceiling_images = link * 1e9 / bytes_per_image
+    print(json.dumps({
+        "metric": "fitted 3D boxes/sec @640x480, host-resident scenes -> records on the host", "value": t["boxes"] / t["total_s"],
+        "unit": "boxes/s", "n_gpus": 1, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{n} scenes (one 480x640 f32 depth plane each, ~7 annotations per image: polygons (24-vertex outlines, some in "
+                               "two parts) and uncompressed COCO run lengths; crowd / tiny / border-touching ones dropped by the reference's "
+                               "keep rule inside the fit launch), batches of {0} images".format(args.batch_images),
+                   "images": int(t["images"]), "annotations_submitted": int(t["instances"]), "boxes_kept": int(t["boxes"]),
+                   "batches": int(t["batches"])},
+        "images_per_s": t["images"] / t["total_s"], "annotations_per_s": t["instances"] / t["total_s"],
+        "split_s": {"copy_to_pinned": t["load_s"], "pack_segmentations": t["pack_s"], "h2d_on_copy_stream": t["h2d_s"],
+                    "fit_and_d2h_on_compute_stream": t["fit_s"], "issue_fit_calls": t.get("fit_issue_s", 0.0), "records_to_python": t["write_s"],
+                    "wall": t["total_s"]},
+        "h2d_bytes": t["h2d_bytes"], "h2d_GBps_achieved_while_copying": t["h2d_bytes"] / t["h2d_s"] / 1e9 if t["h2d_s"] else None,
+        "host_link": {"pinned_h2d_GBps": link, "bytes_per_image": bytes_per_image, "ceiling_images_per_s": ceiling_images,
+                      "ceiling_boxes_per_s": ceiling_images * t["boxes"] / t["images"],
+                      "frac_of_ceiling": (t["images"] / t["total_s"]) / ceiling_images},
+        "note": "stages overlap (loader thread + copy stream run one batch ahead of the fit), so split_s adds up to more than wall; "
+                "copy_to_pinned and pack run on host threads (Python / NumPy); the ceiling is the measured pinned host-to-device rate "
+                "divided by the bytes one image needs on the device",
+    }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -355,6 +538,16 @@ def main():
                          "image with log-uniform mask areas 400..100k px, all instances in ONE call per step")
     ap.add_argument("--config5", action="store_true",
                     help="secondary mode: BASELINE config-5 workload (mask areas log-uniform 8..100k px, private depth)")
+    ap.add_argument("--config4", type=int, default=0, metavar="IMAGES",
+                    help="the north_star partitioning at N ranks: ONE global metadata list of IMAGES shared depth planes (~7 instances each), "
+                         "plan_shards -> every rank materialises and fits only its image range -> one gather (strong scaling; one step = the job)")
+    ap.add_argument("--jobs", type=int, default=3, help="--config4: timed repetitions of the whole job (best is reported)")
+    ap.add_argument("--warmup-jobs", type=int, default=1)
+    ap.add_argument("--dump", default=None, help="--config4: np.save the gathered (B,39) records here (tests)")
+    ap.add_argument("--end-to-end", type=int, default=0, metavar="IMAGES",
+                    help="host-resident scenes -> records on the host through labelany3d_amd.fit_scenes (never the headline): boxes/s with the "
+                         "split pack / H2D / fit / D2H and the host-link ceiling")
+    ap.add_argument("--batch-images", type=int, default=256, help="--end-to-end: images per fit launch")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the independent steps are issued on round-robin (1 = strictly serial steps)")
     args = ap.parse_args()
@@ -385,6 +578,18 @@ def main():
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     device = torch.device("cuda", torch.cuda.current_device())
     red_dev = device if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")   # where the timing scalars are reduced
+
+    if args.config4:
+        run_config4(args, dist, rank, world, device, red_dev)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    if args.end_to_end:
+        if world != 1:
+            raise SystemExit("--end-to-end is a single-GPU measurement")
+        run_end_to_end(args, device)
+        return
 
     from labelany3d_amd import InstanceFitter
     from labelany3d_amd.shard import gather_boxes

@@ -87,6 +87,7 @@ int la3d_mask_counts(const uint8_t* mask, int B, int H, int W, int32_t* counts, 
 #define LA3D_ENGINE_DEFAULT 0
 #define LA3D_ENGINE_INSTANCE 1        /* one workgroup per instance */
 #define LA3D_ENGINE_SPLIT 2           /* band scan + tile-range-balanced passes (falls back to the instance engine where it does not apply) */
+#define LA3D_ENGINE_BAND 3            /* two (or four) workgroups per instance, one per band of tile rows (u8 planes, tiled frames; falls back likewise) */
 #define LA3D_ORDER_DEFAULT 0          /* size-balanced launch order for 256 < B <= 3 resident sets */
 #define LA3D_ORDER_OFF 1              /* a caller pipelining independent batches on several streams wants it off (measured +20 %) */
 #define LA3D_ORDER_ON 2

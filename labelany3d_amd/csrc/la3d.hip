@@ -39,7 +39,14 @@ const Config& config() {
   static const Config c = [] {
     Config k;
     const char* e = getenv("LA3D_ENGINE");
-    k.engine = (e && !strcmp(e, "instance")) ? LA3D_ENGINE_INSTANCE : ((e && !strcmp(e, "split")) ? LA3D_ENGINE_SPLIT : LA3D_ENGINE_DEFAULT);
+    k.engine = (e && !strcmp(e, "instance")) ? LA3D_ENGINE_INSTANCE : (e && !strcmp(e, "split")) ? LA3D_ENGINE_SPLIT
+             : (e && !strcmp(e, "band")) ? LA3D_ENGINE_BAND : LA3D_ENGINE_DEFAULT;
+    e = getenv("LA3D_BANDS");
+    k.bands = (e && (atoi(e) == 4 || atoi(e) == 2)) ? atoi(e) : 0;
+    e = getenv("LA3D_BAND_DEFAULT");      // 0: the band engine only when asked for (LA3D_ENGINE=band / opt_engine)
+    k.band_default = !(e && e[0] == '0');
+    e = getenv("LA3D_BAND_MAXB");
+    k.band_maxb = (e && atoi(e) > 0) ? atoi(e) : 400;
     e = getenv("LA3D_BALANCE");
     k.balance = !(e && e[0] == '0');
     e = getenv("LA3D_BALANCE_ROUNDS");
@@ -1299,6 +1306,366 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
 }
 
 // ------------------------------------------------------------------------------------------
+// band engine (round 4): NB workgroups per instance, one per band of tile rows - the work item finer than an instance
+// that BASELINE config 5 / SURVEY section 7 name.  T(B) = 35 us + 72 us * B / 1024 fits the instance engine at B = 1024 / 2048 /
+// 8192 (profiles/r04/r04_cull.txt): the 35 us are ramp-up (nothing to compute until a whole mask plane is streamed) and tail (the
+// chain of the last instance: stream, list, pass A, axis, pass B, box on ONE workgroup), and both shrink with the work item.
+// A band workgroup streams its rows of the mask plane, lists its active tiles, runs pass A on them and publishes its partial
+// moments; the NB workgroups of an instance meet through global memory (release / acquire at agent scope: one fence pair per
+// workgroup and exchange), every one sums the NB partials in band order - the same numbers in the same order, hence the same
+// axis - and runs pass B on its own tiles; the workgroup that arrives LAST with its extents combines them and writes the record.
+// Waiting happens once per instance (for the partner's moments) and is deadlock free as long as the partner is resident or
+// will become resident without anybody waiting for this workgroup: partners are 8 blocks apart in dispatch order (same XCD: the
+// exchange stays in one L2), so at any time all but the last few dispatched workgroups have their partners on the chip and
+// finish.  A watchdog turns a partner that never shows up into status LA3D_BOX_UNSUPPORTED instead of a hang.
+// Records: deterministic run to run and under any launch order; the fp64 partial sums are grouped by band, so they agree with
+// the instance engine to rounding (like the split engine), not bit for bit.  u8 planes, tiled frames, full-mask mode only.
+// ------------------------------------------------------------------------------------------
+constexpr int BAND_XD = 8;                 // doubles per published moment record: Sx, Sz, Sxx, Sxz, Szz, n_valid, n_mask, -
+constexpr unsigned BAND_SPIN_MAX = 1u << 21;
+
+// per-instance exchange area in the workspace: [NB][2 rounds][BAND_XD] moments, [NB][6] extents
+template <int NB>
+__device__ inline double* band_xch(const FitParams& p, int inst) { return p.band_xch + (long long)inst * (NB * (2 * BAND_XD + 6)); }
+
+// Ordering of the exchange: every exchanged word is written and read with AGENT-scope relaxed atomics - single instructions that
+// are coherent at the L2 / memory side by themselves (sc1) - so all that is needed between "my record" and "my arrival" (and
+// between "their arrival" and "their record") is that the earlier instructions have completed: a workgroup-scope fence, i.e.
+// s_waitcnt.  An agent-scope FENCE would write back and invalidate the XCD's whole L2 - in the middle of everybody's streams:
+// measured 409 us instead of 107 us per 1024-instance call with four of them per workgroup (profiles/r04/r04_band.txt).
+__device__ inline void band_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+__device__ inline void st_agent(double* q, double v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline double ld_agent(const double* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Band moments -> instance moments -> status / axis, for every band of the instance alike.  Thread 0 publishes this band's
+// partial record, waits for the other bands of the instance, then sums the NB records IN BAND ORDER (its own re-read from
+// memory like the others: identical operands in identical order in every band).  Returns false on a watchdog timeout.
+template <int NB>
+__device__ inline void band_moments_to_axis(Shared* sh, const FitParams& p, int inst, int h, int round, const double* acc, int cnt,
+                                            int nmask, int tid, int wave, int lane, bool allow_redo) {
+  {
+    const double r0 = wave_sum(acc[0]), r1 = wave_sum(acc[1]), r2 = wave_sum(acc[2]), r3 = wave_sum(acc[3]), r4 = wave_sum(acc[4]);
+    const int rc = wave_sum_i(cnt), rn = wave_sum_i(nmask);
+    if (lane == 0) {
+      double* pp = sh->part[wave];
+      pp[0] = r0; pp[1] = r1; pp[2] = r2; pp[3] = r3; pp[4] = r4;
+      sh->cnt[wave] = rc; sh->nmask[wave] = rn;
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    double s[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) s[k] = lane < NWAVE ? sh->part[lane][k] : 0.0;
+    int n = lane < NWAVE ? sh->cnt[lane] : 0, nm = lane < NWAVE ? sh->nmask[lane] : 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { s[k] += dpp_f64<DPP_XOR1>(s[k]); s[k] += dpp_f64<DPP_XOR2>(s[k]); s[k] += dpp_f64<DPP_HALF_MIRROR>(s[k]); }
+    n += dpp_i32<DPP_XOR1>(n); n += dpp_i32<DPP_XOR2>(n); n += dpp_i32<DPP_HALF_MIRROR>(n);
+    nm += dpp_i32<DPP_XOR1>(nm); nm += dpp_i32<DPP_XOR2>(nm); nm += dpp_i32<DPP_HALF_MIRROR>(nm);
+    if (lane == 0) {
+      double* x = band_xch<NB>(p, inst);
+      double* mine = x + (h * 2 + round) * BAND_XD;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) st_agent(mine + k, s[k]);
+      st_agent(mine + 5, (double)n); st_agent(mine + 6, (double)nm);
+      band_fence();                                        // the record is complete (acknowledged) before the arrival
+      int* arrive = p.band_arrive + (long long)inst * 4 + round;
+      atomicAdd(arrive, 1);
+      unsigned spins = 0;
+      while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NB && spins < BAND_SPIN_MAX) {
+        __builtin_amdgcn_s_sleep(4);
+        ++spins;
+      }
+      const bool timeout = spins >= BAND_SPIN_MAX;
+      band_fence();                                        // the other bands' records are read after their arrivals
+      double t[5] = {0, 0, 0, 0, 0}, tn = 0, tm = 0;
+#pragma unroll 1   // (unrolled, the compiler keeps all NB records in flight: 56 registers at NB = 4 -> spills)
+      for (int hb = 0; hb < NB; ++hb) {                    // band order: the same sum in every band of the instance
+        const double* r = x + (hb * 2 + round) * BAND_XD;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) t[k] += ld_agent(r + k);
+        tn += ld_agent(r + 5); tm += ld_agent(r + 6);
+      }
+      const int nt = (int)tn;
+      double gap = NAN;
+      int st = LA3D_BOX_OK;
+      if (timeout) st = LA3D_BOX_UNSUPPORTED;
+      else if (sh->bad_ground) st = LA3D_BOX_BAD_GROUND;
+      else if (nt == 0) st = LA3D_BOX_EMPTY;
+      else if (nt == 1) st = LA3D_BOX_TOO_FEW;
+      const double chk = (t[0] + t[1]) + (t[2] + t[3]) + t[4];
+      sh->redo = (allow_redo && !timeout && !sh->bad_ground && !(fabs(chk) <= 1.79769313486231570815e308)) ? 1 : 0;
+      double cy = NAN, sy = NAN;
+      if (st == LA3D_BOX_OK) axis_from_sums((double)nt, t[0], t[1], t[2], t[3], t[4], &cy, &sy, &gap);
+      sh->cyaw = cy; sh->syaw = sy;
+      sh->qhead = 0u;
+      sh->st = st;
+      sh->n_valid = nt;
+      sh->gap = gap;
+      sh->nm = (int)tm;
+    }
+  }
+  __syncthreads();
+  if (sh->redo) return;   // uniform
+  // rejected instance: band 0 writes the outputs, every band returns (a watchdog timeout - the only source of UNSUPPORTED here -
+  // is reported by whichever band ran into it: the others may never learn)
+  if (tid == 0 && (h == 0 || sh->st == LA3D_BOX_UNSUPPORTED) && sh->st != LA3D_BOX_OK) {
+    if (p.aux) {
+      double* a = p.aux + (long long)inst * LA3D_AUX;
+      a[0] = atan2(sh->syaw, sh->cyaw); a[1] = (double)sh->n_valid; a[2] = (double)sh->nm; a[3] = sh->gap;
+    }
+    p.status[inst] = sh->st;
+    write_nan_box(p.out + (long long)inst * LA3D_REC);
+    if (p.proj) { for (int j = 0; j < 8; ++j) p.proj[(long long)inst * 8 + j] = NAN; }
+  }
+}
+
+template <int NB>
+__global__ __launch_bounds__(NT, NT / 64) void fit_bands_kernel(const FitParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned* bits = reinterpret_cast<unsigned*>(smem);
+  Shared* sh = reinterpret_cast<Shared*>(smem + p.mask_lds_bytes);
+  unsigned short* list = reinterpret_cast<unsigned short*>(smem + p.mask_lds_bytes + sizeof(Shared));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // block -> (instance slot, band): partners are 8 blocks apart, i.e. on the same XCD (the dispatcher places block b on XCD b % 8)
+  const int bx = (int)blockIdx.x;
+  const int slot = ((bx >> 3) / NB) * 8 + (bx & 7), h = (bx >> 3) % NB;
+  if (slot >= p.B) return;   // (grid padded to a multiple of 8 * NB)
+  const int inst = p.order_nch > 0 ? order_select(p, slot, sh, wave, lane) : xcd_remap(slot, p.B);
+  if (tid == 0) sh->order_inst = inst;
+  const int img = p.image_index ? p.image_index[inst] : inst;
+  // this band: tile rows [ty0, ty0 + ntyb) of the frame, pixel rows [row0, row0 + rows_b)
+  const int ty0 = h * p.band_trows, ntyb = (h == NB - 1) ? p.nty - ty0 : p.band_trows;
+  const int row0 = ty0 * 8, rows_b = min(ntyb * 8, p.H - row0);
+  const int HWb = rows_b * p.W;
+  const float* dpl = p.depth + (long long)img * p.depth_plane_stride + (long long)row0 * p.W;
+  const unsigned char* mpl = p.mask + (long long)inst * p.HW + (long long)row0 * p.W;
+
+  if (tid == NT - 1) {
+    // per-instance geometry as in the instance engine, in BAND-LOCAL pixel rows: v = v' + row0 folds into the constant column
+    double Kinv[9], Rg[9];
+    inv3_cofactor(p.K + (long long)img * p.k_stride, Kinv);
+    sh->bad_ground = ground_rotation(p.ground ? p.ground + (long long)inst * 4 : nullptr, Rg);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      double m[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) m[j] = Rg[i] * Kinv[j] + Rg[3 + i] * Kinv[3 + j] + Rg[6 + i] * Kinv[6 + j];
+      sh->M[i * 3] = m[0]; sh->M[i * 3 + 1] = m[1]; sh->M[i * 3 + 2] = fma(m[1], (double)row0, m[2]);
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) sh->Rg[i] = Rg[i];
+  }
+
+  // ---- phase 0: the band's rows of the u8 plane -> bit image in LDS (same forms as the instance engine) ----
+  int nmask = 0;
+  {
+    unsigned short* b16 = reinterpret_cast<unsigned short*>(bits);
+    const int ngroups = HWb >> 4;
+    const u32x4* m4 = reinterpret_cast<const u32x4*>(mpl);
+    unsigned seen = 0;
+#pragma unroll LA3D_P0_UNROLL
+    for (int g = tid; g < ngroups; g += NT) {
+      const u32x4 w = __builtin_nontemporal_load(m4 + g);
+      const unsigned lo = __builtin_amdgcn_udot4(w.y, 0x80402010u, __builtin_amdgcn_udot4(w.x, 0x08040201u, 0u, false), false);
+      const unsigned hi = __builtin_amdgcn_udot4(w.w, 0x80402010u, __builtin_amdgcn_udot4(w.z, 0x08040201u, 0u, false), false);
+      const unsigned pat = lo | (hi << 8);
+      seen |= (w.x | w.y) | (w.z | w.w);
+      b16[g] = (unsigned short)pat;
+      nmask += __popc(pat);
+    }
+    const unsigned long long odd = __ballot((seen & 0xfefefefeu) != 0);
+    if (lane == 0) sh->scan[wave] = odd != 0 ? 1u : 0u;
+    __syncthreads();
+    unsigned general = 0;
+#pragma unroll
+    for (int w = 0; w < NWAVE; ++w) general |= sh->scan[w];
+    if (general) {   // uniform: some byte is neither 0 nor 1 (e.g. 255-valued masks)
+      nmask = 0;
+#pragma unroll LA3D_P0_UNROLL
+      for (int g = tid; g < ngroups; g += NT) {
+        const u32x4 w = m4[g];
+        const unsigned pat = nz16(w.x, w.y, w.z, w.w);
+        b16[g] = (unsigned short)pat;
+        nmask += __popc(pat);
+      }
+    }
+  }
+  __syncthreads();
+  const int inst_p = __builtin_amdgcn_readfirstlane(sh->order_inst);
+  double Mg[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Mg[i] = uniform_f64(sh->M[i]);
+
+  // a FitParams of the band: the walk functions see a frame of rows_b rows
+  FitParams pb = p;
+  pb.H = rows_b; pb.nty = ntyb; pb.HW = HWb;
+
+  // ---- active-tile list of the band (one pass, ballots in SGPRs, image compacted in place) ----
+  int nactive = 0, compact = 0;
+  {
+    const int ntiles = p.ntx * ntyb, per = (ntiles + NWAVE - 1) / NWAVE;   // per <= 256: fit_dispatch checks
+    const int tbeg = wave * per, tend = min(tbeg + per, ntiles);
+    int base = 0, wcount = 0;
+    unsigned long long bal[4];
+    unsigned wrd[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int t = tbeg + k * 64 + lane;
+      unsigned any = 0;
+      if (t < tend) {
+        const int ty = (int)(((float)t + 0.5f) * p.rcp_ntx), tx = t - ty * p.ntx;
+        const int rmax = rows_b - 1 - ty * 8;
+        const unsigned* bw = bits + (ty * 8) * p.ntx + tx;
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          const unsigned w = bw[min(rr, rmax) * p.ntx];
+          any |= w;
+          wrd[k][rr] = rr <= rmax ? w : 0u;
+        }
+      }
+      bal[k] = __ballot(any != 0);
+      wcount += __popcll(bal[k]);
+    }
+    if (lane == 0) sh->scan[wave] = (unsigned)wcount;
+    __syncthreads();
+    for (int w = 0; w < NWAVE; ++w) {
+      const int c = (int)sh->scan[w];
+      if (w < wave) base += c;
+      nactive += c;
+    }
+    if (nactive > p.list_cap) {
+      nactive = -1;   // dense walk of the band
+    } else {
+      int off = base;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if ((bal[k] >> lane) & 1ull) {
+          const int t = tbeg + k * 64 + lane;
+          const int ty = (int)(((float)t + 0.5f) * p.rcp_ntx), tx = t - ty * p.ntx;
+          list[off + __popcll(bal[k] & ((1ull << lane) - 1ull))] = (unsigned short)((ty << 8) | tx);
+        }
+        off += __popcll(bal[k]);
+      }
+      if (nactive * 32 + cull_rng_words(nactive) * 4 <= p.mask_lds_bytes) {   // uniform
+        compact = 1;
+        off = base;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if ((bal[k] >> lane) & 1ull) {
+            uint4* e = reinterpret_cast<uint4*>(bits) + 2 * (off + __popcll(bal[k] & ((1ull << lane) - 1ull)));
+            e[0] = make_uint4(wrd[k][0], wrd[k][1], wrd[k][2], wrd[k][3]);
+            e[1] = make_uint4(wrd[k][4], wrd[k][5], wrd[k][6], wrd[k][7]);
+          }
+          off += __popcll(bal[k]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  bool cull = false;
+  int rng_words = 0;
+  if (compact) {   // uniform
+    rng_words = cull_rng_words(nactive);
+    cull = LA3D_CULL && nactive >= CULL_MIN && nactive <= CULL_MAXT;
+    if (!cull) {
+      unsigned short* surv = reinterpret_cast<unsigned short*>(bits + nactive * 8);
+      for (int t = tid; t < nactive; t += NT) surv[t] = (unsigned short)t;
+    }
+  }
+
+  // ---- pass A on the band, exchange, axis ----
+  double acc[5] = {0, 0, 0, 0, 0};
+  int cnt = 0;
+  Keep<0> keep;
+  bool checked = false;
+  if (cull) sweep_tiled<0, false, 0, true>(pb, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, nullptr, nullptr, compact, rng_words);
+  else sweep_tiled<0, false, 0>(pb, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, nullptr, nullptr, compact, rng_words);
+  cnt = nmask;   // optimistic pass: valid pixels = mask pixels
+  band_moments_to_axis<NB>(sh, p, inst_p, h, 0, acc, cnt, nmask, tid, wave, lane, true);
+  if (sh->redo) {   // uniform, and the same in every band of the instance: the summed moments decide
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 5; ++i) acc[i] = 0;
+    cnt = 0;
+    checked = true;
+    if (cull) sweep_tiled<0, true, 0, true>(pb, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, nullptr, nullptr, compact, rng_words);
+    else sweep_tiled<0, true, 0>(pb, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, nullptr, nullptr, compact, rng_words);
+    band_moments_to_axis<NB>(sh, p, inst_p, h, 1, acc, cnt, nmask, tid, wave, lane, false);
+  }
+  if (sh->st != LA3D_BOX_OK) return;
+
+  // ---- pass B on the band ----
+  double ext[6] = {INFINITY, -INFINITY, INFINITY, -INFINITY, INFINITY, -INFINITY};
+  {
+    double N0[3], N2[3];
+    yaw_rows(sh, Mg, N0, N2);
+    int d0 = 0;
+    int nsurv = compact ? nactive : -1;
+    if (cull) {   // uniform
+      nsurv = checked ? cull_plan<true>(sh, pb, dpl, bits, list, nactive, rng_words, N0, Mg + 3, N2, tid, wave, lane, ext)
+                      : cull_plan<false>(sh, pb, dpl, bits, list, nactive, rng_words, N0, Mg + 3, N2, tid, wave, lane, ext);
+    }
+    if (checked) sweep_tiled<1, true, 0>(pb, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0, keep, nullptr, &sh->qhead, compact, rng_words, nsurv);
+    else sweep_tiled<1, false, 0>(pb, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0, keep, nullptr, &sh->qhead, compact, rng_words, nsurv);
+  }
+  // ---- extents of the band -> exchange -> the last band to arrive writes the record ----
+  {
+    const double r0 = wave_min(ext[0]), r1 = wave_max(ext[1]), r2 = wave_min(ext[2]), r3 = wave_max(ext[3]), r4 = wave_min(ext[4]), r5 = wave_max(ext[5]);
+    if (lane == 0) {
+      double* pp = sh->part[wave];
+      pp[0] = r0; pp[1] = r1; pp[2] = r2; pp[3] = r3; pp[4] = r4; pp[5] = r5;
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  double lo[3], hi[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    lo[k] = lane < NWAVE ? sh->part[lane][2 * k] : INFINITY;
+    hi[k] = lane < NWAVE ? sh->part[lane][2 * k + 1] : -INFINITY;
+    lo[k] = fmin(lo[k], dpp_f64<DPP_XOR1>(lo[k])); lo[k] = fmin(lo[k], dpp_f64<DPP_XOR2>(lo[k])); lo[k] = fmin(lo[k], dpp_f64<DPP_HALF_MIRROR>(lo[k]));
+    hi[k] = fmax(hi[k], dpp_f64<DPP_XOR1>(hi[k])); hi[k] = fmax(hi[k], dpp_f64<DPP_XOR2>(hi[k])); hi[k] = fmax(hi[k], dpp_f64<DPP_HALF_MIRROR>(hi[k]));
+  }
+  double* xe = band_xch<NB>(p, inst_p) + NB * 2 * BAND_XD;   // [NB][6]
+  int last = 0;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { st_agent(xe + h * 6 + 2 * k, lo[k]); st_agent(xe + h * 6 + 2 * k + 1, hi[k]); }
+    band_fence();
+    last = atomicAdd(p.band_arrive + (long long)inst_p * 4 + 2, 1) == NB - 1 ? 1 : 0;
+    band_fence();
+  }
+  last = __builtin_amdgcn_readfirstlane(last);
+  if (!last) return;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {   // min / max over the bands (uniform loads: every lane reads the same words)
+    double l = ld_agent(xe + 2 * k), u = ld_agent(xe + 2 * k + 1);
+#pragma unroll 1
+    for (int hb = 1; hb < NB; ++hb) { l = fmin(l, ld_agent(xe + hb * 6 + 2 * k)); u = fmax(u, ld_agent(xe + hb * 6 + 2 * k + 1)); }
+    lo[k] = uniform_f64(l); hi[k] = uniform_f64(u);
+  }
+  double Rg[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Rg[i] = sh->Rg[i];
+  if (p.proj) {
+    const int im = p.image_index ? p.image_index[inst_p] : inst_p;
+    write_box_wave(p.out + (long long)inst_p * LA3D_REC, Rg, sh->cyaw, sh->syaw, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], lane,
+                   p.proj + (long long)inst_p * 8, p.K + (long long)im * p.k_stride, p.proj_w, p.proj_h);
+  } else {
+    write_box_wave(p.out + (long long)inst_p * LA3D_REC, Rg, sh->cyaw, sh->syaw, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], lane);
+  }
+  if (lane == 63) {
+    if (p.aux) {
+      double* a = p.aux + (long long)inst_p * LA3D_AUX;
+      a[0] = atan2(sh->syaw, sh->cyaw); a[1] = (double)sh->n_valid; a[2] = (double)sh->nm; a[3] = sh->gap;
+    }
+    p.status[inst_p] = LA3D_BOX_OK;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // point-cloud fit: one workgroup per cloud  (estimate_bbox on explicit (N,3) float64 input)
 // ------------------------------------------------------------------------------------------
 struct PtsParams {
@@ -1389,8 +1756,12 @@ __device__ inline bool hull_yaw(SharedHull* hs, SharedP* sh, int tid, double* ya
   // chain of dependent LDS reads - one lane needed ~150 us for 500 points.  Round 3: (1) sixteen lanes each run the chain over a
   // sixteenth of the sorted points and mark what survives in their chunk (a point inside its chunk's hull cannot be a vertex of the
   // whole hull; collinear points drop out either way), the survivors are compacted in sorted order; (2) four lanes do the same
-  // over quarters of the survivors; (3) one lane runs the SAME chain over what is left.  The vertex sequence - hence every edge,
-  // area and the winning yaw - is the one the chain over all points gives.  The two stack tops live in registers (chain_pass).
+  // over quarters of the survivors; (3) one lane runs the SAME chain over what is left.  With exact orientation predicates the
+  // vertex sequence - hence every edge, area and the winning yaw - is the one the chain over all points gives; the fp64 cross
+  // products are rounded, so in NEARLY collinear configurations (or with duplicate points straddling a chunk boundary) a point
+  // may be kept by one form and dropped by the other: the hulls then differ by a vertex that moves no edge beyond rounding, and the
+  // minimum-area yaw can only move between edges whose areas tie to rounding (the documented don't-care; profiles/r03/stress_hull.py
+  // holds both forms to the oracle with a yaw / area tolerance).  The two stack tops live in registers (chain_pass).
   unsigned short* cl = reinterpret_cast<unsigned short*>(hs->yaw);   // current candidates in sorted order (yaw[] is written after the chain)
   for (int i = tid; i < n; i += NTP) cl[i] = (unsigned short)i;
   int m = n;
@@ -2703,10 +3074,11 @@ __global__ __launch_bounds__(256) void size_estimate_kernel(const unsigned char*
                                                             const long long* __restrict__ rle_offsets,
                                                             const int* __restrict__ poly_xy, const long long* __restrict__ poly_ring_off,
                                                             const long long* __restrict__ poly_inst_rings, int B, int HW,
-                                                            int step, int shift, unsigned* __restrict__ keys) {
+                                                            int step, int shift, unsigned* __restrict__ keys, int* __restrict__ band_arrive) {
   const int lane = threadIdx.x & 63;
   const int inst = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (inst >= B) return;
+  if (band_arrive && lane < 4) band_arrive[inst * 4 + lane] = 0;   // band engine: the arrival counters of this launch start at zero
   int c = 0;
   if (poly_xy) {  // shoelace area of every part (an estimate: parts may overlap or leave the frame)
     long long tot = 0;
@@ -2796,7 +3168,7 @@ int launch_fit_inst(const FitParams& p_in, size_t lds, hipStream_t s, void* work
         int shift = 0;
         while ((amax >> shift) > 0x3ffff) ++shift;
         hipLaunchKernelGGL(size_estimate_kernel, dim3((p.B + 3) / 4), dim3(256), 0, s, p.mask, p.rle_counts, p.rle_offsets, p.poly_xy,
-                           p.poly_ring_off, p.poly_inst_rings, p.B, p.HW, step, shift, est);
+                           p.poly_ring_off, p.poly_inst_rings, p.B, p.HW, step, shift, est, nullptr);
         p.order_keys = est;
       }
     }
@@ -2807,6 +3179,92 @@ int launch_fit_inst(const FitParams& p_in, size_t lds, hipStream_t s, void* work
 #endif
   hipLaunchKernelGGL(kern, dim3(p.B), dim3(NT), lds, s, p);
   return check_launch("fit_instances_kernel");
+}
+
+// ---- band engine (fit_bands_kernel) ----
+constexpr int BAND_NB_MAX = 4;
+constexpr size_t band_xch_doubles(int nb) { return (size_t)nb * (2 * BAND_XD + 6); }
+
+// workspace of the band engine: [B] u32 sort keys | [B][4] i32 arrival counters | [B][NB_MAX * 22] f64 exchange records
+inline size_t band_keys_bytes(int B) { return ((size_t)B * 4 + 255) & ~(size_t)255; }
+inline size_t band_workspace_bytes(int B) { return band_keys_bytes(B) + (size_t)B * 16 + (size_t)B * band_xch_doubles(BAND_NB_MAX) * 8 + 256; }
+
+inline bool band_frame_ok(int H, int W, int nb) {
+  if (W % 32 != 0 || (long long)H * W % 16 != 0) return false;
+  const int ntx = W / 32, nty = (H + 7) / 8;
+  if (ntx > 255 || nty > 255 || nty < nb) return false;
+  const int tb = nty / nb, tmax = nty - (nb - 1) * tb;   // the last band takes the remainder
+  return (long long)ntx * tmax <= 256 * NWAVE;          // one-pass tile list: <= 256 tiles per wave
+}
+
+// Bands per instance: LA3D_BANDS pins 2 or 4; otherwise four up to 288 instances, two beyond (measured, us per call, u8 planes,
+// split | instance | two bands | four bands - profiles/r04/r04_band.txt: B = 4: 34 | 37 | 44 | 31; 64: 43 | 56 | 51 | 38;
+// 256: 67 | 67 | 64 | 63; 320: 80 | 76 | 68 | 69; 384: - | 75 | 73 | 77; 512: - | 80 | 85 | 95; 1024: - | 107 | 134 | 168).
+inline int band_count(const FitParams& p) {
+  int nb = config().bands ? config().bands : (p.B <= 288 ? 4 : 2);
+  if (nb == 4 && !band_frame_ok(p.H, p.W, 4)) nb = 2;
+  return nb;
+}
+
+// u8 planes, 16-byte aligned, full-mask mode.  By default the band engine takes 4 <= B <= 400: below, one instance per call
+// gains nothing from four workgroups that each pay the fixed latencies of a workgroup; above, the per-workgroup latencies
+// (order, list, two reductions, two exchanges, axis, box: ~60 % of a half-size work item) cost more slot time than the shorter
+// ramp-up and tail give back.  LA3D_ENGINE=band / opt_engine pins it for any batch.
+inline bool band_eligible(const FitParams& p, bool vec, bool sample) {
+  const int e = p.opt_engine != LA3D_ENGINE_DEFAULT ? p.opt_engine : config().engine;
+  if (e == LA3D_ENGINE_INSTANCE || e == LA3D_ENGINE_SPLIT) return false;
+  if (!vec || sample || p.mask == nullptr || !band_frame_ok(p.H, p.W, band_count(p))) return false;
+  if (e == LA3D_ENGINE_BAND) return true;
+  return config().band_default && p.B >= 4 && p.B <= config().band_maxb;
+}
+
+template <int NB>
+int launch_fit_bands(const FitParams& p_in, hipStream_t s, void* workspace) {
+  FitParams p = p_in;
+  auto kern = fit_bands_kernel<NB>;
+  allow_big_lds(reinterpret_cast<const void*>(kern));
+  p.ntx = p.W / 32; p.nty = (p.H + 7) / 8;
+  p.rcp_ntx = 1.0f / (float)p.ntx;
+  p.band_trows = p.nty / NB;
+  const int tmax = p.nty - (NB - 1) * p.band_trows;
+  p.list_cap = p.ntx * tmax;
+  p.tiles_per_wave = (p.list_cap + NWAVE - 1) / NWAVE;
+  // LDS: four workgroups per CU by wave slots, so each may use a quarter of the CU's LDS: the region behind the band's bit image
+  // keeps depth tiles between the passes
+  const size_t img = (((size_t)tmax * 8 * p.W / 8) + 15) & ~(size_t)15;
+  const size_t fixed = sizeof(Shared) + (((size_t)p.list_cap * 2 + 15) & ~(size_t)15);
+  size_t region = ((160 * 1024 / 4) - fixed) & ~(size_t)15;
+  if (region < img) region = img;
+  if (region + fixed > 160 * 1024 - 256) return LA3D_ERR_UNSUPPORTED;   // (band_frame_ok keeps frames far below this)
+  p.mask_lds_bytes = (int)region;
+  unsigned char* w = static_cast<unsigned char*>(workspace);
+  unsigned* keys = reinterpret_cast<unsigned*>(w);
+  p.band_arrive = reinterpret_cast<int*>(w + band_keys_bytes(p.B));
+  p.band_xch = reinterpret_cast<double*>(w + band_keys_bytes(p.B) + (size_t)p.B * 16);
+  p.order_nch = 0; p.order_keys = nullptr; p.order_resident = 0; p.order_shift = 0;
+  bool zeroed = false;
+  if (p.B > 256 && p.B <= ORDER_MAX_B && balance_enabled(p) && p.B <= balance_max_rounds() * 4 * 256) {
+    // largest instances first (chunk-local ranking as in the instance engine; no per-CU pairing: an instance's bands sit on NB CUs)
+    p.order_nch = (p.B + ORDER_CHUNK - 1) / ORDER_CHUNK;
+    if (p.area_hint) {
+      while (((long long)p.HW >> p.order_shift) > 0x3ffff) ++p.order_shift;
+    } else {
+      int step = 1;
+      for (int cand : {EST_STEP, 31, 17, 7, 3})
+        if ((p.HW >> 7) / cand >= 64) { step = cand; break; }
+      const long long amax = (long long)p.HW / step + 128;
+      int shift = 0;
+      while ((amax >> shift) > 0x3ffff) ++shift;
+      hipLaunchKernelGGL(size_estimate_kernel, dim3((p.B + 3) / 4), dim3(256), 0, s, p.mask, nullptr, nullptr, nullptr, nullptr, nullptr,
+                         p.B, p.HW, step, shift, keys, p.band_arrive);
+      p.order_keys = keys;
+      zeroed = true;
+    }
+  }
+  if (!zeroed && hipMemsetAsync(p.band_arrive, 0, (size_t)p.B * 16, s) != hipSuccess) return check_launch("band engine memset");
+  const int grid = ((p.B + 7) / 8) * 8 * NB;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), region + fixed, s, p);
+  return check_launch("fit_bands_kernel");
 }
 
 // run-length input is its own instantiation (it needs the LDS bit image), so the u8 kernels carry no decode code
@@ -2860,12 +3318,15 @@ int la3d_debug_set_block_order(const int32_t* perm_dev, int n) {   // measuremen
 
 // Workspace layout (one per concurrently running call; contents need not be initialised or preserved):
 //   instance engine: [B] u32 sort keys of the size-balanced launch order (4*B bytes)
+//   band engine:     [B] u32 sort keys | [B][4] i32 arrival counters | [B][88] f64 exchange records (band_workspace_bytes)
 //   split engine:    [B][GEO_D] f64 geometry, then bit images, tile lists and partial-sum slots (split_workspace_bytes)
 size_t la3d_workspace_bytes(int B, int H, int W) {
   if (B <= 0) return 0;
   const size_t inst = (size_t)B * GEO_D * sizeof(double);  // kept as the minimum (older callers size by it)
   const size_t split = split_workspace_bytes(B, H, W);     // split engine: + bit image, tile lists, partial slots
-  return split > inst ? split : inst;
+  const size_t band = band_frame_ok(H, W, 2) ? band_workspace_bytes(B) : 0;   // band engine: keys, arrival counters, exchange records
+  const size_t m = split > inst ? split : inst;
+  return band > m ? band : m;
 }
 
 int la3d_unproject(const float* depth, const double* K9, const double* Rt12, int H, int W, void* out,
@@ -2993,6 +3454,9 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   // polygons: the side stage sits behind Shared, where the tile list / rank prefix go later (disjoint in time)
   const size_t poly_stage = poly ? (size_t)POLY_STAGE_BYTES : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (band_eligible(p, vec, sample)) {   // u8 planes, 4 <= B <= 400 (or pinned): two / four workgroups per instance, ONE launch
+    return band_count(p) == 4 ? launch_fit_bands<4>(p, s, workspace) : launch_fit_bands<2>(p, s, workspace);
+  }
   if (!sample && split_eligible(p, vec, ldsmask)) {
     const int rc = split_fit(p, workspace, s);   // (the split engine's final kernel does not project: one small follow-up launch)
     if (rc != LA3D_SUCCESS || !p.proj) return rc;
@@ -3163,7 +3627,7 @@ int la3d_fit_instances_ex(const la3d_fit_args* args) {
   const bool filter_on = a.filter_boundary >= 0 && a.filter_max_edge > 0;
   const FilterArgs fa{a.filter_boundary, a.filter_min_area, a.filter_max_edge, a.stats};
   const ProjArgs pr{a.proj, a.image_width, a.image_height};
-  if (a.opt_engine < 0 || a.opt_engine > LA3D_ENGINE_SPLIT || a.opt_launch_order < 0 || a.opt_launch_order > LA3D_ORDER_ON ||
+  if (a.opt_engine < 0 || a.opt_engine > LA3D_ENGINE_BAND || a.opt_launch_order < 0 || a.opt_launch_order > LA3D_ORDER_ON ||
       a.opt_build < 0 || a.opt_build > LA3D_BUILD_RETAINING || a.opt_reserved != 0) {
     set_err("la3d_fit_instances_ex: bad opt_engine / opt_launch_order / opt_build (or opt_reserved != 0)");
     return LA3D_ERR_ARG;
@@ -3294,18 +3758,21 @@ int la3d_mask_stats_rle(const int32_t* counts, const int64_t* offsets, int B, in
 int la3d_masked_ratio_median(const float* num, int64_t num_plane_stride, const int32_t* image_index, const float* den,
                              const uint8_t* mask_a, const uint8_t* mask_b, int B, int H, int W, float* median,
                              int32_t* count, void* stream) {
-  if (!num || !den || !mask_a || !median || !count || B < 0 || H <= 0 || W <= 0 || num_plane_stride < 0 ||
-      (long long)H * W > (1LL << 20)) {
-    set_err("la3d_masked_ratio_median: bad argument (H*W <= 819200)");
+  if (!num || !den || !mask_a || !median || !count || B < 0 || H <= 0 || W <= 0 || num_plane_stride < 0) {
+    set_err("la3d_masked_ratio_median: bad argument (null pointer, negative size or stride)");
     return LA3D_ERR_ARG;
   }
   if (B == 0) return LA3D_SUCCESS;
-  const int HW = H * W, nwords = (HW + 31) / 32;
-  const size_t lds = (size_t)((nwords + 3) & ~3) * 4 + (size_t)(RM_CAP + 1024 + 256 + 16) * 4 + (size_t)((HW + 63) / 64) * 2 + 16;
-  if (lds > 160 * 1024) {   // bit image + chunk list + key buffer must fit one CU's LDS: frames up to ~820 k pixels
-    set_err("la3d_masked_ratio_median: frame too large for the LDS bit image (H*W <= 819200)");
+  // ONE size limit, from the LDS the kernel needs: bit image + chunk list + key buffer in one CU's 160 KiB (about 819 k pixels)
+  const long long HWl = (long long)H * W;
+  const long long nwl = (HWl + 31) / 32;
+  const long long ldsl = ((nwl + 3) & ~3LL) * 4 + (long long)(RM_CAP + 1024 + 256 + 16) * 4 + ((HWl + 63) / 64) * 2 + 16;
+  if (ldsl > 160 * 1024) {
+    set_err("la3d_masked_ratio_median: frame too large for the LDS bit image (H*W up to about 819200)");
     return LA3D_ERR_UNSUPPORTED;
   }
+  const int HW = (int)HWl, nwords = (int)nwl;
+  const size_t lds = (size_t)ldsl;
   allow_big_lds(reinterpret_cast<const void*>(ratio_median_kernel));
   hipLaunchKernelGGL(ratio_median_kernel, dim3(B), dim3(RM_NT), lds, static_cast<hipStream_t>(stream), num,
                      (long long)num_plane_stride, image_index, den, mask_a, mask_b, HW, nwords, median, count);

@@ -30,7 +30,10 @@ inline void set_err(const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg)
 // the hot path of the C-ABI never calls getenv.  Measurement scripts set the variables before the first call; a caller that
 // wants a different decision for one call uses la3d_fit_args::opt_*.  Speed only - records never depend on any of it.
 struct Config {
-  int engine;          // LA3D_ENGINE=instance|split -> LA3D_ENGINE_*
+  int engine;          // LA3D_ENGINE=instance|split|band -> LA3D_ENGINE_*
+  int bands;           // LA3D_BANDS=2|4 pins the workgroups per instance of the band engine (0: by batch size)
+  int band_default;    // LA3D_BAND_DEFAULT=0: the band engine only when pinned
+  int band_maxb;       // LA3D_BAND_MAXB: largest batch the band engine takes by default
   int balance;         // LA3D_BALANCE=0 -> launch order off by default
   int balance_rounds;  // LA3D_BALANCE_ROUNDS: batches up to this many resident sets are ordered (default 3)
   int retain;          // LA3D_RETAIN=0|1 -> LA3D_BUILD_PLAIN / LA3D_BUILD_RETAINING (0 = by batch size)
@@ -484,6 +487,11 @@ struct FitParams {
   double proj_w, proj_h;
   const int* area_hint;   // [B] mask areas known to the caller (launch order without the estimate pass), or null
   int opt_engine, opt_order, opt_build;   // per-call overrides (la3d_fit_args::opt_*; host side only), 0 = the library's choice
+  // band engine (fit_bands_kernel): tile rows per band (the last band takes the remainder), arrival counters [B][4] (zeroed before
+  // the launch) and the exchange area [B][NB * 22] doubles, both in the workspace
+  int band_trows;
+  int* band_arrive;
+  double* band_xch;
   double* out;
   int* status;
   double* aux;

@@ -202,7 +202,7 @@ def filter_annotations(annotations, image_size, boundary_threshold: int = 10, sc
 
 
 def fit_instances_ex(depth, K, masks=None, rles=None, polys=None, ground=None, sample_idx=None, image_index=None, filter=None,
-                     image_size=None, area_hint=None, stream=None, device=None):
+                     image_size=None, area_hint=None, stream=None, device=None, _fitter=None, _stats=None):
     """Every option of the fit in one call (C-ABI ``la3d_fit_instances_ex``): exactly one of ``masks`` (B,H,W) u8 / bool,
     ``rles`` (COCO RLE list or ``pack_rle`` tuple), ``polys`` (``pack_polygons`` tuple) gives the masks; ``filter`` as in
     ``fit_instances_poly`` (run-length / polygon masks only); ``image_size=(width, height)`` adds the 2-D boxes the reference's
@@ -247,10 +247,11 @@ def fit_instances_ex(depth, K, masks=None, rles=None, polys=None, ground=None, s
     d, k, P, ii, g, si = _fit_common(depth, K, H, W, B, ground, sample_idx, image_index, dev, what)
     out = {}
     with torch.cuda.device(dev):
-        f = InstanceFitter(B, H, W, dev)
+        # (_fitter / _stats: buffers a per-image caller keeps between calls - fit_annotations - instead of allocating them per call)
+        f = _fitter if _fitter is not None else InstanceFitter(B, H, W, dev)
         out.update(boxes=f.boxes[0], status=f.status[0], aux=f.aux[0])
         if filter:
-            out["stats"] = torch.zeros((B, 4), dtype=torch.int32, device=dev)
+            out["stats"] = _stats if _stats is not None else torch.zeros((B, 4), dtype=torch.int32, device=dev)
         if image_size is not None:
             out["boxes2d"] = torch.full((B, 8), float("nan"), dtype=torch.float64, device=dev)
         if B == 0:
@@ -278,8 +279,24 @@ def fit_instances_ex(depth, K, masks=None, rles=None, polys=None, ground=None, s
     return out
 
 
+_ANN_CACHE: dict = {}   # (B, H, W, device) -> (InstanceFitter, stats, pinned read-back buffer): the per-image pattern repeats a few shapes
+
+
+def _ann_buffers(B, H, W, dev, kind):
+    key = (B, H, W, kind, dev.index if dev.index is not None else torch.cuda.current_device())
+    ent = _ANN_CACHE.get(key)
+    if ent is None:
+        if len(_ANN_CACHE) >= 64:
+            _ANN_CACHE.pop(next(iter(_ANN_CACHE)))
+        f = InstanceFitter(B, H, W, dev)
+        # the pinned buffer mirrors the head of the fitter's arena: boxes | aux | status (256-aligned pieces), without the workspace
+        ent = (f, torch.empty((B, 4), dtype=torch.int32, device=dev), torch.empty(f._arena.numel() - f.workspace.numel(), dtype=torch.uint8, pin_memory=True))
+        _ANN_CACHE[key] = ent
+    return ent
+
+
 def fit_annotations(annotations, image_size, depth, K, ground=None, boundary_threshold: int = 10, scale_threshold: int = 100,
-                    image_index=None, device=None):
+                    image_index=None, device=None, to_host: bool = False):
     """``read_bounding_boxes_segmentations`` (reference src/util.py:336-383) and the box fit in ONE pass over the annotations:
     crowd annotations are skipped (:355-357); every other annotation's segmentation is decoded / rasterised once, inside the
     fit launch, which also evaluates the keep rule (:375) on the bit image and fits only the kept instances (``filter=`` of
@@ -287,7 +304,10 @@ def fit_annotations(annotations, image_size, depth, K, ground=None, boundary_thr
 
     depth / K / image_index as in ``fit_instances`` (image_index per ANNOTATION when depth holds several planes); ground: None
     or (len(annotations), 4).  Returns ``(bboxes, kept_index, category_ids, boxes (n,39) f64, status (n,) i32)`` for the kept
-    annotations in annotation order, the last two on the GPU."""
+    annotations in annotation order, the last two on the GPU - or, with ``to_host=True``, as NumPy arrays taken from the ONE
+    packed read-back (records | aux | status in a single copy into pinned memory) that the keep decision needs anyway: no
+    further device work, which is what a caller writing JSON wants.  Output buffers, workspace and the pinned buffer are kept per
+    (B, H, W) between calls (the per-image pattern repeats a handful of shapes)."""
     W_img, H_img = int(image_size[0]), int(image_size[1])
     dev = _dev(device)
     groups = {"rle": ([], []), "poly": ([], [])}
@@ -299,7 +319,7 @@ def fit_annotations(annotations, image_size, depth, K, ground=None, boundary_thr
         groups[kind][0].append(i)
         groups[kind][1].append({"size": seg["size"], "counts": seg["counts"]} if kind == "rle" else seg)
     flt = {"boundary_threshold": boundary_threshold, "scale_threshold": scale_threshold}
-    sels, box_all, st_all = [], [], []
+    sels, box_all, st_all, pins = [], [], [], []
     for kind, (idx, segs) in groups.items():
         if not idx:
             continue
@@ -327,17 +347,32 @@ def fit_annotations(annotations, image_size, depth, K, ground=None, boundary_thr
         g_d = up[-4] if up[-4] is not None else g
         ii_d = up[-3] if up[-3] is not None else ii
         K_d = up[-1] if up[-1] is not None else K
-        res = fit_instances_ex(depth, K_d, ground=g_d, image_index=ii_d, device=dev, filter=flt, area_hint=up[-2], **kw)
-        sels.append(sel); box_all.append(res["boxes"]); st_all.append(res["status"])
+        fitter, stats_buf, pin = _ann_buffers(len(idx), Hh, Ww, dev, kind)
+        res = fit_instances_ex(depth, K_d, ground=g_d, image_index=ii_d, device=dev, filter=flt, area_hint=up[-2], _fitter=fitter,
+                               _stats=stats_buf, **kw)
+        head = fitter._arena[:pin.numel()]
+        pin.copy_(head, non_blocking=True)      # records | aux | status of this group: one copy, read after the one synchronisation
+        sels.append(sel); box_all.append(res["boxes"]); st_all.append(res["status"]); pins.append((pin, len(idx)))
     if not sels:
         return [], np.zeros(0, np.int64), [], torch.zeros((0, 39), dtype=torch.float64, device=dev), torch.zeros(0, dtype=torch.int32, device=dev)
-    boxes_c = box_all[0] if len(box_all) == 1 else torch.cat(box_all)
-    status_c = st_all[0] if len(st_all) == 1 else torch.cat(st_all)
-    st_host = status_c.cpu().numpy()                      # the one synchronisation of the call
+    torch.cuda.current_stream(dev).synchronize()          # the one synchronisation of the call
+    up8 = lambda v: (v + 255) // 256 * 256  # noqa: E731  (InstanceFitter's arena layout)
+    hb, hs = [], []
+    for pin, n in pins:
+        raw = pin.numpy()
+        nb, na = n * REC * 8, n * AUX * 8
+        hb.append(raw[:nb].view(np.float64).reshape(n, REC))
+        hs.append(raw[up8(nb) + up8(na):up8(nb) + up8(na) + n * 4].view(np.int32))
+    st_host = hs[0] if len(hs) == 1 else np.concatenate(hs)
     sel_c = np.concatenate(sels)
     pos = np.nonzero(st_host != 6)[0]                     # kept rows of the concatenated results ...
     pos = pos[np.argsort(sel_c[pos], kind="stable")]      # ... in annotation order
     kept = sel_c[pos]
+    if to_host:
+        bh = hb[0] if len(hb) == 1 else np.concatenate(hb)
+        return ([annotations[i]["bbox"] for i in kept], kept, [annotations[i]["category_id"] for i in kept], bh[pos].copy(), st_host[pos].copy())
+    boxes_c = box_all[0] if len(box_all) == 1 else torch.cat(box_all)
+    status_c = st_all[0] if len(st_all) == 1 else torch.cat(st_all)
     pt = torch.as_tensor(pos, device=dev)
     return ([annotations[i]["bbox"] for i in kept], kept, [annotations[i]["category_id"] for i in kept],
             boxes_c.index_select(0, pt), status_c.index_select(0, pt))
@@ -391,7 +426,13 @@ def _filter_args(filter):
     unknown = set(f) - {"boundary_threshold", "scale_threshold", "truncation_pixels"}
     if unknown:
         raise ValueError(f"unknown filter keys: {sorted(unknown)}")
-    return int(f.get("boundary_threshold", 10)), int(f.get("scale_threshold", 100)), int(f.get("truncation_pixels", 10))
+    b, a, e = int(f.get("boundary_threshold", 10)), int(f.get("scale_threshold", 100)), int(f.get("truncation_pixels", 10))
+    if b < 0 or e <= 0:
+        # the C-ABI reads filter_boundary < 0 or filter_max_edge <= 0 as "no filter" (a zero-initialised la3d_fit_args means none);
+        # truncation_pixels <= 0 would mean "reject every instance" in the reference's rule (edge < 0 never holds): refuse it here
+        # instead of silently fitting everything
+        raise ValueError("filter: boundary_threshold must be >= 0 and truncation_pixels >= 1")
+    return b, a, e
 
 
 def fit_instances_poly(depth, polys, K, ground=None, sample_idx=None, image_index=None, stream=None, device=None, filter=None):

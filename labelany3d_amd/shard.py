@@ -133,7 +133,7 @@ def gather_boxes(boxes: torch.Tensor, status: torch.Tensor, dst: int = 0, group=
 
 
 def fit_instances_sharded(depth, masks, K, image_index, ground=None, sample_idx=None, areas=None, dst: int = 0, group=None,
-                          fit_fn: Optional[Callable] = None, load_fn: Optional[Callable] = None):
+                          fit_fn: Optional[Callable] = None, load_fn: Optional[Callable] = None, timings: Optional[dict] = None):
     """Every rank passes the same METADATA (``image_index``, optionally ``areas``); images are split into contiguous,
     cost-balanced ranges (``plan_shards``), each rank fits the instances of its images on its own GPU and the records are
     gathered on ``dst`` in global instance order.
@@ -144,7 +144,9 @@ def fit_instances_sharded(depth, masks, K, image_index, ground=None, sample_idx=
       * ``load_fn(shard) -> (depth, masks, K, ground, sample_idx)`` returning ONLY this rank's images / instances (depth planes
         img_lo..img_hi, masks inst_lo..inst_hi); pass ``depth=(P, H, W)`` (the global shape) and ``masks=None``.
     ``areas`` (B,) are per-instance mask areas for the balance (None: count-based).  ``fit_fn`` defaults to
-    labelany3d_amd.fit_instances (injectable so the sharding logic is testable on CPU with gloo)."""
+    labelany3d_amd.fit_instances (injectable so the sharding logic is testable on CPU with gloo).  ``timings`` (a dict, optional):
+    filled with this rank's ``load_s`` / ``fit_s`` / ``gather_s`` wall-clock seconds (the device is synchronised around each
+    stage then, which a production call has no reason to do) and its shard."""
     if fit_fn is None:
         from .batched import fit_instances as fit_fn
     world = dist.get_world_size(group)
@@ -157,6 +159,13 @@ def fit_instances_sharded(depth, masks, K, image_index, ground=None, sample_idx=
     plan = plan_shards(img, P, world, areas=areas, frame_pixels=H * W)
     sh = plan[rank]
     local_img = (img[sh.inst_lo:sh.inst_hi] - sh.img_lo).astype(np.int32)
+    import time
+
+    def _sync():
+        if timings is not None and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        return time.perf_counter()
+    t0 = _sync()
     if load_fn is not None:
         d, m, k, g, si = load_fn(sh)
     else:
@@ -167,11 +176,17 @@ def fit_instances_sharded(depth, masks, K, image_index, ground=None, sample_idx=
             k = K[sh.img_lo:sh.img_hi]
         g = None if ground is None else ground[sh.inst_lo:sh.inst_hi]
         si = None if sample_idx is None else sample_idx[sh.inst_lo:sh.inst_hi]
+    t1 = _sync()
     if sh.inst_hi > sh.inst_lo:
         boxes, status, _ = fit_fn(d, m, k, ground=g, sample_idx=si, image_index=local_img)
     else:  # a rank without instances still takes part in the gather
         dev = m.device if isinstance(m, torch.Tensor) else torch.device("cpu")
         boxes = torch.zeros((0, 39), dtype=torch.float64, device=dev)
         status = torch.zeros((0,), dtype=torch.int32, device=dev)
+    t2 = _sync()
     # every rank knows every shard's size from the plan: no count exchange
-    return gather_boxes(boxes, status, dst=dst, group=group, counts=[p.inst_hi - p.inst_lo for p in plan])
+    out = gather_boxes(boxes, status, dst=dst, group=group, counts=[p.inst_hi - p.inst_lo for p in plan])
+    if timings is not None:
+        t3 = _sync()
+        timings.update(load_s=t1 - t0, fit_s=t2 - t1, gather_s=t3 - t2, shard=tuple(sh), plan=[tuple(p) for p in plan])
+    return out

@@ -1,0 +1,138 @@
+"""The band engine (round 4): two workgroups per instance, one per band of tile rows, meeting through global memory for the
+moments (before the axis) and the extents (before the record).  Parity against the CPU oracle at the stated 1e-9, agreement with
+the instance engine to rounding (the fp64 partial sums are grouped by band), determinism, and every branch of the exchange:
+rejected instances, the checked re-run on non-finite depth, launch order on / off, 255-valued masks, odd batch sizes."""
+import numpy as np
+import pytest
+
+from oracle import la3d_oracle as O
+
+from .conftest import SCHED
+from .test_gpu_parity import K640, assert_records, np_, rect_masks
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def la():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import labelany3d_amd
+
+    return labelany3d_amd
+
+
+def _both(la, monkeypatch, depth, masks, K, ground=None):
+    out = {}
+    for eng in ("band", "instance"):
+        monkeypatch.setattr(SCHED(), "engine", eng)
+        b, s, a = la.fit_instances(depth, masks, K, ground=ground)
+        out[eng] = (np_(b), np_(s), np_(a))
+    monkeypatch.setattr(SCHED(), "engine", None)
+    return out
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 480, 640), (5, 480, 640), (37, 480, 640), (48, 96, 128), (9, 64, 32), (3, 16, 64)])
+def test_band_engine_vs_oracle(la, monkeypatch, B, H, W):
+    rs = np.random.RandomState(B * 7 + H)
+    depth = rs.uniform(0.5, 10, (B, H, W)).astype(np.float32)
+    masks = rect_masks(rs, B, H, W, hmax=H, wmax=W) if H >= 96 else (rs.rand(B, H, W) < 0.3)
+    if B > 4:
+        masks[1] = False                               # empty mask -> status 1
+        masks[2] = False; masks[2, H // 2, W // 3] = True   # one pixel -> status 3
+        masks[3] = False; masks[3, :8, :32] = True     # everything in band 0
+        masks[4] = False; masks[4, H - 3:, W - 40:] = True   # everything in the last band
+    K = K640 if (H, W) == (480, 640) else np.array([[100.0, 0, W / 2], [0, 100.0, H / 2], [0, 0, 1]])
+    ground = np.array([[0.05, -0.97, 0.1, 1.2]] * B) + 0.02 * rs.randn(B, 4)
+    if B > 6:
+        ground[5] = [0, -1, 0, 1.0]                    # degenerate ground -> status 2
+        ground[6, 0] = np.nan                          # "no ground"
+    got = _both(la, monkeypatch, depth, masks, K, ground)
+    ground_o = [None if np.isnan(g[0]) else g for g in ground]
+    ref, rst, _, nval = O.fit_instances(depth, masks, np.broadcast_to(K, (B, 3, 3)), ground=ground_o)
+    for eng in ("band", "instance"):
+        b, s, a = got[eng]
+        assert s.tolist() == list(rst), eng
+        ok = s == 0
+        assert_records(b[ok], ref[ok], f"{eng} B={B} {H}x{W}", gap=a[ok, 3])
+        assert np.isnan(b[~ok]).all()
+        np.testing.assert_array_equal(a[ok, 1], nval[ok])
+        np.testing.assert_array_equal(a[:, 2], masks.reshape(B, -1).sum(1))
+    ok = got["band"][1] == 0
+    np.testing.assert_allclose(got["band"][0][ok][:, :15], got["instance"][0][ok][:, :15], rtol=1e-11, atol=1e-11)
+
+
+def test_band_engine_nonfinite_depth_and_byte_masks(la, monkeypatch):
+    """inf / NaN under the mask in ONE band: the summed moments are non-finite in every band of the instance, so all of them re-run
+    the checked pass and exchange a second time; masks holding 255 take the general byte test."""
+    rs = np.random.RandomState(3)
+    B, H, W = 12, 480, 640
+    depth = rs.uniform(0.5, 10, (B, H, W)).astype(np.float32)
+    masks = rect_masks(rs, B, H, W).astype(np.uint8)
+    masks[::2] *= 255
+    for i in range(0, B, 3):
+        r, c = np.argwhere(masks[i])[rs.randint(int(masks[i].astype(bool).sum()))]
+        depth[i, r, c] = [np.inf, np.nan, -np.inf][(i // 3) % 3]
+    got = _both(la, monkeypatch, depth, masks, K640)
+    ref, rst, _, nval = O.fit_instances(depth, masks.astype(bool), np.broadcast_to(K640, (B, 3, 3)))
+    b, s, a = got["band"]
+    assert s.tolist() == list(rst)
+    assert_records(b, ref, "band/nonfinite", gap=a[:, 3])
+    np.testing.assert_array_equal(a[:, 1], nval)
+
+
+def test_band_engine_full_batch_is_deterministic_and_order_free(la, monkeypatch):
+    """BASELINE config 2 at full size with the band engine pinned: every record written, identical run to run and with the launch
+    order on / off, and within 1e-11 of the instance engine; a sample against the oracle."""
+    import torch
+
+    import bench
+    from labelany3d_amd import InstanceFitter
+
+    dev = torch.device("cuda", 0)
+    B = 1024
+    depth, masks, K, _, _ = bench.make_inputs(B, dev, 1234)
+    f = InstanceFitter(B, bench.H, bench.W, dev, slots=4)
+    runs = []
+    for slot, kw in enumerate((dict(engine="band"), dict(engine="band"), dict(engine="band", launch_order=False), dict(engine="instance"))):
+        f.boxes[slot].fill_(12345.0); f.status[slot].fill_(-1)
+        runs.append(tuple(t.clone() for t in f.run(depth, masks, K, slot=slot, **kw)))
+    torch.cuda.synchronize()
+    assert int((runs[0][1] == 0).sum()) == B
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][2], runs[1][2])
+    assert torch.equal(runs[0][0], runs[2][0]) and torch.equal(runs[0][1], runs[2][1])
+    torch.testing.assert_close(runs[0][0][:, :15], runs[3][0][:, :15], rtol=1e-11, atol=1e-11)
+    idx = np.random.RandomState(0).choice(B, 24, replace=False)
+    ref, rst, _, _ = O.fit_instances(np_(depth[idx]), np_(masks[idx]).astype(bool), np.broadcast_to(K640, (24, 3, 3)))
+    assert_records(np_(runs[0][0])[idx], ref, "band/config2", gap=np_(runs[0][2])[idx, 3])
+    # the default dispatch takes the band engine for 4 <= B <= 400 u8 planes (four bands up to 288, two beyond): same records as
+    # the pinned call
+    for Bs in (64, 320):
+        fs = InstanceFitter(Bs, bench.H, bench.W, dev, slots=2)
+        a = fs.run(depth[:Bs], masks[:Bs], K, slot=0)
+        b = fs.run(depth[:Bs], masks[:Bs], K, slot=1, engine="band")
+        torch.cuda.synchronize()
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_band_engine_shared_depth_planes_and_2d_boxes(la, monkeypatch):
+    """image_index (shared depth planes, config 3 / 4 layout) and the fused 2-D boxes of la3d_fit_instances_ex through the band engine"""
+    import torch
+
+    from labelany3d_amd import fit_instances_ex, project_boxes
+
+    rs = np.random.RandomState(8)
+    P, B, H, W = 5, 23, 480, 640
+    depth = rs.uniform(0.5, 10, (P, H, W)).astype(np.float32)
+    masks = rect_masks(rs, B, H, W)
+    img = rs.randint(0, P, B).astype(np.int32)
+    monkeypatch.setattr(SCHED(), "engine", "band")
+    res = fit_instances_ex(depth, K640, masks=masks, image_index=img, image_size=(W, H))
+    b, s = np_(res["boxes"]), np_(res["status"])
+    ref, rst, _, _ = O.fit_instances(depth, masks, np.broadcast_to(K640, (P, 3, 3)), depth_index=img)
+    assert s.tolist() == list(rst)
+    assert_records(b, ref, "band/shared", gap=np_(res["aux"])[:, 3])
+    want2d = project_boxes(res["boxes"], K640, (W, H), image_index=img)
+    np.testing.assert_array_equal(np_(res["boxes2d"]), np_(want2d))

@@ -148,8 +148,12 @@ def test_fit_from_polygons_equals_fit_from_planes(la):
         np.testing.assert_array_equal(np_(a1), np_(a2))
         np.testing.assert_array_equal(np_(s3), np_(s2))
         np.testing.assert_array_equal(np_(b3), np_(b2))
-    b1, s1, a1 = la.fit_instances_poly(depth, polys, K, ground=ground)      # the library's own choice (40 instances: split both)
-    np.testing.assert_array_equal(np_(b1), np_(la.fit_instances(depth, masks, K, ground=ground)[0]))
+    # the library's own choice at 40 instances: the split engine for polygon parts, the band engine for u8 planes (round 4) - two
+    # engines, two groupings of the fp64 partial sums: equal to rounding, not bit for bit
+    b1, s1, a1 = la.fit_instances_poly(depth, polys, K, ground=ground)
+    b2 = np_(la.fit_instances(depth, masks, K, ground=ground)[0])
+    ok = np_(s1) == 0
+    np.testing.assert_allclose(np_(b1)[ok][:, :15], b2[ok][:, :15], rtol=1e-10, atol=1e-10)
     assert np_(s1)[-1] == 1                    # the empty instance: "No valid points"
     for i in range(0, B - 1, 5):
         want, _ = P.create_boolean_mask_from_polygon((W, H), segs[i])

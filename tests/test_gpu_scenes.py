@@ -1,0 +1,100 @@
+"""The real-data entry (labelany3d_amd/fit_scenes.py): a synthetic tree of 64 scene folders (depth_map.npy, cam_params.json,
+ground files for some) + a COCO-style annotation file with polygon and run-length segmentations, crowd / tiny / border-touching
+annotations -> 3dbbox.json per scene.  Every record is compared with the CPU oracle in REFERENCE-SUBSAMPLE mode (the reference's
+semantics for masks above 500 px, drawn from the global NumPy RNG in kept-instance order), the keep decisions and object ids with
+the oracle's restatement of the reference's reader (src/util.py:336-383)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import la3d_oracle as O
+from oracle import poly_oracle as P
+
+from .test_gpu_parity import assert_records
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_scene(sc, names, subsample, rng_state):
+    """the reference's reader + estimate_bbox per kept instance, restated by the oracle; consumes np.random like the reference"""
+    H, W = sc["height"], sc["width"]
+    depth, K = sc["depth"], np.asarray(sc["K"], dtype=np.float64)
+    kept = []
+    for a in sc["annotations"]:
+        if a["iscrowd"] or "segmentation" not in a:
+            continue
+        seg = a["segmentation"]
+        if isinstance(seg, dict):
+            mask = O.rle_decode(np.asarray(seg["counts"]), H, W)
+            from_rle = True
+        else:
+            mask, _ = P.create_boolean_mask_from_polygon((W, H), seg)
+            from_rle = False
+        if O.keep_instance(O.mask_stats(mask), H, from_rle):
+            kept.append((a, mask))
+    recs = []
+    pts_all = O.depth_to_points(depth[None], K)
+    for k, (a, mask) in enumerate(kept):
+        pts = pts_all[mask]
+        g = sc.get("ground", {}).get(k) if isinstance(sc.get("ground"), dict) else None
+        ri = False
+        if subsample and len(pts) > 500:
+            ri = np.random.randint(0, len(pts), 500)     # the reference's draw (src/util_3dbox.py:124), global RNG
+        rec, st, _ = O.fit_points(pts, g, ri)
+        if st == 0:
+            recs.append((str(k), names.get(a["category_id"], "unknown"), rec))
+    return recs
+
+
+@pytest.mark.parametrize("subsample", [True, False])
+def test_fit_scenes_tool_on_a_synthetic_tree(tmp_path, subsample):
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from labelany3d_amd import fit_scenes as F
+
+    root = str(tmp_path / "scenes")
+    scenes, data = F.synthetic_scenes(64, seed=5, root=root, with_ground=True)
+    assert os.path.exists(os.path.join(root, scenes[0]["name"], "depth_map.npy"))
+    np.random.seed(123)
+    argv = ["--scenes", root, "--batch-images", "24"] + (["--subsample", "--seed", "123"] if subsample else [])
+    assert F.main(argv) == 0
+    names = F.category_names(data["categories"])
+    # the oracle consumes the global RNG in kept-instance order over the scenes IN THE TOOL'S BATCH ORDER (one frame size here:
+    # batches are consecutive scenes), like the reference's loop would
+    np.random.seed(123)
+    n_boxes = 0
+    for sc in scenes:
+        want = _oracle_scene(sc, names, subsample, None)
+        with open(os.path.join(root, sc["name"], "3dbbox.json")) as f:
+            got = json.load(f)
+        assert [g["obj_id"] for g in got] == [w[0] for w in want], sc["name"]
+        assert [g["category_name"] for g in got] == [w[1] for w in want]
+        for g, w in zip(got, want):
+            assert list(g) == ["obj_id", "category_name", "center_cam", "R_cam", "dimensions", "bbox3D_cam"]   # src/util_3dbox.py:283-290
+            rec = np.concatenate([g["center_cam"], g["dimensions"], np.ravel(g["R_cam"]), np.ravel(g["bbox3D_cam"])])
+            assert_records(rec[None], w[2][None], f"{sc['name']} obj {g['obj_id']}")
+        n_boxes += len(got)
+    assert n_boxes > 150
+
+
+def test_scene_pipeline_in_memory_matches_disk(tmp_path):
+    """the same scenes handed over as in-memory dicts (what bench.py --end-to-end times) give the records the tool writes"""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from labelany3d_amd import fit_scenes as F
+
+    root = str(tmp_path / "scenes")
+    scenes, data = F.synthetic_scenes(20, seed=9, root=root)
+    timings = {}
+    mem = {sc["name"]: recs for sc, recs in F.ScenePipeline(batch_images=7, write=False, timings=timings).run(scenes)}
+    disk = {sc["name"]: recs for sc, recs in F.ScenePipeline(batch_images=32).run(F.scenes_from_disk(root, os.path.join(root, "annotations.json")))}
+    assert set(mem) == set(disk) == {sc["name"] for sc in scenes}
+    for k in mem:
+        assert json.dumps(mem[k]) == json.dumps(disk[k]), k
+    assert timings["images"] == 20 and timings["h2d_bytes"] > 20 * 480 * 640 * 4 and timings["fit_s"] > 0

@@ -191,17 +191,14 @@ def test_pipelined_batches_and_retaining_build_give_the_same_records(la, monkeyp
         for k in range(5):
             d, m, K_ = batches[k]
             yield d.clone(), m.clone(), K_.clone()
-    prev = la.set_launch_order(True)
-    try:
+    with la.scheduling(launch_order=True):   # the caller's own (thread-local) choice; fit_batches switches the order off per call
         views = []
         for k, r in enumerate(la.fit_batches(lazily(), copy=False)):   # zero-copy views: valid until two more are requested
             assert torch.equal(r[0], want[k][0]) and torch.equal(r[1], want[k][1])
             views.append(r)
             if k >= 1:
                 assert torch.equal(views[k - 1][0], want[k - 1][0])
-        assert la.set_launch_order(prev) is True      # fit_batches put the caller's explicit setting back
-    finally:
-        la.set_launch_order(prev)
+        assert SCHED().launch_order is True      # fit_batches did not touch the caller's setting
     monkeypatch.setattr(SCHED(), "build", "retaining")
     for (depth, masks, K), w in zip(batches[:2], want[:2]):
         b, s, a = la.fit_instances(depth, masks, K)
@@ -301,6 +298,70 @@ def test_bench_multi_rank_path_two_ranks_one_gpu():
     assert abs(d["value"] - 2 * 6 * 512 / (d["ms_per_step"] * 1e-3 * 6)) < 1e-6 * d["value"]     # whole-job aggregate over both ranks
     assert "DRY RUN" in d["config"]["sharding"] and "cpu_baseline" not in d
     assert 0 < d["roofline"]["frac"] < 1
+
+
+def test_bench_config4_mode_two_ranks_one_gpu_equals_one_process(tmp_path):
+    """bench.py --config4: ONE global metadata list -> plan_shards -> every rank materialises and fits only its image range ->
+    one gather (the north_star partitioning, reference --start_index / --end_index).  Two gloo ranks sharing this box's GPU
+    must deliver, in global instance order, exactly the records of the one-process job, which in turn match a direct
+    fit_instances call on the whole materialised job; the JSON line carries per-rank fit times and the gather's time."""
+    import json
+    import subprocess
+    import sys
+
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for world in (1, 2):
+        dump = str(tmp_path / f"rec{world}.npy")
+        env = dict(os.environ, LA3D_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", LA3D_ENGINE="instance")
+        base = [os.path.join(root, "bench.py"), "--gpus", str(world), "--config4", "60", "--jobs", "1", "--warmup-jobs", "1", "--dump", dump]
+        cmd = ([sys.executable] + base if world == 1 else
+               [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port())] + base)
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == world and d["scaling"] == "strong" and len(d["per_rank_fit_ms"]) == world
+        assert sum(d["config"]["instances_per_rank"]) == d["config"]["instances"] and sum(d["config"]["images_per_rank"]) == 60
+        assert d["gather_ms"] >= 0 and d["fit_ms_max"] >= d["fit_ms_min"] > 0 and d["imbalance_max_over_mean"] >= 1.0
+        assert abs(d["value"] - d["config"]["instances"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+        outs[world] = np.load(dump)
+    # a shard boundary changes neither the instance engine's records (one workgroup per instance: no cross-instance arithmetic)
+    np.testing.assert_array_equal(outs[1], outs[2])
+    import bench
+    import labelany3d_amd as la
+    from .conftest import SCHED
+
+    meta = bench.config4_metadata(60, 1234)
+    dev = torch.device("cuda", 0)
+    depth, masks, K, _, _ = bench.config4_materialize(meta, (0, 60, 0, meta["B"]), dev)
+    SCHED().engine = "instance"
+    try:
+        b, s, _ = la.fit_instances(depth, masks, K, image_index=meta["img"].astype(np.int32))
+    finally:
+        SCHED().engine = None
+    np.testing.assert_array_equal(b.cpu().numpy(), outs[1])
+
+
+def test_config4_metadata_and_plan_cpu_side():
+    """the metadata every rank derives and the plan over it: contiguous, complete, balanced by the cost model (no GPU work)"""
+    import bench
+    from labelany3d_amd.shard import plan_shards
+
+    meta = bench.config4_metadata(500, 7)
+    assert (np.diff(meta["img"]) >= 0).all() and meta["img"].max() == 499 and len(meta["area"]) == meta["B"]
+    for world in (1, 2, 8):
+        plan = plan_shards(meta["img"], 500, world, areas=meta["area"], frame_pixels=480 * 640)
+        assert plan[0].img_lo == 0 and plan[-1].img_hi == 500 and plan[-1].inst_hi == meta["B"]
+        for a, b in zip(plan, plan[1:]):
+            assert a.img_hi == b.img_lo and a.inst_hi == b.inst_lo
+        cost = [float((480 * 640 + 8 * meta["area"][p.inst_lo:p.inst_hi]).sum()) for p in plan]
+        assert max(cost) / (sum(cost) / world) < 1.1
 
 
 _NCCL_WORKER = r"""
