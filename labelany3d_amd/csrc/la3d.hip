@@ -290,7 +290,7 @@ __device__ inline void tile_range(const TileCtx& c, int e, unsigned nib, const u
 }
 
 // stage 2: the pixel math of a step on quads dq / nibbles pk (all lanes; unmasked lanes carry zeros / NaNs)
-template <int PASS, bool CHK, bool LK = false, bool SURV = false, bool RNG = false>
+template <int PASS, bool CHK, bool LK = false, bool SURV = false, bool RNG = false, bool SPEC = false>
 __device__ inline void tile_compute(const TileCtx& c, const unsigned short* list, int nsteps, bool dense, int j0, int rev_base,
                                     const uint4* dq, unsigned pk, double* sv, int* n) {
 #pragma unroll
@@ -308,7 +308,7 @@ __device__ inline void tile_compute(const TileCtx& c, const unsigned short* list
     const double r2 = fma(c.a20, ud, fma(c.a21, vd, c.a22));
     double r1 = 0;
     if (PASS == 1) r1 = fma(c.a10, ud, fma(c.a11, vd, c.a12));
-    quad_math<PASS, CHK>(nib, db, r0, r1, r2, c.a00, c.a10, c.a20, sv, n);
+    quad_math<PASS, CHK, SPEC>(nib, db, r0, r1, r2, c.a00, c.a10, c.a20, sv, n);
     if (RNG && PASS == 0) tile_range<CHK>(c, j, nib, db);
   }
 }
@@ -324,7 +324,9 @@ __device__ inline int cull_rng_words(int nactive) { return ((2 * nactive + 3) & 
 
 // RNG (pass A, plain build, compact image): also leave every tile's depth range for pass-B culling (rng_words > 0 then).
 // nsurv >= 0 (pass B): walk only the culling survivors surv[0 .. nsurv) (fit_instances_kernel builds the list).
-template <int PASS, bool CHK, int RET, bool RNG = false>
+// SPEC: the un-grounded, skew-free forms of the pixel math (quad_math): the caller checks M's row 2 == (0, 0, 1) for pass A,
+// M[1][0] == 0 for pass B.
+template <int PASS, bool CHK, int RET, bool RNG = false, bool SPEC = false>
 __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__ dpl, const unsigned* bits,
                                    const unsigned short* list, int nactive, const double* A0, const double* A1,
                                    const double* A2, int wave, int lane, double* acc, int* cnt, Keep<RET>& keep,
@@ -367,7 +369,7 @@ __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__
 #pragma unroll
     for (int s = 0; s < RET; ++s) {
       const int j0 = (s * NWAVE + wave) * TG;
-      if (j0 < nsteps) tile_compute<PASS, CHK>(c, list, nsteps, false, j0, -1, keep.dq[s], keep.nib[s], sv, &n);
+      if (j0 < nsteps) tile_compute<PASS, CHK, false, false, false, SPEC>(c, list, nsteps, false, j0, -1, keep.dq[s], keep.nib[s], sv, &n);
     }
     jstart = (RET * NWAVE + wave) * TG;
     kept = RET * NWAVE * TG;
@@ -389,7 +391,7 @@ __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__
           for (int g = 0; g < TG; ++g) dq[g] = slot[g * 64];
           pk = *nslot;
         }
-        tile_compute<PASS, CHK>(c, list, nsteps, false, jstart, -1, dq, pk, sv, &n);
+        tile_compute<PASS, CHK, false, false, false, SPEC>(c, list, nsteps, false, jstart, -1, dq, pk, sv, &n);
       }
       jstart += NWAVE * TG;
       kept += NWAVE * TG;
@@ -404,7 +406,7 @@ __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__
       if (j0 >= nsurv) break;
       uint4 dq[TG];
       const unsigned pk = tile_fetch<PASS, LK, true>(c, dpl, bits, list, nsurv, false, j0, -1, dq);
-      tile_compute<PASS, CHK, LK, true>(c, list, nsurv, false, j0, -1, dq, pk, sv, &n);
+      tile_compute<PASS, CHK, LK, true, false, SPEC>(c, list, nsurv, false, j0, -1, dq, pk, sv, &n);
     }
   } else
   if (!(LA3D_CULL && LK) && PASS == 1 && qhead != nullptr && !dense) {
@@ -419,13 +421,13 @@ __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__
       if (j0 >= nsteps) break;
       uint4 dq[TG];
       const unsigned pk = tile_fetch<PASS, LK>(c, dpl, bits, list, nsteps, false, j0, rev_base, dq);
-      tile_compute<PASS, CHK, LK>(c, list, nsteps, false, j0, rev_base, dq, pk, sv, &n);
+      tile_compute<PASS, CHK, LK, false, false, SPEC>(c, list, nsteps, false, j0, rev_base, dq, pk, sv, &n);
     }
   } else {
     for (int j0 = jstart; j0 < nsteps; j0 += NWAVE * TG) {
       uint4 dq[TG];
       const unsigned pk = tile_fetch<PASS, LK>(c, dpl, bits, list, nsteps, dense, j0, rev_base, dq);
-      tile_compute<PASS, CHK, LK, false, RNG && LK>(c, list, nsteps, dense, j0, rev_base, dq, pk, sv, &n);
+      tile_compute<PASS, CHK, LK, false, RNG && LK, SPEC>(c, list, nsteps, dense, j0, rev_base, dq, pk, sv, &n);
     }
   }
 #pragma unroll
@@ -1232,8 +1234,18 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
 #ifndef LA3D_ABL_NO_PASSA
   if (!sampled) {
     if (TILED) {
-      if (LA3D_CULL && LK && cull) sweep_tiled<0, false, RET, true>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, lds_keep, nullptr, compact, rng_words);
-      else sweep_tiled<0, false, RET>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, lds_keep, nullptr, compact, rng_words);
+      // (the un-grounded, skew-free forms of the pixel math where they apply: same records, fewer instructions - quad_math)
+      // (not in the subsample build, which walks tiles only for its small masks and has no registers to spare, and not in the
+      // retaining build, whose register allocation the extra bodies disturb: config 5 at B = 1024 +5 %, profiles/r04/r04_spec.txt)
+      constexpr bool SP = !SAMPLE && RET == 0;
+      const bool specA = SP && Mg[6] == 0.0 && Mg[7] == 0.0 && Mg[8] == 1.0;   // uniform
+      if (LA3D_CULL && LK && cull) {
+        if (specA) sweep_tiled<0, false, RET, true, SP>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, lds_keep, nullptr, compact, rng_words);
+        else sweep_tiled<0, false, RET, true>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, lds_keep, nullptr, compact, rng_words);
+      } else {
+        if (specA) sweep_tiled<0, false, RET, false, SP>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, lds_keep, nullptr, compact, rng_words);
+        else sweep_tiled<0, false, RET>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, lds_keep, nullptr, compact, rng_words);
+      }
       cnt = nmask;   // the optimistic pass does not count: with every masked depth finite, valid pixels = mask pixels
     }
     else sweep<VEC, LDSMASK, 0>(p, dpl, mpl, bits, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, &nmask);
@@ -1292,6 +1304,7 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
       if (tid == 0) { int* cs = reinterpret_cast<int*>(p.geo) + p.B + 2 * inst_p; cs[0] = nactive; cs[1] = cull ? nsurv + 6 : (nsurv >= 0 ? nsurv : nactive); }
 #endif
       if (checked) sweep_tiled<1, true, RET>(p, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0, keep, lds_keep, qh, compact, rng_words, nsurv);
+      else if (!SAMPLE && RET == 0 && Mg[3] == 0.0) sweep_tiled<1, false, RET, false, !SAMPLE && RET == 0>(p, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0, keep, lds_keep, qh, compact, rng_words, nsurv);
       else sweep_tiled<1, false, RET>(p, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0, keep, lds_keep, qh, compact, rng_words, nsurv);
     }
     else sweep<VEC, LDSMASK, 1>(p, dpl, mpl, bits, N0, Mg + 3, N2, wave, lane, ext, &d0, &d1);
@@ -1580,8 +1593,14 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_bands_kernel(const FitParams 
   int cnt = 0;
   Keep<0> keep;
   bool checked = false;
-  if (cull) sweep_tiled<0, false, 0, true>(pb, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, nullptr, nullptr, compact, rng_words);
-  else sweep_tiled<0, false, 0>(pb, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, nullptr, nullptr, compact, rng_words);
+  const bool specA = Mg[6] == 0.0 && Mg[7] == 0.0 && Mg[8] == 1.0;   // uniform (quad_math: the un-grounded forms, same records)
+  if (cull) {
+    if (specA) sweep_tiled<0, false, 0, true, true>(pb, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, nullptr, nullptr, compact, rng_words);
+    else sweep_tiled<0, false, 0, true>(pb, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, nullptr, nullptr, compact, rng_words);
+  } else {
+    if (specA) sweep_tiled<0, false, 0, false, true>(pb, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, nullptr, nullptr, compact, rng_words);
+    else sweep_tiled<0, false, 0>(pb, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, nullptr, nullptr, compact, rng_words);
+  }
   cnt = nmask;   // optimistic pass: valid pixels = mask pixels
   band_moments_to_axis<NB>(sh, p, inst_p, h, 0, acc, cnt, nmask, tid, wave, lane, true);
   if (sh->redo) {   // uniform, and the same in every band of the instance: the summed moments decide
@@ -1608,6 +1627,7 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_bands_kernel(const FitParams 
                       : cull_plan<false>(sh, pb, dpl, bits, list, nactive, rng_words, N0, Mg + 3, N2, tid, wave, lane, ext);
     }
     if (checked) sweep_tiled<1, true, 0>(pb, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0, keep, nullptr, &sh->qhead, compact, rng_words, nsurv);
+    else if (Mg[3] == 0.0) sweep_tiled<1, false, 0, false, true>(pb, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0, keep, nullptr, &sh->qhead, compact, rng_words, nsurv);
     else sweep_tiled<1, false, 0>(pb, dpl, bits, list, nactive, N0, Mg + 3, N2, wave, lane, ext, &d0, keep, nullptr, &sh->qhead, compact, rng_words, nsurv);
   }
   // ---- extents of the band -> exchange -> the last band to arrive writes the record ----

@@ -542,9 +542,37 @@ __device__ inline void pix_uv(unsigned i, int W, float rcpW, unsigned* u, unsign
 // CHK = false is the optimistic form: only the mask bit gates a pixel.  Its results are identical to CHK = true as long as
 // every masked depth is finite; a non-finite one turns the fp64 sums of pass 0 into inf/NaN for good (inf and NaN are
 // sticky under + and fma), which the caller detects after the reduce and answers by re-running the checked form.
-template <int PASS, bool CHK = true>
+// SPEC (round 4, the "VALU diet"): the form for a camera without ground rotation and without skew - by far the common call (config
+// 2, every un-grounded call).  Bit-identical to the general form, just fewer instructions:
+//   pass 0: row 2 of M is exactly (0, 0, 1), so z = d * 1 = d: no z product, no ray increment for it (8 instead of 10 fp64 ops);
+//   pass 1: M[1][0] == 0, so the y ray r1 is constant along the quad: multiplication by a constant is monotone under rounding,
+//           hence min_k fl(d_k r1) is fl(dmin r1) or fl(dmax r1) - the quad's y extent costs two fp32 min3 / max3 pairs on the raw
+//           depths plus six fp64 operations per QUAD instead of four fp64 operations per PIXEL.
+__device__ inline float min3_f32(float a, float b, float c) {
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ inline float max3_f32(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ inline float min_f32_raw(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ inline float max_f32_raw(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+template <int PASS, bool CHK = true, bool SPEC = false>
 __device__ inline void quad_math(unsigned nib, const unsigned* db, double r0, double r1, double r2, double a00,
                                  double a10, double a20, double* s, int* n) {
+  float fk[4];   // SPEC pass 1: the quad's depths with NaN for invalid pixels (ignored by min / max)
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     int m;  // 0 / -1 validity word
@@ -556,19 +584,38 @@ __device__ inline void quad_math(unsigned nib, const unsigned* db, double r0, do
     }
     if (PASS == 0) {
       const double d = (double)__uint_as_float(db[k] & (unsigned)m);   // invalid -> +0.0
-      const double x = d * r0, z = d * r2;
-      s[0] += x; s[1] += z;
-      s[2] = fma(x, x, s[2]); s[3] = fma(x, z, s[3]); s[4] = fma(z, z, s[4]);
+      if (SPEC) {
+        const double x = d * r0;
+        s[0] += x; s[1] += d;
+        s[2] = fma(x, x, s[2]); s[3] = fma(x, d, s[3]); s[4] = fma(d, d, s[4]);
+      } else {
+        const double x = d * r0, z = d * r2;
+        s[0] += x; s[1] += z;
+        s[2] = fma(x, x, s[2]); s[3] = fma(x, z, s[3]); s[4] = fma(z, z, s[4]);
+      }
       if (CHK) *n -= m;   // the optimistic form does not count: its caller takes the mask popcount
     } else {
-      const double d = (double)__uint_as_float(db[k] | ~(unsigned)m);  // invalid -> NaN, ignored by min/max
-      const double x = d * r0, y = d * r1, z = d * r2;
+      const unsigned bits = db[k] | ~(unsigned)m;                      // invalid -> NaN, ignored by min/max
+      const double d = (double)__uint_as_float(bits);
+      const double x = d * r0, z = d * r2;
       s[0] = dmin(s[0], x); s[1] = dmax(s[1], x);
-      s[2] = dmin(s[2], y); s[3] = dmax(s[3], y);
       s[4] = dmin(s[4], z); s[5] = dmax(s[5], z);
-      r1 += a10;
+      if (SPEC) {
+        fk[k] = __uint_as_float(bits);
+      } else {
+        const double y = d * r1;
+        s[2] = dmin(s[2], y); s[3] = dmax(s[3], y);
+        r1 += a10;
+      }
     }
-    r0 += a00; r2 += a20;   // next pixel of the row: u + 1
+    r0 += a00;
+    if (!(SPEC && PASS == 0)) r2 += a20;   // next pixel of the row: u + 1
+  }
+  if (SPEC && PASS == 1) {
+    const double dlo = (double)min_f32_raw(min3_f32(fk[0], fk[1], fk[2]), fk[3]);
+    const double dhi = (double)max_f32_raw(max3_f32(fk[0], fk[1], fk[2]), fk[3]);
+    const double ya = dlo * r1, yb = dhi * r1;
+    s[2] = dmin(s[2], dmin(ya, yb)); s[3] = dmax(s[3], dmax(ya, yb));
   }
 }
 
