@@ -14,8 +14,8 @@ import bench  # noqa: E402
 
 SIMDS = 256 * 4
 CLOCK_GHZ = 2.4
-files = {"config2": "r03_config2_summary.md", "config2_rle": "r03_config2_rle_sq_summary.md", "config2_poly": "r03_config2_poly_sq_summary.md",
-         "config2_B8192": "r03_config2_B8192_sq_summary.md"}
+files = {"config2": "r04_config2_summary.md", "config2_rle": "r04_config2_rle_sq_summary.md", "config2_poly": "r04_config2_poly_sq_summary.md",
+         "config2_B8192": "r04_config2_B8192_sq_summary.md"}
 out = {}
 for mode, fn in files.items():
     p = os.path.join(ROOT, "profiles", fn)
