@@ -440,6 +440,10 @@ def fit_instances_poly(depth, polys, K, ground=None, sample_idx=None, image_inde
     (cv2.fillPoly semantics, reference src/util.py:386-400).  Arguments and returns as ``labelany3d_amd.fit_instances``;
     ``polys`` is the tuple from ``pack_polygons``.
 
+    PARITY UNPINNED until ``tests/golden/g16_fillpoly.npz`` exists: the rasteriser follows a restatement of OpenCV 4.x's fillPoly
+    (oracle/poly_oracle.py), not outputs of cv2 itself - OpenCV cannot be installed in the build image.  Where it can:
+    ``pip install opencv-python==4.10.0.84 && python tests/golden/make_golden_fillpoly.py``, then run the polygon tests.
+
     ``filter=True`` (or a dict of thresholds, see ``_filter_args``) fuses the reference's instance filter (src/util.py:375, polygon
     branch: height = last row - first row + 1) into the same launch: dropped instances get status 6 and a NaN record and cost no
     passes; a fourth return value holds the (B,4) statistics (area, rows, span, edge pixels) as ``mask_stats_poly`` gives them."""
