@@ -3203,6 +3203,7 @@ int launch_fit_inst(const FitParams& p_in, size_t lds, hipStream_t s, void* work
 
 // ---- band engine (fit_bands_kernel) ----
 constexpr int BAND_NB_MAX = 4;
+constexpr int BAND_MINB = 48;   // smallest batch the band engine takes by default
 constexpr size_t band_xch_doubles(int nb) { return (size_t)nb * (2 * BAND_XD + 6); }
 
 // workspace of the band engine: [B] u32 sort keys | [B][4] i32 arrival counters | [B][NB_MAX * 22] f64 exchange records
@@ -3226,8 +3227,8 @@ inline int band_count(const FitParams& p) {
   return nb;
 }
 
-// u8 planes, 16-byte aligned, full-mask mode.  By default the band engine takes 4 <= B <= 400: below, one instance per call
-// gains nothing from four workgroups that each pay the fixed latencies of a workgroup; above, the per-workgroup latencies
+// u8 planes, 16-byte aligned, full-mask mode.  By default the band engine takes 48 <= B <= 400: below, it ties with the split
+// engine (33-38 us per call either way over two measurement sets) and the split engine stays; above, the per-workgroup latencies
 // (order, list, two reductions, two exchanges, axis, box: ~60 % of a half-size work item) cost more slot time than the shorter
 // ramp-up and tail give back.  LA3D_ENGINE=band / opt_engine pins it for any batch.
 inline bool band_eligible(const FitParams& p, bool vec, bool sample) {
@@ -3235,7 +3236,7 @@ inline bool band_eligible(const FitParams& p, bool vec, bool sample) {
   if (e == LA3D_ENGINE_INSTANCE || e == LA3D_ENGINE_SPLIT) return false;
   if (!vec || sample || p.mask == nullptr || !band_frame_ok(p.H, p.W, band_count(p))) return false;
   if (e == LA3D_ENGINE_BAND) return true;
-  return config().band_default && p.B >= 4 && p.B <= config().band_maxb;
+  return config().band_default && p.B >= BAND_MINB && p.B <= config().band_maxb;
 }
 
 template <int NB>
@@ -3474,7 +3475,7 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   // polygons: the side stage sits behind Shared, where the tile list / rank prefix go later (disjoint in time)
   const size_t poly_stage = poly ? (size_t)POLY_STAGE_BYTES : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (band_eligible(p, vec, sample)) {   // u8 planes, 4 <= B <= 400 (or pinned): two / four workgroups per instance, ONE launch
+  if (band_eligible(p, vec, sample)) {   // u8 planes, 48 <= B <= 400 (or pinned): two / four workgroups per instance, ONE launch
     return band_count(p) == 4 ? launch_fit_bands<4>(p, s, workspace) : launch_fit_bands<2>(p, s, workspace);
   }
   if (!sample && split_eligible(p, vec, ldsmask)) {

@@ -115,6 +115,10 @@ def _load_scene(scene: dict, depth_out: np.ndarray, k_out: np.ndarray) -> None:
     k_out[:] = np.asarray(K, dtype=np.float64).reshape(9)
 
 
+_PINNED: Dict[tuple, torch.Tensor] = {}   # pinned host buffers by (shape, dtype, tag): pinning costs far more than the copy it serves,
+                                            # so they outlive a pipeline object (a tool run creates one; bench.py several)
+
+
 class _Prepared:
     __slots__ = ("scenes", "H", "W", "depth", "K", "groups", "ready", "h2d0", "parity", "t_pack", "t_load", "nbytes", "grounds")
 
@@ -136,16 +140,17 @@ class ScenePipeline:
         self.t = timings if timings is not None else {}
         for k in ("load_s", "pack_s", "h2d_bytes", "h2d_s", "fit_s", "d2h_s", "write_s", "images", "instances", "boxes", "batches"):
             self.t.setdefault(k, 0.0)
-        self._pinned: Dict[tuple, torch.Tensor] = {}
         self._busy: Dict[tuple, torch.cuda.Event] = {}
 
     # ---- stage 1 (background thread): load, pack, start the uploads ------------------------------------------------------------
     def _pin(self, shape, dtype, tag):
         """a pinned host buffer per (shape, dtype, tag), allocated once (pinning costs far more than the copy it serves)"""
         key = (tuple(shape), dtype, tag)
-        if key not in self._pinned:
-            self._pinned[key] = torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
-        return self._pinned[key]
+        if key not in _PINNED:
+            if len(_PINNED) >= 48:
+                _PINNED.pop(next(iter(_PINNED)))
+            _PINNED[key] = torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
+        return _PINNED[key]
 
     def _pinned_depth(self, P, H, W, parity):
         ev = self._busy.get((P, H, W, parity))

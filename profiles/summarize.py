@@ -10,7 +10,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ("fit_instances_kernel", "fit_points_kernel", "prep_kernel", "unproject_kernel", "mask_counts_kernel",
+    for k in ("fit_instances_kernel", "fit_bands_kernel", "fit_points_kernel", "prep_kernel", "unproject_kernel", "mask_counts_kernel",
               "size_estimate_kernel", "launch_order_kernel", "poly_decode_kernel", "mask_stats_poly_kernel", "ratio_median_kernel",
               "align_count_kernel", "align_scan_kernel", "align_scatter_kernel", "align_apply_kernel", "rle_decode_kernel", "mask_stats", "scan_kernel", "plan_kernel", "walk_kernel", "axis_kernel", "final_kernel", "geo_kernel"):
         if k in name:

@@ -865,3 +865,43 @@ def test_fit_points_wave_per_cloud_equals_workgroup_per_cloud(la):
             assert np_(sw)[i] == st, (i, np_(sw)[i], st)
             if st == 0:
                 np.testing.assert_allclose(np_(bw)[i, :15], rec[:15], rtol=0, atol=1e-9 * max(1.0, np.abs(rec[:6]).max()))
+
+
+def test_convex_hull_yaw_stress_duplicates_and_collinear_runs(la):
+    """The convex-hull yaw runs its monotone chain in levels (16 lanes reduce chunks, 4 lanes quarters, one lane finishes): with exact
+    predicates the vertex sequence is the serial chain's; the fp64 cross products are rounded, so nearly collinear points or
+    duplicates straddling a chunk boundary may be kept by one form and dropped by the other.  Held to the oracle's serial chain with
+    the tolerance that distinction deserves: same rectangle (centre, dy, {dx, dz} as a set) or, on a tie between edges, the same area
+    - over lattice clouds (many duplicates, collinear runs), clouds on a circle (every point a vertex), rotated boxes, blobs and
+    stacks of equal x (formerly a one-off script, profiles/r03/stress_hull.py)."""
+    rs = np.random.RandomState(77)
+    clouds = []
+    for k in range(200):
+        kind = k % 5
+        n = int(rs.choice([3, 4, 5, 7, 16, 17, 33, 64, 65, 100, 257, 500, 512]))
+        if kind == 0:
+            pc = np.stack([rs.randint(0, 6, n), rs.rand(n), rs.randint(0, 5, n)], 1).astype(float)
+        elif kind == 1:
+            a = np.sort(rs.uniform(0, 2 * np.pi, n)); pc = np.stack([2 * np.cos(a), rs.rand(n), 1.5 * np.sin(a)], 1)
+        elif kind == 2:
+            pc = (rs.rand(n, 3) * [3, 1, 1]) @ O.rotate_y(rs.uniform(-3, 3)).T
+        elif kind == 3:
+            pc = rs.randn(n, 3) * [2, 0.3, 0.7]
+        else:
+            pc = np.stack([rs.randint(0, 3, n) * 1.0, rs.rand(n), rs.rand(n)], 1)
+        clouds.append(pc + [0, 0, 6])
+    boxes, status, aux = la.fit_points(clouds, None, None, "convex_hull")
+    boxes, status = np_(boxes), np_(status)
+    fitted = 0
+    for i, c in enumerate(clouds):
+        rec, st, _ = O.fit_points(c, None, False, "convex_hull")
+        assert st == status[i], (i, st, status[i])
+        if st:
+            continue
+        fitted += 1
+        same = (np.allclose(boxes[i, [0, 1, 2, 4]], rec[[0, 1, 2, 4]], rtol=0, atol=1e-9) and
+                np.allclose(sorted(boxes[i, [3, 5]]), sorted(rec[[3, 5]]), rtol=0, atol=1e-9))
+        if not same:   # a different edge of (nearly) equal area
+            ar_g, ar_r = boxes[i, 3] * boxes[i, 5], rec[3] * rec[5]
+            assert abs(ar_g - ar_r) <= 1e-9 * max(1.0, ar_r), (i, len(c), boxes[i, :6], rec[:6])
+    assert fitted > 150
