@@ -233,7 +233,8 @@ __device__ inline void tile_coords(const TileCtx& c, const unsigned short* list,
 // Returns the TG nibbles packed into one word.
 template <int PASS, bool LK, bool SURV = false>
 __device__ inline unsigned tile_fetch(const TileCtx& c, const float* __restrict__ dpl, const unsigned* bits,
-                                      const unsigned short* list, int nsteps, bool dense, int j0, int rev_base, uint4* dq) {
+                                      const unsigned short* list, int nsteps, bool dense, int j0, int rev_base, uint4* dq,
+                                      int* tcs = nullptr) {   // tcs (SURV): the tiles' coordinates for tile_compute, which then need not look them up again
   unsigned nib[TG];
   int txs[TG], tys[TG], ent[TG];
 #pragma unroll
@@ -242,9 +243,16 @@ __device__ inline unsigned tile_fetch(const TileCtx& c, const float* __restrict_
     nib[g] = 0; txs[g] = 0; tys[g] = 0; ent[g] = 0x7fffffff;
     dq[g] = make_uint4(0u, 0u, 0u, 0u);
     if (j < nsteps) {
-      tile_coords<SURV>(c, list, dense, j, rev_base, &txs[g], &tys[g]);
+      if (SURV) {   // survivor j -> list entry -> tile: two dependent LDS reads, done once per tile
+        ent[g] = __builtin_amdgcn_readfirstlane((int)c.surv[j]);
+        const unsigned t = __builtin_amdgcn_readfirstlane((unsigned)list[ent[g]]);
+        txs[g] = (int)(t & 0xffu); tys[g] = (int)(t >> 8);
+        if (tcs) tcs[g] = (int)t;
+      } else {
+        tile_coords<false>(c, list, dense, j, rev_base, &txs[g], &tys[g]);
+      }
       if (LK && c.compact) {   // uniform
-        ent[g] = SURV ? __builtin_amdgcn_readfirstlane((int)c.surv[j]) : (rev_base >= 0 ? rev_base - j : j);
+        if (!SURV) ent[g] = rev_base >= 0 ? rev_base - j : j;
         nib[g] = (bits[ent[g] * 8 + c.r] >> (c.cq * 4)) & 0xFu;   // rows past the frame were stored as zeros
       } else {
         const int row = tys[g] * 8 + c.r;
@@ -292,7 +300,7 @@ __device__ inline void tile_range(const TileCtx& c, int e, unsigned nib, const u
 // stage 2: the pixel math of a step on quads dq / nibbles pk (all lanes; unmasked lanes carry zeros / NaNs)
 template <int PASS, bool CHK, bool LK = false, bool SURV = false, bool RNG = false, bool SPEC = false>
 __device__ inline void tile_compute(const TileCtx& c, const unsigned short* list, int nsteps, bool dense, int j0, int rev_base,
-                                    const uint4* dq, unsigned pk, double* sv, int* n) {
+                                    const uint4* dq, unsigned pk, double* sv, int* n, const int* tcs = nullptr) {
 #pragma unroll
   for (int g = 0; g < TG; ++g) {
     const int j = j0 + g;
@@ -301,7 +309,8 @@ __device__ inline void tile_compute(const TileCtx& c, const unsigned short* list
     const unsigned nib = (pk >> (4 * g)) & 0xFu;
     if (dense && __ballot(nib != 0) == 0) continue;
     int tx, ty;
-    tile_coords<SURV>(c, list, dense, j, rev_base, &tx, &ty);
+    if (SURV && tcs) { tx = tcs[g] & 0xff; ty = tcs[g] >> 8; }
+    else tile_coords<SURV>(c, list, dense, j, rev_base, &tx, &ty);
     const unsigned db[4] = {dq[g].x, dq[g].y, dq[g].z, dq[g].w};
     const double vd = (double)(ty * 8 + c.r), ud = (double)(tx * 32 + c.cq * 4);
     const double r0 = fma(c.a00, ud, fma(c.a01, vd, c.a02));
@@ -405,8 +414,9 @@ __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__
       const int j0 = __builtin_amdgcn_readfirstlane((int)off);
       if (j0 >= nsurv) break;
       uint4 dq[TG];
-      const unsigned pk = tile_fetch<PASS, LK, true>(c, dpl, bits, list, nsurv, false, j0, -1, dq);
-      tile_compute<PASS, CHK, LK, true, false, SPEC>(c, list, nsurv, false, j0, -1, dq, pk, sv, &n);
+      int tcs[TG];
+      const unsigned pk = tile_fetch<PASS, LK, true>(c, dpl, bits, list, nsurv, false, j0, -1, dq, tcs);
+      tile_compute<PASS, CHK, LK, true, false, SPEC>(c, list, nsurv, false, j0, -1, dq, pk, sv, &n, tcs);
     }
   } else
   if (!(LA3D_CULL && LK) && PASS == 1 && qhead != nullptr && !dense) {
