@@ -12,7 +12,12 @@ the timed region.  Full-mask mode, ground=None, K=[[500,0,320],[0,500,240],[0,0,
 
 N > 1: one process per GPU, instances sharded across ranks (weak scaling: 1024 per rank, no data-path
 collective); the only communication is ONE gather of every rank's (steps*B, 39) box tensor + status to
-rank 0 over RCCL at the end of the timed region.  Rank 0 prints one JSON line.
+rank 0 over RCCL after the K timed fit steps (timed on its own: gather_ms).  Rank 0 prints one JSON line.
+
+Other modes (never the headline): --config4 IMAGES = the north_star partitioning (one global metadata list -> plan_shards -> every
+rank materialises and fits only its image range -> one gather; strong scaling, per-rank fit times); --end-to-end IMAGES = host-resident
+scenes -> records through labelany3d_amd.fit_scenes with the pack / H2D / fit / D2H split; --rle / --poly / --subsample / --area-hint /
+--config3 / --config5 / --streams as their help texts say.
 """
 import argparse
 import json
@@ -799,8 +804,9 @@ def main():
             "roofline": {
                 "bound": "hbm",
                 "kernel": ("fit_instances_kernel<VEC,LDSMASK,SAMPLE=1> (instance engine, reference-subsample mode)" if args.subsample else
-                           "fit_instances_kernel<VEC,LDSMASK,SAMPLE=0,TILED,SRC,RET> (instance engine; u8 planes with 272 < B <= 1280 take "
-                           "the retaining build RET=4, larger batches and run-length / polygon input RET=0; B <= 272 (u8) / 288 (run lengths, polygons) takes the split engine)"),
+                           "fit_instances_kernel<VEC,LDSMASK,SAMPLE=0,TILED,SRC,RET> (instance engine; u8 planes with 400 < B <= 1280 take "
+                           "the retaining build RET=4, larger batches and run-length / polygon input RET=0 with pass-B tile culling; u8 planes with "
+                           "48 <= B <= 400 take the band engine fit_bands_kernel<NB>, smaller u8 batches and B <= 288 run lengths / polygons the split engine)"),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
