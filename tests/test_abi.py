@@ -320,3 +320,30 @@ def test_bad_scheduling_options_are_rejected():
     with pytest.raises(ValueError):
         with options.scheduling(build="huge"):
             pass
+
+
+def test_scheduling_options_are_thread_local_and_validated():
+    """labelany3d_amd.options: the per-call codes of la3d_fit_args::opt_*; a `scheduling` block pins them for ITS thread only and
+    restores the previous state on exit (no GPU needed)."""
+    import threading
+
+    from labelany3d_amd import options
+
+    assert options.codes() == (0, 0, 0)
+    assert options.codes(engine="band", launch_order=False, build="retaining") == (3, 1, 2)
+    seen = {}
+
+    def other():
+        seen["other"] = options.codes()
+
+    with options.scheduling(engine="split", launch_order=True):
+        assert options.codes() == (2, 2, 0)
+        assert options.codes(engine="instance") == (1, 2, 0)          # an explicit argument wins over the block
+        t = threading.Thread(target=other)
+        t.start(); t.join()
+        with options.scheduling(build="plain", launch_order=None):
+            assert options.codes() == (2, 0, 1)
+        assert options.codes() == (2, 2, 0)
+    assert options.codes() == (0, 0, 0) and seen["other"] == (0, 0, 0)
+    with pytest.raises(ValueError):
+        options.codes(build="big")

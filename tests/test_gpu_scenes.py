@@ -98,3 +98,34 @@ def test_scene_pipeline_in_memory_matches_disk(tmp_path):
     for k in mem:
         assert json.dumps(mem[k]) == json.dumps(disk[k]), k
     assert timings["images"] == 20 and timings["h2d_bytes"] > 20 * 480 * 640 * 4 and timings["fit_s"] > 0
+
+
+def test_scene_pipeline_mixed_frame_sizes_and_rle_strings():
+    """images of two frame sizes in one run (batches are formed per size) and COCO run lengths given as COMPRESSED strings (what
+    COCONut's annotation files hold): the records of every scene equal those of the scene fitted on its own"""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from labelany3d_amd import fit_scenes as F
+
+    a, _ = F.synthetic_scenes(9, seed=21, H=480, W=640, rle_fraction=0.5)
+    b, _ = F.synthetic_scenes(7, seed=22, H=384, W=512, rle_fraction=0.5)
+    scenes = [x for pair in zip(a, b) for x in pair] + a[7:]
+    for i, sc in enumerate(scenes):
+        sc["name"] = f"s{i}"
+        for an in sc["annotations"]:
+            seg = an["segmentation"]
+            if isinstance(seg, dict):
+                seg["counts"] = O.rle_to_string(seg["counts"])     # pycocotools' compressed form
+    together = {sc["name"]: recs for sc, recs in F.ScenePipeline(batch_images=4, write=False).run(scenes)}
+    assert set(together) == {sc["name"] for sc in scenes}
+    flat = lambda recs: np.array([np.concatenate([r["center_cam"], r["dimensions"], np.ravel(r["R_cam"]), np.ravel(r["bbox3D_cam"])]) for r in recs]).reshape(-1, 39)  # noqa: E731
+    for sc in scenes:
+        alone = [recs for _, recs in F.ScenePipeline(batch_images=1, write=False).run([sc])][0]
+        both = together[sc["name"]]
+        assert [(r["obj_id"], r["category_name"]) for r in alone] == [(r["obj_id"], r["category_name"]) for r in both], sc["name"]
+        # (small batches of run-length / polygon input take the split engine, whose fp64 partial sums are grouped by the batch's
+        # concatenated tile list: the same instance in a different batch agrees to rounding, INTEGRATION.md "Bitwise reproducibility")
+        np.testing.assert_allclose(flat(alone)[:, :15], flat(both)[:, :15], rtol=1e-10, atol=1e-10, err_msg=sc["name"])
+        np.testing.assert_allclose(flat(alone)[:, 15:], flat(both)[:, 15:], rtol=0, atol=2e-2, err_msg=sc["name"])
