@@ -201,6 +201,7 @@ struct Keep {
 
 struct TileCtx {
   int W, H, ntx, r, cq;
+  unsigned loff;   // byte offset of this lane's depth quad inside a tile: (r W + 4 cq) floats
   // compacted bit image (plain build): list entry e owns the eight row words of its tile at words [8e, 8e + 8) of the image
   // region, and the depth quads of list entries < keepn stay in the LDS that frees (1 KiB per tile) between the passes
   int compact, keepn;
@@ -231,7 +232,11 @@ __device__ inline void tile_coords(const TileCtx& c, const unsigned short* list,
 
 // stage 1 of a step (TG consecutive list entries of one wave): bit-image nibbles, then all depth loads back to back.
 // Returns the TG nibbles packed into one word.
-template <int PASS, bool LK, bool SURV = false>
+// ZERO = false: dq is NOT cleared - lanes without a mask bit hold whatever their registers held (an empty asm statement
+// "defines" the quad without an instruction).  That is harmless by construction: every consumer gates a quad through its
+// nibble (pass A ANDs the validity word into the bits, pass B ORs its complement, tile_range does both), and saves four moves
+// per tile.
+template <int PASS, bool LK, bool SURV = false, bool ZERO = true>
 __device__ inline unsigned tile_fetch(const TileCtx& c, const float* __restrict__ dpl, const unsigned* bits,
                                       const unsigned short* list, int nsteps, bool dense, int j0, int rev_base, uint4* dq,
                                       int* tcs = nullptr) {   // tcs (SURV): the tiles' coordinates for tile_compute, which then need not look them up again
@@ -241,7 +246,12 @@ __device__ inline unsigned tile_fetch(const TileCtx& c, const float* __restrict_
   for (int g = 0; g < TG; ++g) {
     const int j = j0 + g;
     nib[g] = 0; txs[g] = 0; tys[g] = 0; ent[g] = 0x7fffffff;
-    dq[g] = make_uint4(0u, 0u, 0u, 0u);
+    if (ZERO) dq[g] = make_uint4(0u, 0u, 0u, 0u);
+    else {
+      u32x4 t;
+      asm volatile("" : "=v"(t));
+      dq[g] = make_uint4(t.x, t.y, t.z, t.w);
+    }
     if (j < nsteps) {
       if (SURV) {   // survivor j -> list entry -> tile: two dependent LDS reads, done once per tile
         ent[g] = __builtin_amdgcn_readfirstlane((int)c.surv[j]);
@@ -264,7 +274,11 @@ __device__ inline unsigned tile_fetch(const TileCtx& c, const float* __restrict_
 #pragma unroll
   for (int g = 0; g < TG; ++g) {
     if (LK && PASS == 1 && ent[g] < c.keepn) dq[g] = c.keep[ent[g] * 64 + (c.r * 8 + c.cq)];   // kept by pass A
-    else if (nib[g]) dq[g] = *reinterpret_cast<const uint4*>(dpl + (long long)(tys[g] * 8 + c.r) * c.W + txs[g] * 32 + c.cq * 4);
+    else if (nib[g]) {
+      // uniform tile origin (scalar registers) + the lane's constant byte offset: the load takes its address as SGPR base + VGPR offset
+      const float* tp = dpl + ((long long)(tys[g] * 8) * c.W + txs[g] * 32);
+      dq[g] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(tp) + c.loff);
+    }
     pk |= nib[g] << (4 * g);
   }
   return pk;
@@ -277,23 +291,27 @@ __device__ inline unsigned tile_fetch(const TileCtx& c, const float* __restrict_
 constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
 template <bool CHK>
 __device__ inline void tile_range(const TileCtx& c, int e, unsigned nib, const unsigned* db) {
-  unsigned lo = 0xffffffffu, hi = 0u;
+  // per pixel: the validity word m (0 / -1) and db & m are the pixel math's own values (same expressions: shared after inlining);
+  // db | ~m is one v_bfi_b32 (m ? db : ones).  The cross-lane steps carry the operation's identity as `old`, which lets the
+  // compiler fold every move into its min / max (v_min_u32_dpp: one instruction per step instead of three).
+  unsigned w[4], v[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     int m = -(int)((nib >> k) & 1u);
-    if (CHK) m &= ((int)(db[k] & 0x7fffffffu) - 0x7f800000) >> 31;
-    lo = min(lo, db[k] | ~(unsigned)m);
-    hi = max(hi, db[k] & (unsigned)m);
+    if (CHK) m = (((int)(db[k] & 0x7fffffffu) - 0x7f800000) >> 31) & m;
+    v[k] = db[k] & (unsigned)m;
+    asm("v_bfi_b32 %0, %1, %2, -1" : "=v"(w[k]) : "v"(m), "v"(db[k]));
   }
+  unsigned lo = min(min(w[0], w[1]), min(w[2], w[3])), hi = max(max(v[0], v[1]), max(v[2], v[3]));
   lo = min(lo, (unsigned)dpp_i32<DPP_XOR1>((int)lo)); hi = max(hi, (unsigned)dpp_i32<DPP_XOR1>((int)hi));
   lo = min(lo, (unsigned)dpp_i32<DPP_XOR2>((int)lo)); hi = max(hi, (unsigned)dpp_i32<DPP_XOR2>((int)hi));
   lo = min(lo, (unsigned)dpp_i32<DPP_HALF_MIRROR>((int)lo)); hi = max(hi, (unsigned)dpp_i32<DPP_HALF_MIRROR>((int)hi));
   lo = min(lo, (unsigned)dpp_i32<DPP_MIRROR>((int)lo)); hi = max(hi, (unsigned)dpp_i32<DPP_MIRROR>((int)hi));
   // rows 1 and 3 take in lane 15 of the row before them, then rows 2 and 3 lane 31: row 3 holds the wave's result
-  lo = min(lo, (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, DPP_ROW_BCAST15, 0xa, 0xf, false));
-  hi = max(hi, (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, DPP_ROW_BCAST15, 0xa, 0xf, false));
-  lo = min(lo, (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, DPP_ROW_BCAST31, 0xc, 0xf, false));
-  hi = max(hi, (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, DPP_ROW_BCAST31, 0xc, 0xf, false));
+  lo = min(lo, (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)lo, DPP_ROW_BCAST15, 0xa, 0xf, false));
+  hi = max(hi, (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, DPP_ROW_BCAST15, 0xa, 0xf, false));
+  lo = min(lo, (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)lo, DPP_ROW_BCAST31, 0xc, 0xf, false));
+  hi = max(hi, (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, DPP_ROW_BCAST31, 0xc, 0xf, false));
   if (c.r * 8 + c.cq == 63) *reinterpret_cast<uint2*>(c.rng + 2 * e) = make_uint2(lo, hi);
 }
 
@@ -344,6 +362,7 @@ __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__
   constexpr bool LK = LA3D_LDSKEEP0 && RET == 0;
   TileCtx c;
   c.W = p.W; c.H = p.H; c.ntx = p.ntx; c.r = lane >> 3; c.cq = lane & 7;
+  c.loff = (unsigned)(c.r * p.W + c.cq * 4) * 4u;
   c.compact = LK ? compact : 0; c.keepn = 0; c.keep = nullptr;
   c.rng = nullptr; c.surv = nullptr;
   if (LK && compact) {   // uniform: the image region behind the compacted entries holds depth tiles between the passes
@@ -415,7 +434,7 @@ __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__
       if (j0 >= nsurv) break;
       uint4 dq[TG];
       int tcs[TG];
-      const unsigned pk = tile_fetch<PASS, LK, true>(c, dpl, bits, list, nsurv, false, j0, -1, dq, tcs);
+      const unsigned pk = tile_fetch<PASS, LK, true, false>(c, dpl, bits, list, nsurv, false, j0, -1, dq, tcs);
       tile_compute<PASS, CHK, LK, true, false, SPEC>(c, list, nsurv, false, j0, -1, dq, pk, sv, &n, tcs);
     }
   } else
@@ -430,13 +449,13 @@ __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__
       const int j0 = kept + __builtin_amdgcn_readfirstlane((int)off);
       if (j0 >= nsteps) break;
       uint4 dq[TG];
-      const unsigned pk = tile_fetch<PASS, LK>(c, dpl, bits, list, nsteps, false, j0, rev_base, dq);
+      const unsigned pk = tile_fetch<PASS, LK, false, false>(c, dpl, bits, list, nsteps, false, j0, rev_base, dq);
       tile_compute<PASS, CHK, LK, false, false, SPEC>(c, list, nsteps, false, j0, rev_base, dq, pk, sv, &n);
     }
   } else {
     for (int j0 = jstart; j0 < nsteps; j0 += NWAVE * TG) {
       uint4 dq[TG];
-      const unsigned pk = tile_fetch<PASS, LK>(c, dpl, bits, list, nsteps, dense, j0, rev_base, dq);
+      const unsigned pk = tile_fetch<PASS, LK, false, false>(c, dpl, bits, list, nsteps, dense, j0, rev_base, dq);
       tile_compute<PASS, CHK, LK, false, RNG && LK, SPEC>(c, list, nsteps, dense, j0, rev_base, dq, pk, sv, &n);
     }
   }

@@ -232,8 +232,11 @@ __device__ inline void write_box(double* out, const double* Rg, double cyaw, dou
 // R_cam row each (the single-thread version is ~3000 dependent fp64 instructions, i.e. ~10 us of pure
 // latency when a whole kernel consists of it).  Bit-identical to write_box.
 // DPP cross-lane moves (see the wave reductions below)
+// (full row / bank masks and a control whose source lanes all exist: written as a move without an `old` value and with
+// bound_ctrl, the compiler folds it into the consuming 32-bit operation - v_add_u32_dpp, v_min_u32_dpp, ...: one instruction
+// per reduction step instead of three; fp64 steps become two moves + the operation instead of four + it)
 template <int CTRL>
-__device__ inline int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+__device__ inline int dpp_i32(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
 template <int CTRL>
 __device__ inline double dpp_f64(double v) {
   return __hiloint2double(dpp_i32<CTRL>(__double2hiint(v)), dpp_i32<CTRL>(__double2loint(v)));
