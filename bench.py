@@ -650,6 +650,27 @@ def main():
     # measured read-only stream ceiling of THIS run (also what brings the chip to its working clocks before the warm-up steps:
     # a 20-step timed region entered from an idle chip reads ~5 % slower, profiles/r03/exp_step_ramp.py)
     stream_GBps, _ = measured_stream_ceiling(masks)
+    # secondary figure, before the warm-up: the SAME serial step in a long back-to-back loop (>= 40 ms of GPU time, HIP events on
+    # the launch stream) - what a caller that keeps fitting batches sees.  It also leaves the chip in the power / clock state of
+    # this kernel rather than of the pure reader above: a 20-step region entered after 5 warm-up steps otherwise reads 2-4 us per
+    # step slower than the same 20 steps after 50 (profiles/r04/exp_driver_overhead.py; the timed K steps below are unchanged).
+    steady = None
+    if not args.config3 and len(streams) == 1:
+        se0, se1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n_ss, tot_ms, best_ms = 0, 0.0, None
+        for _ in range(4):
+            torch.cuda.synchronize()
+            se0.record(stream)
+            for _k in range(100):
+                run(slot=0, stream=stream)
+            se1.record(stream)
+            torch.cuda.synchronize()
+            ms = se0.elapsed_time(se1) / 100
+            n_ss += 100; tot_ms += ms * 100
+            best_ms = ms if best_ms is None else min(best_ms, ms)
+            if tot_ms >= 40.0:
+                break
+        steady = (best_ms, n_ss)
     for _ in range(warmup):
         run(slot=0, stream=stream)
     if dist is not None:  # warm the communicator outside the timed region
@@ -804,8 +825,8 @@ def main():
             "roofline": {
                 "bound": "hbm",
                 "kernel": ("fit_instances_kernel<VEC,LDSMASK,SAMPLE=1> (instance engine, reference-subsample mode)" if args.subsample else
-                           "fit_instances_kernel<VEC,LDSMASK,SAMPLE=0,TILED,SRC,RET> (instance engine; u8 planes with 400 < B <= 1280 take "
-                           "the retaining build RET=4, larger batches and run-length / polygon input RET=0 with pass-B tile culling; u8 planes with "
+                           "fit_instances_kernel<VEC,LDSMASK,SAMPLE=0,TILED,SRC,RET=0> (instance engine, plain build: 64 VGPRs, four workgroups per CU, "
+                           "pass-B tile culling; the 128-VGPR retaining build RET=4 is opt-in since round 4; u8 planes with "
                            "48 <= B <= 400 take the band engine fit_bands_kernel<NB>, smaller u8 batches and B <= 288 run lengths / polygons the split engine)"),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
@@ -840,6 +861,12 @@ def main():
                         "step's VALU instructions (fp64 ~5.2 cycles per wave-instruction), from the shader-side counters of the same profile set.",
             },
         }
+        if steady is not None:
+            out["steady_state"] = {
+                "value": world * B / (steady[0] * 1e-3), "unit": "boxes/s", "ms_per_step": steady[0], "steps_run": steady[1],
+                "note": "secondary: the same serial step (one batch after the other on one stream) in back-to-back loops of 100, HIP events, "
+                        "best loop, run BEFORE the W warm-up steps (rank 0's figure x ranks); the headline `value` is the K steps the driver asked for",
+            }
         if pipelined is not None:
             out["pipelined"] = {
                 "value": world * steps * B / pipelined, "unit": "boxes/s", "ms_per_step": pipelined / steps * 1e3, "streams": 2,

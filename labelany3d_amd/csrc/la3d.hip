@@ -10,8 +10,8 @@
 // DESIGN.md.  This file holds the INSTANCE ENGINE of la3d_fit_instances (one workgroup per instance; used for
 // B > 272 (u8 planes) / 288 (run lengths, polygon parts), for the fused instance filter, for reference-subsample mode and
 // for frames the split engine does not take - la3d_split.hip is the other engine) and every other kernel of the C-ABI.  `fit_instances_kernel` in short:
-//   one 512-thread workgroup (8 wave64) per instance, 64 VGPRs / 40 KB LDS -> 4 workgroups per CU (the "retaining" build for
-//            u8 planes up to 1280 instances: 128 VGPRs, 2 workgroups per CU, depth tiles kept on chip between the passes);
+//   one 512-thread workgroup (8 wave64) per instance, 64 VGPRs / 40 KB LDS -> 4 workgroups per CU (the opt-in "retaining" build:
+//            128 VGPRs, 2 workgroups per CU, depth tiles kept in registers between the passes - the default of rounds 2-3 for u8 planes);
 //   order    256 < B <= 3 resident sets: which instance a workgroup fits is decided in the kernel (order_select) from the sort
 //            keys of ONE estimate kernel (or the caller's area hints: no helper launch) - size-balanced, speed only;
 //   phase 0  streams the u8 mask plane once with 16-byte non-temporal loads (or decodes COCO run lengths / rasterises polygon
@@ -909,6 +909,19 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
 #define LA3D_STAMP(k) do { } while (0)
 #endif
   LA3D_STAMP(0);
+  if (RET == 0 && SRC == 0 && !SAMPLE && p.stagger_ticks > 0 && p.order_nch > 0 && blockIdx.x < 1024) {
+    // Plain build, u8 planes, size-ordered launch (round 4): the four groups of 256 workgroups that fill the chip start one
+    // stagger period apart, the group of the 256 LARGEST instances first (group g of the launch order = blocks [256 g, 256 g + 256)).
+    // Every instance streams the same H*W mask bytes whatever its size; started together, the 1024 streams share the bandwidth and
+    // nobody's passes begin before ~50 us.  Staggered, the large instances stream at four times the share and are in their (long)
+    // passes - VALU work - while the smaller ones, which have the slack, stream.  Measured, us per call, without / with 10 us
+    // (profiles/r04/r04_stagger.txt): config-2 masks B = 448 / 640 / 1024 / 1280 / 2048: 71.6 / 80.6 / 103.6 / 125.6 / 176.2 ->
+    // 66.9 / 74.8 / 99.7 / 118.2 / 170.0; config-5 masks B = 512 / 1024 / 2048: 75.1 / 91.4 / 144.1 -> 69.9 / 83.2 / 139.6; neutral
+    // from 4096 up.  Speed only: records do not depend on it.  (Run-length / polygon input has no stream to spread: slower there.)
+    const unsigned long long t0 = wall_clock64();
+    const unsigned long long w = (unsigned long long)p.stagger_ticks * (blockIdx.x >> 8);
+    while (wall_clock64() - t0 < w) __builtin_amdgcn_s_sleep(32);
+  }
   if (RET > 0 && SRC == 0 && p.stagger_ticks > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
     // retaining build, two workgroups per CU: the second-dispatched one (block b + 256 shares CU b % 256 with block b - measured
     // placement, speed only) holds back for about the time the first needs to stream its mask plane at full bandwidth, so that
@@ -1028,6 +1041,7 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
   double Mg[9];   // wave-uniform: moved to SGPRs
 #pragma unroll
   for (int i = 0; i < 9; ++i) Mg[i] = uniform_f64(sh->M[i]);
+  LA3D_STAMP(13);
 
   // reference-subsample mode: the reference subsamples when in_pc.shape[0] > 500 (src/util_3dbox.py:123) - needs N first.
   // Sampled instances need no tile list (their 500 points are picked through the block prefix, which shares its LDS).
@@ -1077,6 +1091,7 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
       }
       if (lane == 0) sh->scan[wave] = (unsigned)wcount;
       __syncthreads();
+      LA3D_STAMP(14);
       for (int w = 0; w < NWAVE; ++w) {
         const int c = (int)sh->scan[w];
         if (w < wave) base += c;
@@ -1141,6 +1156,7 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
         }
       }
     }
+    LA3D_STAMP(15);
     __syncthreads();
   }
 
@@ -3328,20 +3344,22 @@ int launch_fit(const FitParams& p, size_t lds, hipStream_t s, void* workspace = 
 #ifndef LA3D_RET
 #define LA3D_RET 4
 #endif
-constexpr int RETAIN_MAXB_DEFAULT = 1280;
+constexpr int RETAIN_MAXB_DEFAULT = 0;   // the retaining build is opt-in since round 4 (see below)
 inline int retain_steps(const FitParams& p) {
   // The 128-VGPR build keeps up to 160 depth tiles per instance on chip between the passes: two
   // workgroups per CU instead of four, the second one of every CU staggered by the time a mask plane takes to stream.
-  // Measured (u8 planes, us per call, retaining vs plain build): config-2 masks B = 384 / 512 / 768 / 1024 / 1280: 78 / 82 / 91 /
-  // 108 / 128 vs 86 / 91 / 100 / 111 / 131; config-5 masks B = 512 / 768 / 1024 / 1280: 84 / 86 / 90 / 110 vs 95 / 101 / 110 / 116;
-  // beyond ~1.5 k instances the plain build's four workgroups per CU win (10 % at B >= 2048).  opt_build / LA3D_RETAIN pin the
-  // choice, LA3D_RETAIN_MAXB moves the threshold.
+  // Rounds 2-3 it was the default for u8 planes up to 1280 instances (108 vs 111 us at B = 1024).  Round 4's plain build - pass-B
+  // culling, the LDS-kept tiles, the shorter pixel and reduction code - has overtaken it (u8 planes, us per call, retaining vs
+  // plain, profiles/r04/r04_plain_vs_retaining.txt): config-2 masks B = 448 / 512 / 768 / 1024 / 1280 / 1536: 73.6 / 78.7 / 90.1 /
+  // 106.5 / 128.5 / 143.8 vs 71.6 / 76.3 / 85.8 / 104.0 / 125.3 / 139.4; config-5 masks: 80.1 / 81.6 / 83.8 / 88.9 / 104.6 / 120.4 vs
+  // 73.9 / 75.6 / 83.1 / 90.2 / 100.2 / 115.1.  So the plain build is the default everywhere; opt_build / LA3D_RETAIN=1 pin the
+  // retaining one, LA3D_RETAIN_MAXB=n makes it the default again up to n instances.
   const Config& c = config();
   const int pin = p.opt_build != LA3D_BUILD_DEFAULT ? p.opt_build : c.retain;
   if (pin == LA3D_BUILD_PLAIN) return 0;
   if (pin == LA3D_BUILD_RETAINING) return LA3D_RET;
   // a caller that has switched the launch order off is pipelining batches on several streams: that regime behaves like one
-  // large batch, where the plain build wins (81.6 vs 87.0 us per 1024-instance call)
+  // large batch, where the plain build wins by more (81.6 vs 87.0 us per 1024-instance call)
   if (!balance_enabled(p)) return 0;
   return p.B <= (c.retain_maxb >= 0 ? c.retain_maxb : RETAIN_MAXB_DEFAULT) ? LA3D_RET : 0;
 }
@@ -3578,6 +3596,13 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
           p.stagger_ticks = (int)(us * 100.0);
         }
         return launch_fit<true, true, false, true, LA3D_RET>(p, tot, s, workspace);
+      }
+      if (mask != nullptr && B > 256) {
+        // u8 planes: the resident groups start 0.76 x (256 x H*W bytes at ~6 TB/s) apart - 10 us for 640x480 (the kernel applies it
+        // only under the size-ordered launch; LA3D_STAGGER_US overrides, 0 switches it off)
+        double us = 0.76 * 256.0 * (double)p.HW / 6.0e6;
+        if (config().stagger_us >= 0) us = config().stagger_us;
+        p.stagger_ticks = (int)(us * 100.0);
       }
       return launch_fit<true, true, false, true>(p, fixed + ((size_t)cap * 2 > poly_stage ? (size_t)cap * 2 : poly_stage), s, workspace);
     }

@@ -481,7 +481,7 @@ struct FitParams {
   const int* debug_perm;   // measurement build only (profiles/r03/order_search.py): block -> instance table set by la3d_debug_set_block_order
 #endif
   int lds_keep_off;    // retaining build: byte offset in dynamic LDS of the per-wave kept step (0: none)
-  int stagger_ticks;   // retaining build: the second-dispatched workgroup of every CU starts this many 100 MHz ticks late (0: off)
+  int stagger_ticks;   // u8 planes: resident groups of 256 workgroups start this many 100 MHz ticks apart (0: off; see fit_instances_kernel)
   // instance filter fused into the fit (run-length / polygon input): boundary < 0 = off
   int filter_boundary, filter_min_area, filter_max_edge;
   int* filter_stats;   // [B][4] area, rows, span, edge (may be null)

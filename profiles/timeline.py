@@ -99,6 +99,11 @@ def one(B, sizes="bench"):
           "pass B end (wave 0) -> all waves in %.2f -> box written %.2f -> end %.2f" %
           (np.mean(sub[:, 0] - t[:, 3]), np.mean(sub[:, 1] - sub[:, 0]), np.mean(t[:, 4] - sub[:, 1]),
            np.mean(sub[:, 2] - t[:, 5]), np.mean(sub[:, 3] - sub[:, 2]), np.mean(t[:, 6] - sub[:, 3])))
+    ls = (tl[:, 13:16] - t0) / 100.0           # stamps inside the list stage (thread 0): geometry read, first barrier, before the last barrier
+    late = np.argsort(t[:, 6])[-64:]
+    for nm, sel in (("all", slice(None)), ("the 64 latest finishers", late)):
+        print("  list stage (%s), mean us: stream done -> M read %.2f -> row words / ballots / barrier %.2f -> list + compaction written %.2f -> barrier + survivor list %.2f" %
+              (nm, np.mean(ls[sel, 0] - t[sel, 1]), np.mean(ls[sel, 1] - ls[sel, 0]), np.mean(ls[sel, 2] - ls[sel, 1]), np.mean(t[sel, 2] - ls[sel, 2])))
     d = np.diff(t, axis=1)
     print("  durations: " + "  ".join(f"{n}={d[:, k].mean():.1f} (max {d[:, k].max():.1f})"
                                       for k, n in enumerate(["stream", "list", "passA", "axis", "passB", "box"])))
