@@ -523,6 +523,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU per step (config 2: 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-steady", action="store_true", help="skip the steady-state secondary figure (counter passes: profiles/run_profile.sh "
+                                                             "divides the counters by the launches of --steps + --warmup)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the secondary two-stream pipelined measurement")
     ap.add_argument("--rle", action="store_true",
                     help="feed the masks as COCO run lengths (la3d_fit_instances_rle) instead of u8 planes; NOT the "
@@ -655,7 +657,7 @@ def main():
     # this kernel rather than of the pure reader above: a 20-step region entered after 5 warm-up steps otherwise reads 2-4 us per
     # step slower than the same 20 steps after 50 (profiles/r04/exp_driver_overhead.py; the timed K steps below are unchanged).
     steady = None
-    if not args.config3 and len(streams) == 1:
+    if not args.config3 and len(streams) == 1 and not args.no_steady:
         se0, se1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n_ss, tot_ms, best_ms = 0, 0.0, None
         for _ in range(4):

@@ -13,7 +13,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $REPO/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-pipelined $EXTRA"
+BENCH="python $REPO/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-pipelined --no-steady $EXTRA"
 # 1) per-kernel time of the default-length command
 if [ "${LIGHT:-0}" != "1" ]; then
   rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o stats -- python $REPO/bench.py --no-cpu-baseline --no-pipelined $EXTRA > $OUT/stats.log 2>&1
