@@ -59,6 +59,10 @@ const Config& config() {
     k.retain_nomask = (e && e[0] == '1') ? 1 : 0;
     e = getenv("LA3D_LDSKEEP");
     k.ldskeep = !(e && e[0] == '0');
+    e = getenv("LA3D_CULL_MIN");          // pass-B culling threshold (active tiles) for every input; unset: 224, u8 planes LA3D_CULL_MIN_U8
+    k.cull_min = e ? atoi(e) : 0;
+    e = getenv("LA3D_CULL_MIN_U8");
+    k.cull_min_u8 = (e && atoi(e) > 0) ? atoi(e) : 128;
     e = getenv("LA3D_STAGGER_US");
     k.stagger_us = e ? atof(e) : -1.0;
     e = getenv("LA3D_SPLIT_GRID");
@@ -185,6 +189,9 @@ constexpr int TG = LA3D_TG;
 #ifndef LA3D_LDSKEEP0
 #define LA3D_LDSKEEP0 1
 #endif
+#ifndef LA3D_SURV_REV
+#define LA3D_SURV_REV 0  // experiment: pass B takes the survivor list from its end (the tiles pass A read last first)
+#endif
 #ifndef LA3D_CULL
 #define LA3D_CULL 1      // pass-B tile culling (plain build; see cull_plan)
 #endif
@@ -254,7 +261,7 @@ __device__ inline unsigned tile_fetch(const TileCtx& c, const float* __restrict_
     }
     if (j < nsteps) {
       if (SURV) {   // survivor j -> list entry -> tile: two dependent LDS reads, done once per tile
-        ent[g] = __builtin_amdgcn_readfirstlane((int)c.surv[j]);
+        ent[g] = __builtin_amdgcn_readfirstlane((int)c.surv[LA3D_SURV_REV ? nsteps - 1 - j : j]);
         const unsigned t = __builtin_amdgcn_readfirstlane((unsigned)list[ent[g]]);
         txs[g] = (int)(t & 0xffu); tys[g] = (int)(t >> 8);
         if (tcs) tcs[g] = (int)t;
@@ -679,7 +686,10 @@ __device__ inline int order_select(const FitParams& p, int b, Shared* sh, int wa
 // instances', which are the launch's critical path); smooth depth: 15-30 %.
 // ------------------------------------------------------------------------------------------
 #ifndef LA3D_CULL_MIN
-#define LA3D_CULL_MIN 224     // active tiles below which the plan costs more than it saves (measured: profiles/r04/r04_cull.txt)
+#define LA3D_CULL_MIN 224     // active tiles below which the plan costs more than it saves (measured: profiles/r04/r04_cull.txt); the
+                              // per-call value is FitParams::cull_min: 128 for u8 planes, whose launches are bandwidth-bound - after the
+                              // cheaper tile range B = 1024 / 1536 / 2048 run 98.6 / 133.1 / 170.1 -> 96.8 / 130.3 / 164.6 us, config-5 masks
+                              // unchanged, run lengths 68.0 -> 69.1 (hence 224 there); profiles/r04/r04_cull_threshold.txt
 #endif
 constexpr int CULL_MIN = LA3D_CULL_MIN;
 constexpr int CULL_MAXT = 2 * NT;   // tiles the plan handles (two per thread)
@@ -1167,7 +1177,7 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
     // (every compact instance reserves the area: pass B always walks a survivor list - the identity when nothing is culled)
     if (compact) {   // uniform
       rng_words = cull_rng_words(nactive);
-      cull = nactive >= CULL_MIN && nactive <= CULL_MAXT;
+      cull = nactive >= p.cull_min && nactive <= CULL_MAXT;
       if (!cull) {
         unsigned short* surv = reinterpret_cast<unsigned short*>(bits + nactive * 8);
         for (int t = tid; t < nactive; t += NT) surv[t] = (unsigned short)t;   // (visible after the barriers of the axis stage)
@@ -1626,7 +1636,7 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_bands_kernel(const FitParams 
   int rng_words = 0;
   if (compact) {   // uniform
     rng_words = cull_rng_words(nactive);
-    cull = LA3D_CULL && nactive >= CULL_MIN && nactive <= CULL_MAXT;
+    cull = LA3D_CULL && nactive >= p.cull_min && nactive <= CULL_MAXT;
     if (!cull) {
       unsigned short* surv = reinterpret_cast<unsigned short*>(bits + nactive * 8);
       for (int t = tid; t < nactive; t += NT) surv[t] = (unsigned short)t;
@@ -3495,6 +3505,7 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   p.order_nch = 0; p.order_keys = nullptr; p.order_resident = 0; p.order_shift = 0;
   p.lds_keep_off = 0;
   p.stagger_ticks = 0;
+  p.cull_min = config().cull_min > 0 ? config().cull_min : (mask != nullptr ? config().cull_min_u8 : CULL_MIN);
   p.filter_boundary = -1; p.filter_min_area = 0; p.filter_max_edge = 0; p.filter_stats = nullptr;
   p.proj = proj ? proj->out : nullptr; p.proj_w = proj ? proj->width : 0; p.proj_h = proj ? proj->height : 0;
   p.area_hint = area_hint;

@@ -40,6 +40,7 @@ struct Config {
   int retain_maxb;     // LA3D_RETAIN_MAXB (default RETAIN_MAXB_DEFAULT)
   int retain_nomask;   // LA3D_RETAIN_NOMASK=1: retaining build for run-length / polygon input too
   int ldskeep;         // LA3D_LDSKEEP=0: retaining build without its LDS-kept step
+  int cull_min, cull_min_u8;   // LA3D_CULL_MIN (all inputs; 0: defaults), LA3D_CULL_MIN_U8 (u8 planes, default 128)
   double stagger_us;   // LA3D_STAGGER_US (< 0: the computed default)
   int split_grid;      // LA3D_SPLIT_GRID (0: by batch size)
   int split_sub;       // LA3D_SPLIT_SUB (0: by batch size)
@@ -481,6 +482,7 @@ struct FitParams {
   const int* debug_perm;   // measurement build only (profiles/r03/order_search.py): block -> instance table set by la3d_debug_set_block_order
 #endif
   int lds_keep_off;    // retaining build: byte offset in dynamic LDS of the per-wave kept step (0: none)
+  int cull_min;        // pass-B culling: instances with at least this many active tiles plan (cull_plan)
   int stagger_ticks;   // u8 planes: resident groups of 256 workgroups start this many 100 MHz ticks apart (0: off; see fit_instances_kernel)
   // instance filter fused into the fit (run-length / polygon input): boundary < 0 = off
   int filter_boundary, filter_min_area, filter_max_edge;
