@@ -137,3 +137,52 @@ def test_culling_rle_and_polygon_input_match_planes(la, monkeypatch):
     assert np_(s0).tolist() == np_(s1).tolist()
     ref, rst, _, _ = O.fit_instances(depth, masks, np.broadcast_to(K640, (B, 3, 3)))
     assert_records(np_(b1), ref, "cull/rle")
+
+
+# ------------------------------------------------------------------------------------------
+# Round 4, late: the speed knobs of the plain build - the staggered start of the resident groups, the culling threshold, the
+# retaining build - are read once per process (config()), so each setting runs in its own interpreter; records must not move by a bit.
+# ------------------------------------------------------------------------------------------
+_KNOB_SCRIPT = r"""
+import hashlib, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+from labelany3d_amd import InstanceFitter
+B, H, W = 700, 480, 640
+rs = np.random.RandomState(77)
+dev = torch.device("cuda", 0)
+depth = torch.as_tensor(rs.uniform(0.5, 10, (8, H, W)).astype(np.float32), device=dev)
+ii = torch.as_tensor(rs.randint(0, 8, B).astype(np.int32), device=dev)
+m = np.zeros((B, H, W), np.uint8)
+for i in range(B):
+    h, w = rs.randint(1, 400), rs.randint(1, 500)
+    r0, c0 = rs.randint(0, H - h + 1), rs.randint(0, W - w + 1)
+    m[i, r0:r0 + h, c0:c0 + w] = 1
+masks = torch.as_tensor(m, device=dev)
+K = torch.tensor([[500.0, 0, 320], [0, 500.0, 240], [0, 0, 1]], dtype=torch.float64, device=dev)
+f = InstanceFitter(B, H, W, dev)
+f.boxes.fill_(12345.0); f.status.fill_(-1)
+b, s, a = f.run(depth, masks, K, image_index=ii)
+torch.cuda.synchronize()
+assert int((s != 0).sum()) == 0, s
+print("SHA", hashlib.sha1(b.cpu().numpy().tobytes() + s.cpu().numpy().tobytes() + a.cpu().numpy().tobytes()).hexdigest())
+"""
+
+
+def test_speed_knobs_leave_the_records_alone(la):
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shas = {}
+    for name, env in (("default", {}), ("no stagger", {"LA3D_STAGGER_US": "0"}), ("long stagger", {"LA3D_STAGGER_US": "23"}),
+                      ("cull everything", {"LA3D_CULL_MIN": "1"}), ("cull nothing", {"LA3D_CULL_MIN": "100000"}),
+                      ("retaining build", {"LA3D_RETAIN": "1"}), ("no launch order", {"LA3D_BALANCE": "0"})):
+        e = dict(os.environ, LA3D_ENGINE="instance", **env)
+        r = subprocess.run([sys.executable, "-c", _KNOB_SCRIPT % root], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        shas[name] = [ln for ln in r.stdout.splitlines() if ln.startswith("SHA")][0]
+    # the plain build's partial sums are grouped alike whatever the knobs; the retaining build groups them like the plain one as long
+    # as the active tiles fit the plain build's list (rectangles below 400 x 500 px do)
+    assert len(set(shas.values())) == 1, shas
