@@ -1081,23 +1081,43 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
       unsigned long long bal[4];
       unsigned wrd[LK ? 4 : 1][8];
       int wcount = 0;
+      if ((p.H & 7) == 0) {   // uniform: every tile row is complete (the common frame heights) - no row clamp, no select per word
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int t = tbeg + k * 64 + lane;
-        unsigned any = 0;
-        if (t < tend) {
-          const int ty = (int)(((float)t + 0.5f) * p.rcp_ntx), tx = t - ty * p.ntx;  // exact: see fit_dispatch
-          const int rmax = p.H - 1 - ty * 8;                                        // >= 0
-          const unsigned* bw = bits + (ty * 8) * p.ntx + tx;
+        for (int k = 0; k < 4; ++k) {
+          const int t = tbeg + k * 64 + lane;
+          unsigned any = 0;
+          if (t < tend) {
+            const int ty = (int)(((float)t + 0.5f) * p.rcp_ntx), tx = t - ty * p.ntx;  // exact: see fit_dispatch
+            const unsigned* bw = bits + (ty * 8) * p.ntx + tx;
 #pragma unroll
-          for (int rr = 0; rr < 8; ++rr) {
-            const unsigned w = bw[min(rr, rmax) * p.ntx];
-            any |= w;
-            if constexpr (LK) wrd[k][rr] = rr <= rmax ? w : 0u;
+            for (int rr = 0; rr < 8; ++rr) {
+              const unsigned w = bw[rr * p.ntx];
+              any |= w;
+              if constexpr (LK) wrd[k][rr] = w;
+            }
           }
+          bal[k] = __ballot(any != 0);
+          wcount += __popcll(bal[k]);
         }
-        bal[k] = __ballot(any != 0);
-        wcount += __popcll(bal[k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int t = tbeg + k * 64 + lane;
+          unsigned any = 0;
+          if (t < tend) {
+            const int ty = (int)(((float)t + 0.5f) * p.rcp_ntx), tx = t - ty * p.ntx;  // exact: see fit_dispatch
+            const int rmax = p.H - 1 - ty * 8;                                        // >= 0
+            const unsigned* bw = bits + (ty * 8) * p.ntx + tx;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+              const unsigned w = bw[min(rr, rmax) * p.ntx];
+              any |= w;
+              if constexpr (LK) wrd[k][rr] = rr <= rmax ? w : 0u;
+            }
+          }
+          bal[k] = __ballot(any != 0);
+          wcount += __popcll(bal[k]);
+        }
       }
       if (lane == 0) sh->scan[wave] = (unsigned)wcount;
       __syncthreads();
