@@ -23,6 +23,8 @@
 //   pass B   same walk, six extents in the yaw frame with NaN-ignoring raw v_min/v_max_f64;
 //   epilog   wave 0 writes center / dims / R_cam / fp16-quantised vertices, one lane per output group.
 #include <atomic>
+#include <chrono>
+#include <cstdint>
 #include <cstddef>
 #include <cstring>
 #include <mutex>
@@ -63,6 +65,8 @@ const Config& config() {
     k.cull_min = e ? atoi(e) : 0;
     e = getenv("LA3D_CULL_MIN_U8");
     k.cull_min_u8 = (e && atoi(e) > 0) ? atoi(e) : 128;
+    e = getenv("LA3D_ORDER_SELF");        // 0: helper kernel in front of every ordered launch; 2: test mode of the fallback
+    k.order_self = e ? atoi(e) : 1;
     e = getenv("LA3D_STAGGER_US");
     k.stagger_us = e ? atof(e) : -1.0;
     e = getenv("LA3D_SPLIT_GRID");
@@ -634,6 +638,133 @@ __device__ inline unsigned make_order_key(int area, int shift, int inst) {
   return (q << KEY_IDX_BITS) | (unsigned)((1 << KEY_IDX_BITS) - 1 - inst);
 }
 
+// the estimate of ONE instance by ONE wave (every lane returns the wave's sum): shoelace area of the polygon parts, the exact sum of
+// the ones-runs, or the popcount of every step-th 128-byte line of the u8 plane
+__device__ inline int estimate_wave(const unsigned char* __restrict__ mask, const int* __restrict__ rle_counts,
+                                    const long long* __restrict__ rle_offsets, const int* __restrict__ poly_xy,
+                                    const long long* __restrict__ poly_ring_off, const long long* __restrict__ poly_inst_rings,
+                                    int inst, int HW, int step, int lane) {
+  int c = 0;
+  if (poly_xy) {  // shoelace area of every part (an estimate: parts may overlap or leave the frame)
+    long long tot = 0;
+    for (long long r = poly_inst_rings[inst]; r < poly_inst_rings[inst + 1]; ++r) {
+      const long long p0 = poly_ring_off[r], n = poly_ring_off[r + 1] - p0;
+      long long a2 = 0;
+      for (long long i = lane; i < n; i += 64) {
+        const long long j = (i + 1 == n) ? 0 : i + 1;
+        a2 += (long long)poly_xy[2 * (p0 + i)] * poly_xy[2 * (p0 + j) + 1] - (long long)poly_xy[2 * (p0 + j)] * poly_xy[2 * (p0 + i) + 1];
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) a2 += __shfl_xor(a2, o);
+      tot += (a2 < 0 ? -a2 : a2) / 2;
+    }
+    c = (int)(tot > (long long)HW ? HW : tot);
+    if (lane != 0) c = 0;   // the wave sum below adds the lanes
+  } else if (rle_counts) {  // exact: the sum of the ones-runs (odd positions)
+    const long long lo = rle_offsets[inst], hi = rle_offsets[inst + 1];
+    for (long long k = lo + 1 + 2 * lane; k < hi; k += 128) {
+      const int v = rle_counts[k];
+      c += v > 0 ? v : 0;
+    }
+  } else {
+    // whole 128-byte lines (HBM delivers nothing smaller): every step-th line of the plane, eight lanes per line,
+    // eight lines per lane in flight (VGA: 65 of 2400 lines, one batch)
+    const u32x4* src = reinterpret_cast<const u32x4*>(mask + (long long)inst * HW);
+    const int nlines = HW >> 7, sub = lane & 7;
+    for (int l0 = (lane >> 3) * step; l0 < nlines; l0 += 64 * step) {
+      u32x4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int l = l0 + k * 8 * step;
+        v[k] = (l < nlines) ? src[l * 8 + sub] : u32x4{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) c += __popc(nz4(v[k].x)) + __popc(nz4(v[k].y)) + __popc(nz4(v[k].z)) + __popc(nz4(v[k].w));
+    }
+  }
+  return wave_sum_i(c);
+}
+
+// Self-estimating launch (round 4): instead of a helper kernel in front of the fit, wave 0 of workgroup b estimates instance b (natural
+// index) in the kernel's prologue and publishes the key together with a per-call nonce (publish_key_word below: agent-scope stores).  The
+// nonce is new for every call, so nothing has to be cleared: a record that does not carry it is "not yet".  order_select waits for
+// the 64 records of its chunk; if they do not show up (a workgroup of this launch is not resident
+// because something else holds the chip) it computes the missing keys itself - the estimate is a pure function of the mask, so
+// everybody sees the same keys whoever wrote them, and nobody waits for ever.
+constexpr unsigned ORDER_SPIN_MAX = 256;    // x (s_sleep(8) + two loads) ~ 1 us each: a quarter of a millisecond before the fallback
+__device__ inline void st_agent_u32(unsigned* q, unsigned v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void st_agent_u64(unsigned long long* q, unsigned long long v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline unsigned ld_agent_u32(const unsigned* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline unsigned long long ld_agent_u64(const unsigned long long* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// this thread's share of the estimate of instance inst when NTH threads work on it (NTH = 64: one wave, NT: the workgroup): the
+// SAME integer whoever computes it - every step-th 128-byte line of the plane, all eight 16-byte groups of a line (u8 planes);
+// the ones-runs (run lengths).  One load in flight per thread: few registers (this code sits in the prologue of the fit kernel).
+template <int NTH>
+__device__ inline int estimate_share(const FitParams& p, int inst, int t) {
+  int c = 0;
+  if (p.rle_counts) {
+    const long long lo = p.rle_offsets[inst], hi = p.rle_offsets[inst + 1];
+#pragma unroll 1
+    for (long long k = lo + 1 + 2 * t; k < hi; k += 2 * NTH) {
+      const int v = p.rle_counts[k];
+      c += v > 0 ? v : 0;
+    }
+  } else {
+    const u32x4* src = reinterpret_cast<const u32x4*>(p.mask + (long long)inst * p.HW);
+    const int nlines = p.HW >> 7, sub = t & 7;
+#pragma unroll 1
+    for (int l = (t >> 3) * p.est_step; l < nlines; l += (NTH / 8) * p.est_step) {
+      const u32x4 v = src[l * 8 + sub];
+      c += __popc(nz4(v.x)) + __popc(nz4(v.y)) + __popc(nz4(v.z)) + __popc(nz4(v.w));
+    }
+  }
+  return c;
+}
+// Publication needs NO ordering between stores: the key travels inside both words of its record, each next to one half of the call's
+// 64-bit nonce - w0 = nonce.lo : key, w1 = nonce.hi : key.  A reader takes the key only when both words carry the nonce and the same
+// key; any other state - stale words of an earlier call, one word of two arrived - reads as "not yet".  (A first version published
+// key, fence, flag in separate words: across XCDs the flag could become visible before the key, and a workgroup ranked with the key
+// of the PREVIOUS call - one skipped and one duplicated instance in one run of the full suite.)
+__device__ inline void publish_key_word(const FitParams& p, int inst, unsigned key) {   // one lane
+  const_cast<unsigned*>(p.order_keys)[inst] = key;   // (the plain table: what the helper kernel leaves - tests and tools read it)
+  st_agent_u64(p.order_flags + 2 * inst, ((p.order_nonce & 0xffffffffull) << 32) | key);
+  st_agent_u64(p.order_flags + 2 * inst + 1, (p.order_nonce & 0xffffffff00000000ull) | key);
+}
+// the key of instance inst if its record is complete for this call, else 0 (no key is 0: the index bits of an instance < 16383 are not)
+__device__ inline unsigned published_key(const FitParams& p, int inst) {
+  const unsigned long long w0 = ld_agent_u64(p.order_flags + 2 * inst), w1 = ld_agent_u64(p.order_flags + 2 * inst + 1);
+  const bool ok = (w0 >> 32) == (p.order_nonce & 0xffffffffull) && (w1 >> 32) == (p.order_nonce >> 32) && (unsigned)w0 == (unsigned)w1;
+  return ok ? (unsigned)w0 : 0u;
+}
+// one wave estimates (polygon input in the prologue - its shoelace sums are per ring -, and the fallback of order_select); every lane
+// returns the key
+__device__ inline unsigned estimate_key_wave(const FitParams& p, int inst, int lane) {
+  int c;
+  if (p.poly_xy) c = estimate_wave(nullptr, nullptr, nullptr, p.poly_xy, p.poly_ring_off, p.poly_inst_rings, inst, p.HW, p.est_step, lane);
+  else c = wave_sum_i(estimate_share<64>(p, inst, lane));
+  return make_order_key(c, p.order_shift, inst);
+}
+__device__ inline void estimate_publish_wave(const FitParams& p, int inst, int lane) {
+  const unsigned key = estimate_key_wave(p, inst, lane);
+  if (lane == 0) publish_key_word(p, inst, key);
+}
+// the prologue: workgroup b estimates instance b with all its threads (every thread of the workgroup calls it; one barrier)
+__device__ inline void estimate_publish_wg(const FitParams& p, int inst, Shared* sh, int tid, int wave, int lane) {
+  if (p.poly_xy) {   // uniform
+    if (wave == 0) estimate_publish_wave(p, inst, lane);
+    return;
+  }
+  const int c = wave_sum_i(estimate_share<NT>(p, inst, tid));
+  if (lane == 0) sh->scan[wave] = (unsigned)c;
+  __syncthreads();
+  if (tid == 0) {
+    int tot = 0;
+#pragma unroll
+    for (int w = 0; w < NWAVE; ++w) tot += (int)sh->scan[w];
+    publish_key_word(p, inst, make_order_key(tot, p.order_shift, inst));
+  }
+}
+
 // every thread of the workgroup calls it (one barrier); returns the instance of block b, wave-uniform
 __device__ inline int order_select(const FitParams& p, int b, Shared* sh, int wave, int lane) {
   const int R = p.B < p.order_resident ? p.B : p.order_resident;
@@ -647,12 +778,32 @@ __device__ inline int order_select(const FitParams& p, int b, Shared* sh, int wa
   const int per = p.B / nch, rem = p.B - per * nch;
   const int start = c * per + (c < rem ? c : rem), size = per + (c < rem ? 1 : 0);
   if (wave < ORDER_CHUNK / 64) {
+    static_assert(ORDER_CHUNK == 64, "the self-estimating launch waits with one wave per chunk");
+    unsigned self_key = 0u;
+    if (p.order_self) {   // uniform: the keys of this chunk are being written by workgroups start .. start + size - 1 of this launch
+      unsigned spins = 0;
+      unsigned long long missing;
+      while (true) {
+        if (lane < size && self_key == 0u) self_key = published_key(p, start + lane);
+        missing = __ballot(lane < size && self_key == 0u);
+        if (missing == 0ull || spins >= ORDER_SPIN_MAX) break;
+        __builtin_amdgcn_s_sleep(8);
+        ++spins;
+      }
+      while (missing) {   // (fallback, normally never: see above)
+        const int m = __ffsll((long long)missing) - 1;
+        missing &= missing - 1ull;
+        const unsigned km = estimate_key_wave(p, start + m, lane);   // (every lane gets the key; not published: the owner will)
+        if (lane == m) self_key = km;
+      }
+    }
     unsigned k[ORDER_CHUNK / 64];
 #pragma unroll
     for (int h = 0; h < ORDER_CHUNK / 64; ++h) {
       const int l = h * 64 + lane;
       k[h] = 0u;   // key 0 never counts as larger
-      if (l < size) k[h] = p.area_hint ? make_order_key(p.area_hint[start + l], p.order_shift, start + l) : p.order_keys[start + l];
+      if (l < size) k[h] = p.area_hint ? make_order_key(p.area_hint[start + l], p.order_shift, start + l)
+                                       : (p.order_self ? self_key : p.order_keys[start + l]);
     }
     unsigned mine = k[0];
 #pragma unroll
@@ -883,6 +1034,9 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
   // youngest of the four workgroups of a CU gets its first load - this perm entry - back only when an older one has finished
   // its mask stream, ~25 us in; warming the table through L1 does not help, and s_setprio by dispatch group only moves the
   // starvation to the oldest group, which holds the largest instances: DESIGN.md section 5.2)
+  // (self-estimating launch; order_self == 2 is the test mode of the fallback: every seventh workgroup keeps its key to itself)
+  if (RET == 0 && !SAMPLE && p.order_self && !(p.order_self == 2 && blockIdx.x % 7 == 3))
+    estimate_publish_wg(p, (int)blockIdx.x, sh, tid, wave, lane);
 #ifdef LA3D_DEBUG_ORDER
   const int inst = p.debug_perm ? p.debug_perm[blockIdx.x]
                                 : (p.order_nch > 0 ? order_select(p, (int)blockIdx.x, sh, wave, lane) : xcd_remap(blockIdx.x, p.B));
@@ -3174,45 +3328,7 @@ __global__ __launch_bounds__(256) void size_estimate_kernel(const unsigned char*
   const int inst = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (inst >= B) return;
   if (band_arrive && lane < 4) band_arrive[inst * 4 + lane] = 0;   // band engine: the arrival counters of this launch start at zero
-  int c = 0;
-  if (poly_xy) {  // shoelace area of every part (an estimate: parts may overlap or leave the frame)
-    long long tot = 0;
-    for (long long r = poly_inst_rings[inst]; r < poly_inst_rings[inst + 1]; ++r) {
-      const long long p0 = poly_ring_off[r], n = poly_ring_off[r + 1] - p0;
-      long long a2 = 0;
-      for (long long i = lane; i < n; i += 64) {
-        const long long j = (i + 1 == n) ? 0 : i + 1;
-        a2 += (long long)poly_xy[2 * (p0 + i)] * poly_xy[2 * (p0 + j) + 1] - (long long)poly_xy[2 * (p0 + j)] * poly_xy[2 * (p0 + i) + 1];
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) a2 += __shfl_xor(a2, o);
-      tot += (a2 < 0 ? -a2 : a2) / 2;
-    }
-    c = (int)(tot > (long long)HW ? HW : tot);
-    if (lane != 0) c = 0;   // the wave sum below adds the lanes
-  } else if (rle_counts) {  // exact: the sum of the ones-runs (odd positions)
-    const long long lo = rle_offsets[inst], hi = rle_offsets[inst + 1];
-    for (long long k = lo + 1 + 2 * lane; k < hi; k += 128) {
-      const int v = rle_counts[k];
-      c += v > 0 ? v : 0;
-    }
-  } else {
-    // whole 128-byte lines (HBM delivers nothing smaller): every step-th line of the plane, eight lanes per line,
-    // eight lines per lane in flight (VGA: 65 of 2400 lines, one batch)
-    const u32x4* src = reinterpret_cast<const u32x4*>(mask + (long long)inst * HW);
-    const int nlines = HW >> 7, sub = lane & 7;
-    for (int l0 = (lane >> 3) * step; l0 < nlines; l0 += 64 * step) {
-      u32x4 v[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int l = l0 + k * 8 * step;
-        v[k] = (l < nlines) ? src[l * 8 + sub] : u32x4{0u, 0u, 0u, 0u};
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) c += __popc(nz4(v[k].x)) + __popc(nz4(v[k].y)) + __popc(nz4(v[k].z)) + __popc(nz4(v[k].w));
-    }
-  }
-  c = wave_sum_i(c);
+  const int c = estimate_wave(mask, rle_counts, rle_offsets, poly_xy, poly_ring_off, poly_inst_rings, inst, HW, step, lane);
   if (lane == 0) {
     keys[inst] = make_order_key(c, shift, inst);
   }
@@ -3239,6 +3355,7 @@ int launch_fit_inst(const FitParams& p_in, size_t lds, hipStream_t s, void* work
   allow_big_lds(reinterpret_cast<const void*>(kern));
   FitParams p = p_in;
   p.order_nch = 0; p.order_keys = nullptr; p.order_resident = 0; p.order_shift = 0;
+  p.order_self = 0; p.order_flags = nullptr; p.order_nonce = 0; p.est_step = 1;
   // size-balanced launch order: needs the 16-byte mask groups (VEC), more than one workgroup per CU, and a batch
   // the O(B^2) ranking is cheap for
   if (workspace && VEC && !SAMPLE && p.B > 256 && p.B <= ORDER_MAX_B && balance_enabled(p)) {
@@ -3262,9 +3379,21 @@ int launch_fit_inst(const FitParams& p_in, size_t lds, hipStream_t s, void* work
         long long amax = (p.rle_counts || p.poly_xy) ? (long long)p.HW : (long long)p.HW / step + 128;
         int shift = 0;
         while ((amax >> shift) > 0x3ffff) ++shift;
-        hipLaunchKernelGGL(size_estimate_kernel, dim3((p.B + 3) / 4), dim3(256), 0, s, p.mask, p.rle_counts, p.rle_offsets, p.poly_xy,
-                           p.poly_ring_off, p.poly_inst_rings, p.B, p.HW, step, shift, est, nullptr);
         p.order_keys = est;
+        bool self = RET == 0 && config().order_self && p.B <= wg_per_cu * 256;   // every workgroup of the launch resident at once
+#ifdef LA3D_TIMELINE
+        self = false;   // (the stamp rows of the measurement build live where the nonces would)
+#endif
+        if (self) {
+          // no helper launch: the fit kernel estimates in its prologue (estimate_publish); nonces behind the keys, 256-byte aligned
+          p.order_self = config().order_self; p.est_step = step; p.order_shift = shift;
+          p.order_flags = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(workspace) + (((size_t)p.B * 4 + 255) & ~(size_t)255));
+          const unsigned long long t = (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
+          p.order_nonce = (t * 0x9E3779B97F4A7C15ull) ^ (unsigned long long)reinterpret_cast<uintptr_t>(workspace) ^ 0xA5A5A5A55A5A5A5Aull;
+        } else {
+          hipLaunchKernelGGL(size_estimate_kernel, dim3((p.B + 3) / 4), dim3(256), 0, s, p.mask, p.rle_counts, p.rle_offsets, p.poly_xy,
+                             p.poly_ring_off, p.poly_inst_rings, p.B, p.HW, step, shift, est, nullptr);
+        }
       }
     }
   }
@@ -3338,6 +3467,7 @@ int launch_fit_bands(const FitParams& p_in, hipStream_t s, void* workspace) {
   p.band_arrive = reinterpret_cast<int*>(w + band_keys_bytes(p.B));
   p.band_xch = reinterpret_cast<double*>(w + band_keys_bytes(p.B) + (size_t)p.B * 16);
   p.order_nch = 0; p.order_keys = nullptr; p.order_resident = 0; p.order_shift = 0;
+  p.order_self = 0; p.order_flags = nullptr; p.order_nonce = 0; p.est_step = 1;
   bool zeroed = false;
   if (p.B > 256 && p.B <= ORDER_MAX_B && balance_enabled(p) && p.B <= balance_max_rounds() * 4 * 256) {
     // largest instances first (chunk-local ranking as in the instance engine; no per-CU pairing: an instance's bands sit on NB CUs)
@@ -3523,6 +3653,7 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   p.ntx = p.nty = p.tiles_per_wave = p.list_cap = 0;
   p.rcp_ntx = 1.0f;
   p.order_nch = 0; p.order_keys = nullptr; p.order_resident = 0; p.order_shift = 0;
+  p.order_self = 0; p.order_flags = nullptr; p.order_nonce = 0; p.est_step = 1;
   p.lds_keep_off = 0;
   p.stagger_ticks = 0;
   p.cull_min = config().cull_min > 0 ? config().cull_min : (mask != nullptr ? config().cull_min_u8 : CULL_MIN);

@@ -41,6 +41,7 @@ struct Config {
   int retain_nomask;   // LA3D_RETAIN_NOMASK=1: retaining build for run-length / polygon input too
   int ldskeep;         // LA3D_LDSKEEP=0: retaining build without its LDS-kept step
   int cull_min, cull_min_u8;   // LA3D_CULL_MIN (all inputs; 0: defaults), LA3D_CULL_MIN_U8 (u8 planes, default 128)
+  int order_self;      // LA3D_ORDER_SELF=0: keep the estimate kernel in front of ordered launches of up to one resident set
   double stagger_us;   // LA3D_STAGGER_US (< 0: the computed default)
   int split_grid;      // LA3D_SPLIT_GRID (0: by batch size)
   int split_sub;       // LA3D_SPLIT_SUB (0: by batch size)
@@ -475,6 +476,11 @@ struct FitParams {
   // size-balanced launch order (order_nch > 0; otherwise workgroup b fits instance xcd_remap(b)): sort keys per instance from
   // the estimate kernel, or built on the fly from area_hint; every workgroup ranks the <= ORDER_CHUNK keys of its chunk itself
   const unsigned* order_keys;
+  // self-estimating launch (round 4; order_self != 0): no helper kernel - workgroup b estimates the key of instance b in its prologue
+  // and publishes it with a per-call nonce; order_select waits for the nonces of its chunk (la3d.hip: estimate_publish)
+  unsigned long long* order_flags;
+  unsigned long long order_nonce;
+  int order_self, est_step;
   int order_nch;       // chunks of consecutive instances (ceil(B / ORDER_CHUNK)), 0 = launch order off
   int order_resident;  // workgroups of the grid that are resident at once
   int order_shift;     // area_hint >> order_shift fits 18 bits

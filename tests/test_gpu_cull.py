@@ -178,7 +178,10 @@ def test_speed_knobs_leave_the_records_alone(la):
     shas = {}
     for name, env in (("default", {}), ("no stagger", {"LA3D_STAGGER_US": "0"}), ("long stagger", {"LA3D_STAGGER_US": "23"}),
                       ("cull everything", {"LA3D_CULL_MIN": "1"}), ("cull nothing", {"LA3D_CULL_MIN": "100000"}),
-                      ("retaining build", {"LA3D_RETAIN": "1"}), ("no launch order", {"LA3D_BALANCE": "0"})):
+                      ("retaining build", {"LA3D_RETAIN": "1"}), ("no launch order", {"LA3D_BALANCE": "0"}),
+                      # the self-estimating launch (no helper kernel): off, and with every seventh workgroup withholding its key,
+                      # so that the waiting workgroups time out and compute the missing keys themselves
+                      ("helper kernel", {"LA3D_ORDER_SELF": "0"}), ("self-estimate fallback", {"LA3D_ORDER_SELF": "2"})):
         e = dict(os.environ, LA3D_ENGINE="instance", **env)
         r = subprocess.run([sys.executable, "-c", _KNOB_SCRIPT % root], env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (name, r.stderr[-2000:])
@@ -186,3 +189,46 @@ def test_speed_knobs_leave_the_records_alone(la):
     # the plain build's partial sums are grouped alike whatever the knobs; the retaining build groups them like the plain one as long
     # as the active tiles fit the plain build's list (rectangles below 400 x 500 px do)
     assert len(set(shas.values())) == 1, shas
+
+
+def test_self_estimating_launch_alternating_batches(la, monkeypatch):
+    """The ordered launch of up to one resident set estimates its sort keys inside the fit kernel and hands them over through the
+    workspace (round 4).  Alternate two batches whose instance sizes differ slot by slot on ONE workspace, many times: a key that
+    arrived from the previous call (or one half of a record) would rank a workgroup differently from its neighbours - a skipped
+    and a duplicated instance.  Every record of every call must equal the unordered launch's, and every instance must be written."""
+    import torch
+
+    from labelany3d_amd import InstanceFitter
+
+    monkeypatch.setattr(SCHED(), "engine", "instance")
+    dev = torch.device("cuda", 0)
+    B, H, W = 1024, 96, 128
+    K = torch.tensor([[100.0, 0, 64], [0, 100.0, 48], [0, 0, 1]], dtype=torch.float64, device=dev)
+    sets = []
+    for seed in (1, 2):
+        rs = np.random.RandomState(seed)
+        depth = torch.as_tensor(rs.uniform(0.5, 10, (B, H, W)).astype(np.float32), device=dev)
+        m = np.zeros((B, H, W), np.uint8)
+        for i in range(B):
+            h, w = rs.randint(1, H + 1), rs.randint(1, W + 1)
+            r0, c0 = rs.randint(0, H - h + 1), rs.randint(0, W - w + 1)
+            m[i, r0:r0 + h, c0:c0 + w] = 1
+        sets.append((depth, torch.as_tensor(m, device=dev)))
+    f = InstanceFitter(B, H, W, dev)
+    ref = []
+    monkeypatch.setattr(SCHED(), "launch_order", False)
+    for depth, masks in sets:
+        b, s, a = f.run(depth, masks, K)
+        torch.cuda.synchronize()
+        ref.append((b.clone(), s.clone(), a.clone()))
+    monkeypatch.setattr(SCHED(), "launch_order", None)
+    ref = [(torch.nan_to_num(b, nan=-7.0), s, torch.nan_to_num(a, nan=-7.0)) for b, s, a in ref]
+    bad = torch.zeros((), dtype=torch.int64, device=dev)
+    for it in range(400):
+        depth, masks = sets[it & 1]
+        if it % 3 == 0:   # (back-to-back calls and calls with a little stream work between them)
+            f.boxes.fill_(12345.0); f.status.fill_(-1); f.aux.fill_(12345.0)
+        b, s, a = f.run(depth, masks, K)
+        rb, rs_, ra = ref[it & 1]   # every call is checked, on the stream: no host synchronisation between the calls
+        bad += (s != rs_).sum() + (torch.nan_to_num(b, nan=-7.0) != rb).sum() + (torch.nan_to_num(a, nan=-7.0) != ra).sum()
+    assert int(bad) == 0
