@@ -1035,8 +1035,14 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
   // its mask stream, ~25 us in; warming the table through L1 does not help, and s_setprio by dispatch group only moves the
   // starvation to the oldest group, which holds the largest instances: DESIGN.md section 5.2)
   // (self-estimating launch; order_self == 2 is the test mode of the fallback: every seventh workgroup keeps its key to itself)
-  if (RET == 0 && !SAMPLE && p.order_self && !(p.order_self == 2 && blockIdx.x % 7 == 3))
-    estimate_publish_wg(p, (int)blockIdx.x, sh, tid, wave, lane);
+  // (batches above one resident set: the workgroups of the FIRST set - the only ones certain to run without waiting for anybody -
+  // estimate instances b, b + R, b + 2R, ...)
+  if (RET == 0 && !SAMPLE && p.order_self && (int)blockIdx.x < p.order_resident && !(p.order_self == 2 && blockIdx.x % 7 == 3)) {
+    for (int ie = (int)blockIdx.x; ie < p.B; ie += p.order_resident) {   // uniform
+      if (ie != (int)blockIdx.x) __syncthreads();   // (the block totals of the previous estimate have been read)
+      estimate_publish_wg(p, ie, sh, tid, wave, lane);
+    }
+  }
 #ifdef LA3D_DEBUG_ORDER
   const int inst = p.debug_perm ? p.debug_perm[blockIdx.x]
                                 : (p.order_nch > 0 ? order_select(p, (int)blockIdx.x, sh, wave, lane) : xcd_remap(blockIdx.x, p.B));
@@ -3380,7 +3386,7 @@ int launch_fit_inst(const FitParams& p_in, size_t lds, hipStream_t s, void* work
         int shift = 0;
         while ((amax >> shift) > 0x3ffff) ++shift;
         p.order_keys = est;
-        bool self = RET == 0 && config().order_self && p.B <= wg_per_cu * 256;   // every workgroup of the launch resident at once
+        bool self = RET == 0 && config().order_self != 0 && wg_per_cu * 256 >= 256;
 #ifdef LA3D_TIMELINE
         self = false;   // (the stamp rows of the measurement build live where the nonces would)
 #endif
