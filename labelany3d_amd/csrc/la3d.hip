@@ -48,7 +48,7 @@ const Config& config() {
     e = getenv("LA3D_BAND_DEFAULT");      // 0: the band engine only when asked for (LA3D_ENGINE=band / opt_engine)
     k.band_default = !(e && e[0] == '0');
     e = getenv("LA3D_BAND_MAXB");
-    k.band_maxb = (e && atoi(e) > 0) ? atoi(e) : 400;
+    k.band_maxb = (e && atoi(e) > 0) ? atoi(e) : 256;
     e = getenv("LA3D_BALANCE");
     k.balance = !(e && e[0] == '0');
     e = getenv("LA3D_BALANCE_ROUNDS");
@@ -790,6 +790,8 @@ __device__ inline int order_select(const FitParams& p, int b, Shared* sh, int wa
         __builtin_amdgcn_s_sleep(8);
         ++spins;
       }
+      // (diagnostics: the word behind the records counts the keys computed here; nobody clears it - tests zero the workspace first)
+      if (missing && lane == 0) atomicAdd(p.order_flags + 2 * (long long)p.B, (unsigned long long)__popcll(missing));
       while (missing) {   // (fallback, normally never: see above)
         const int m = __ffsll((long long)missing) - 1;
         missing &= missing - 1ull;
@@ -3437,10 +3439,11 @@ inline int band_count(const FitParams& p) {
   return nb;
 }
 
-// u8 planes, 16-byte aligned, full-mask mode.  By default the band engine takes 48 <= B <= 400: below, it ties with the split
-// engine (33-38 us per call either way over two measurement sets) and the split engine stays; above, the per-workgroup latencies
-// (order, list, two reductions, two exchanges, axis, box: ~60 % of a half-size work item) cost more slot time than the shorter
-// ramp-up and tail give back.  LA3D_ENGINE=band / opt_engine pins it for any batch.
+// u8 planes, 16-byte aligned, full-mask mode.  By default the band engine takes 48 <= B <= 256: below, it ties with the split
+// engine (33-38 us per call either way over two measurement sets) and the split engine stays; above, the instance engine - since the
+// end of round 4 with the staggered start and without a helper launch - is as fast or faster (us per call, instance | two bands | four
+// bands: B = 256: 59.7 | 58.6 | 60.0; 288: 61.4 | 62.9 | 66.2; 320: 64.5 | 62.4 | 69.9; 384: 63.4 | 66.2 | 78.1; 448: 63.4 | 70.6 |
+// 83.3; until then the bands held up to 400).  LA3D_ENGINE=band / opt_engine pins it for any batch, LA3D_BAND_MAXB moves the limit.
 inline bool band_eligible(const FitParams& p, bool vec, bool sample) {
   const int e = p.opt_engine != LA3D_ENGINE_DEFAULT ? p.opt_engine : config().engine;
   if (e == LA3D_ENGINE_INSTANCE || e == LA3D_ENGINE_SPLIT) return false;
@@ -3690,7 +3693,7 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   // polygons: the side stage sits behind Shared, where the tile list / rank prefix go later (disjoint in time)
   const size_t poly_stage = poly ? (size_t)POLY_STAGE_BYTES : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (band_eligible(p, vec, sample)) {   // u8 planes, 48 <= B <= 400 (or pinned): two / four workgroups per instance, ONE launch
+  if (band_eligible(p, vec, sample)) {   // u8 planes, 48 <= B <= 256 (or pinned): two / four workgroups per instance, ONE launch
     return band_count(p) == 4 ? launch_fit_bands<4>(p, s, workspace) : launch_fit_bands<2>(p, s, workspace);
   }
   if (!sample && split_eligible(p, vec, ldsmask)) {

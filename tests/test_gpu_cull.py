@@ -216,6 +216,7 @@ def test_self_estimating_launch_alternating_batches(la, monkeypatch, B):
             m[i, r0:r0 + h, c0:c0 + w] = 1
         sets.append((depth, torch.as_tensor(m, device=dev)))
     f = InstanceFitter(B, H, W, dev)
+    f.workspace.zero_()
     ref = []
     monkeypatch.setattr(SCHED(), "launch_order", False)
     for depth, masks in sets:
@@ -233,3 +234,7 @@ def test_self_estimating_launch_alternating_batches(la, monkeypatch, B):
         rb, rs_, ra = ref[it & 1]   # every call is checked, on the stream: no host synchronisation between the calls
         bad += (s != rs_).sum() + (torch.nan_to_num(b, nan=-7.0) != rb).sum() + (torch.nan_to_num(a, nan=-7.0) != ra).sum()
     assert int(bad) == 0
+    # the fallback (a workgroup computing a neighbour's key because it did not arrive in time) must not have been needed: its counter
+    # sits behind the B two-word records, which follow the 256-byte aligned key table
+    off = ((B * 4 + 255) // 256) * 256 + 16 * B
+    assert int(f.workspace[0][off:off + 8].view(torch.int64)[0]) == 0
