@@ -1086,7 +1086,7 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
     // stagger period apart, the group of the 256 LARGEST instances first (group g of the launch order = blocks [256 g, 256 g + 256)).
     // Every instance streams the same H*W mask bytes whatever its size; started together, the 1024 streams share the bandwidth and
     // nobody's passes begin before ~50 us.  Staggered, the large instances stream at four times the share and are in their (long)
-    // passes - VALU work - while the smaller ones, which have the slack, stream.  Measured, us per call, without / with 10 us
+    // passes - VALU work - while the smaller ones, which have the slack, stream.  Measured (helper-kernel build), us per call, without / with 10 us
     // (profiles/r04/r04_stagger.txt): config-2 masks B = 448 / 640 / 1024 / 1280 / 2048: 71.6 / 80.6 / 103.6 / 125.6 / 176.2 ->
     // 66.9 / 74.8 / 99.7 / 118.2 / 170.0; config-5 masks B = 512 / 1024 / 2048: 75.1 / 91.4 / 144.1 -> 69.9 / 83.2 / 139.6; neutral
     // from 4096 up.  Speed only: records do not depend on it.  (Run-length / polygon input has no stream to spread: slower there.)
@@ -3769,9 +3769,12 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
         return launch_fit<true, true, false, true, LA3D_RET>(p, tot, s, workspace);
       }
       if (mask != nullptr && B > 256) {
-        // u8 planes: the resident groups start 0.76 x (256 x H*W bytes at ~6 TB/s) apart - 10 us for 640x480 (the kernel applies it
-        // only under the size-ordered launch; LA3D_STAGGER_US overrides, 0 switches it off)
-        double us = 0.76 * 256.0 * (double)p.HW / 6.0e6;
+        // u8 planes: the resident groups start one group's stream time apart - 256 x H*W bytes at the ~6.4 TB/s a pure reader gets:
+        // 12.3 us for 640x480 (the kernel applies it only under the size-ordered launch; LA3D_STAGGER_US overrides, 0 switches it
+        // off).  Measured with the self-estimating launch (profiles/r04/r04_stagger.txt, run 4), us per call at 6 / 8 / 10 / 12 / 14 us:
+        // config-2 masks B = 1024: 96.0 / 94.8 / 93.4 / 94.5 / 95.4, B = 1536: 130.4 / 127.4 / 124.9 / 125.0 / 124.3; config-5 masks
+        // B = 1024: 84.8 / 82.5 / 80.4 / 78.1 / 77.5 - the config-2 optimum is 10, the skewed mix wants more: one stream time is between.
+        double us = 256.0 * (double)p.HW / 6.4e6;
         if (config().stagger_us >= 0) us = config().stagger_us;
         p.stagger_ticks = (int)(us * 100.0);
       }
