@@ -3393,6 +3393,14 @@ int launch_fit_inst(const FitParams& p_in, size_t lds, hipStream_t s, void* work
         self = false;   // (the stamp rows of the measurement build live where the nonces would)
 #endif
         if (self) {
+          // a call captured into a HIP graph would replay with the SAME nonce: the records of the previous replay would read as
+          // complete while this replay's keys are still on their way - with new masks in the same buffers, two workgroups could rank
+          // with different keys.  Captured calls keep the helper kernel.
+          hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+          if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) self = false;
+          (void)hipGetLastError();
+        }
+        if (self) {
           // no helper launch: the fit kernel estimates in its prologue (estimate_publish); nonces behind the keys, 256-byte aligned
           p.order_self = config().order_self; p.est_step = step; p.order_shift = shift;
           p.order_flags = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(workspace) + (((size_t)p.B * 4 + 255) & ~(size_t)255));

@@ -238,3 +238,51 @@ def test_self_estimating_launch_alternating_batches(la, monkeypatch, B):
     # sits behind the B two-word records, which follow the 256-byte aligned key table
     off = ((B * 4 + 255) // 256) * 256 + 16 * B
     assert int(f.workspace[0][off:off + 8].view(torch.int64)[0]) == 0
+
+
+def test_graph_replay_with_new_masks_in_the_same_buffers(la, monkeypatch):
+    """An ordered call captured into a HIP graph and replayed over NEW masks in the same buffers: the captured call must not carry the
+    self-estimating launch's per-call nonce (a replay would find the previous replay's records complete): it keeps the helper kernel.
+    Every replay must equal the eager, unordered launch on the same data."""
+    import torch
+
+    from labelany3d_amd import InstanceFitter
+
+    monkeypatch.setattr(SCHED(), "engine", "instance")
+    dev = torch.device("cuda", 0)
+    B, H, W = 1024, 96, 128
+    K = torch.tensor([[100.0, 0, 64], [0, 100.0, 48], [0, 0, 1]], dtype=torch.float64, device=dev)
+    rs = np.random.RandomState(5)
+    depth = torch.as_tensor(rs.uniform(0.5, 10, (B, H, W)).astype(np.float32), device=dev)
+
+    def new_masks(seed):
+        r = np.random.RandomState(seed)
+        m = np.zeros((B, H, W), np.uint8)
+        for i in range(B):
+            h, w = r.randint(1, H + 1), r.randint(1, W + 1)
+            r0, c0 = r.randint(0, H - h + 1), r.randint(0, W - w + 1)
+            m[i, r0:r0 + h, c0:c0 + w] = 1
+        return torch.as_tensor(m, device=dev)
+
+    masks = new_masks(0)
+    f = InstanceFitter(B, H, W, dev)
+    side = torch.cuda.Stream(device=dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        f.run(depth, masks, K, stream=side)
+        side.synchronize()
+        with torch.cuda.graph(g, stream=side):
+            f.run(depth, masks, K, stream=torch.cuda.current_stream())
+    fr = InstanceFitter(B, H, W, dev)
+    for seed in range(1, 9):
+        masks.copy_(new_masks(seed))
+        f.boxes.fill_(12345.0); f.status.fill_(-1)
+        g.replay()
+        torch.cuda.synchronize()
+        got_b, got_s = f.boxes[0].clone(), f.status[0].clone()
+        monkeypatch.setattr(SCHED(), "launch_order", False)
+        rb, rs_, _ = fr.run(depth, masks, K)
+        monkeypatch.setattr(SCHED(), "launch_order", None)
+        torch.cuda.synchronize()
+        assert torch.equal(got_s, rs_), seed
+        assert torch.equal(torch.nan_to_num(got_b, nan=-7.0), torch.nan_to_num(rb, nan=-7.0)), seed
