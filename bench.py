@@ -854,8 +854,8 @@ def main():
                         "the launch stream (max over ranks); `value` and ms_per_step are on the WALL clock between the two barriers (a few "
                         "us per step more at K = 20). measured_stream_GBps = la3d_mask_counts (a pure 16-byte-load reader) over the same "
                         "mask planes, HIP events, same run, before the warm-up. "
-                        "A step = the fit kernel plus, for 256 < B <= 3072 without area hints, ONE ~5 us estimate kernel (the ranking "
-                        "kernel of rounds 1-2 is gone: every workgroup ranks its chunk's keys itself). "
+                        "A step = ONE kernel: ordered launches (256 < B <= 3072) estimate their sort keys in the fit kernel's prologue since the end of "
+                        "round 4 (no helper launch; the retaining build, the band engine for B > 256 and graph-captured calls keep the ~5 us estimate kernel). "
                         "algorithmic_GBps is SURVEY 8d's H*W*5+312 B/box figure (the kernel never loads depth lines without a mask "
                         "pixel, so that figure exceeds the physical peak and is NOT a roofline fraction). traffic = PMC-measured "
                         "HBM bytes per launch of the profiled build (profiles/, TCC_EA0_RDREQ x 128 B + WRITE_SIZE); "

@@ -88,10 +88,14 @@ int la3d_mask_counts(const uint8_t* mask, int B, int H, int W, int32_t* counts, 
 #define LA3D_ENGINE_INSTANCE 1        /* one workgroup per instance */
 #define LA3D_ENGINE_SPLIT 2           /* band scan + tile-range-balanced passes (falls back to the instance engine where it does not apply) */
 #define LA3D_ENGINE_BAND 3            /* two (or four) workgroups per instance, one per band of tile rows (u8 planes, tiled frames; falls back likewise) */
-#define LA3D_ORDER_DEFAULT 0          /* size-balanced launch order for 256 < B <= 3 resident sets */
+#define LA3D_ORDER_DEFAULT 0          /* size-balanced launch order for 256 < B <= 3 resident sets; the sort keys are estimated inside the
+                                         fit kernel and handed over through the workspace, so ONE workspace serves ONE call at a time, and
+                                         several ORDERED calls running concurrently on different streams slow each other down (a call whose
+                                         workgroups are not all resident waits ~0.25 ms before computing its neighbours' keys itself):
+                                         pipelined callers pass LA3D_ORDER_OFF, as labelany3d_amd/pipeline.py does */
 #define LA3D_ORDER_OFF 1              /* a caller pipelining independent batches on several streams wants it off (measured +20 %) */
 #define LA3D_ORDER_ON 2
-#define LA3D_BUILD_DEFAULT 0
+#define LA3D_BUILD_DEFAULT 0          /* the plain build (since the end of round 4) */
 #define LA3D_BUILD_PLAIN 1            /* 64 VGPRs, four workgroups per CU, pass-B tile culling */
 #define LA3D_BUILD_RETAINING 2        /* 128 VGPRs, two workgroups per CU, depth tiles kept in registers between the passes */
 
