@@ -286,3 +286,47 @@ def test_graph_replay_with_new_masks_in_the_same_buffers(la, monkeypatch):
         torch.cuda.synchronize()
         assert torch.equal(got_s, rs_), seed
         assert torch.equal(torch.nan_to_num(got_b, nan=-7.0), torch.nan_to_num(rb, nan=-7.0)), seed
+
+
+def test_two_ordered_calls_running_concurrently(la, monkeypatch):
+    """Two ORDERED 1024-instance calls on two streams at once, each with its own workspace: neither launch has all its workgroups
+    resident, so workgroups wait for keys whose producers are not on the chip yet - the self-estimating launch must fall back to
+    computing them itself (slow, ~0.25 ms, but never a hang) and every record must still be right."""
+    import torch
+
+    from labelany3d_amd import InstanceFitter
+
+    monkeypatch.setattr(SCHED(), "engine", "instance")
+    dev = torch.device("cuda", 0)
+    B, H, W = 1024, 480, 640
+    K = torch.tensor([[500.0, 0, 320], [0, 500.0, 240], [0, 0, 1]], dtype=torch.float64, device=dev)
+    data = []
+    for seed in (11, 12):
+        rs = np.random.RandomState(seed)
+        depth = torch.as_tensor(rs.uniform(0.5, 10, (4, H, W)).astype(np.float32), device=dev)
+        ii = torch.as_tensor(rs.randint(0, 4, B).astype(np.int32), device=dev)
+        m = np.zeros((B, H, W), np.uint8)
+        for i in range(B):
+            h, w = rs.randint(8, 301), rs.randint(8, 331)
+            r0, c0 = rs.randint(0, H - h + 1), rs.randint(0, W - w + 1)
+            m[i, r0:r0 + h, c0:c0 + w] = 1
+        data.append((depth, torch.as_tensor(m, device=dev), ii))
+    fit = [InstanceFitter(B, H, W, dev) for _ in data]
+    streams = [torch.cuda.Stream(device=dev) for _ in data]
+    ref = []
+    monkeypatch.setattr(SCHED(), "launch_order", False)
+    for f, (depth, masks, ii) in zip(fit, data):
+        b, s, _ = f.run(depth, masks, K, image_index=ii)
+        torch.cuda.synchronize()
+        ref.append((torch.nan_to_num(b, nan=-7.0).clone(), s.clone()))
+    monkeypatch.setattr(SCHED(), "launch_order", None)
+    for rep in range(20):
+        for f in fit:
+            f.boxes.fill_(12345.0); f.status.fill_(-1)
+        torch.cuda.synchronize()
+        for f, st, (depth, masks, ii) in zip(fit, streams, data):
+            f.run(depth, masks, K, image_index=ii, stream=st)
+        torch.cuda.synchronize()
+        for f, (rb, rs_) in zip(fit, ref):
+            assert torch.equal(f.status[0], rs_), rep
+            assert torch.equal(torch.nan_to_num(f.boxes[0], nan=-7.0), rb), rep
