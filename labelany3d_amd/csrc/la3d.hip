@@ -1584,6 +1584,22 @@ __device__ inline double* band_xch(const FitParams& p, int inst) { return p.band
 // s_waitcnt.  An agent-scope FENCE would write back and invalidate the XCD's whole L2 - in the middle of everybody's streams:
 // measured 409 us instead of 107 us per 1024-instance call with four of them per workgroup (profiles/r04/r04_band.txt).
 __device__ inline void band_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+// Arrival counters that nobody has to clear (round 4, late: the band engine is ONE launch - no memset in front): a word holds the
+// call's 48-bit tag and a 16-bit count; the first arrival of a call finds another tag and starts the count at one.  (Calls captured
+// into a HIP graph replay with the same tag: there the words are cleared by a memset node, as before.)
+__device__ inline unsigned tagged_arrive(unsigned long long* w, unsigned long long tag) {   // returns the count including this arrival
+  unsigned long long old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while (true) {
+    const unsigned long long want = ((old >> 16) == tag ? old : (tag << 16)) + 1ull;
+    const unsigned long long prev = atomicCAS(w, old, want);
+    if (prev == old) return (unsigned)(want & 0xffffull);
+    old = prev;
+  }
+}
+__device__ inline unsigned tagged_count(const unsigned long long* w, unsigned long long tag) {
+  const unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (v >> 16) == tag ? (unsigned)(v & 0xffffull) : 0u;
+}
 __device__ inline void st_agent(double* q, double v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline double ld_agent(const double* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -1619,10 +1635,10 @@ __device__ inline void band_moments_to_axis(Shared* sh, const FitParams& p, int 
       for (int k = 0; k < 5; ++k) st_agent(mine + k, s[k]);
       st_agent(mine + 5, (double)n); st_agent(mine + 6, (double)nm);
       band_fence();                                        // the record is complete (acknowledged) before the arrival
-      int* arrive = p.band_arrive + (long long)inst * 4 + round;
-      atomicAdd(arrive, 1);
+      unsigned long long* arrive = p.band_arrive + (long long)inst * 4 + round;
       unsigned spins = 0;
-      while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NB && spins < BAND_SPIN_MAX) {
+      if (tagged_arrive(arrive, p.band_tag) < (unsigned)NB)
+      while (tagged_count(arrive, p.band_tag) < (unsigned)NB && spins < BAND_SPIN_MAX) {
         __builtin_amdgcn_s_sleep(4);
         ++spins;
       }
@@ -1891,7 +1907,7 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_bands_kernel(const FitParams 
 #pragma unroll
     for (int k = 0; k < 3; ++k) { st_agent(xe + h * 6 + 2 * k, lo[k]); st_agent(xe + h * 6 + 2 * k + 1, hi[k]); }
     band_fence();
-    last = atomicAdd(p.band_arrive + (long long)inst_p * 4 + 2, 1) == NB - 1 ? 1 : 0;
+    last = tagged_arrive(p.band_arrive + (long long)inst_p * 4 + 2, p.band_tag) == (unsigned)NB ? 1 : 0;
     band_fence();
   }
   last = __builtin_amdgcn_readfirstlane(last);
@@ -3335,7 +3351,6 @@ __global__ __launch_bounds__(256) void size_estimate_kernel(const unsigned char*
   const int lane = threadIdx.x & 63;
   const int inst = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (inst >= B) return;
-  if (band_arrive && lane < 4) band_arrive[inst * 4 + lane] = 0;   // band engine: the arrival counters of this launch start at zero
   const int c = estimate_wave(mask, rle_counts, rle_offsets, poly_xy, poly_ring_off, poly_inst_rings, inst, HW, step, lane);
   if (lane == 0) {
     keys[inst] = make_order_key(c, shift, inst);
@@ -3423,12 +3438,12 @@ int launch_fit_inst(const FitParams& p_in, size_t lds, hipStream_t s, void* work
 
 // ---- band engine (fit_bands_kernel) ----
 constexpr int BAND_NB_MAX = 4;
-constexpr int BAND_MINB = 48;   // smallest batch the band engine takes by default
+constexpr int BAND_MINB = 16;   // smallest batch the band engine takes by default (48 while a memset preceded the launch)
 constexpr size_t band_xch_doubles(int nb) { return (size_t)nb * (2 * BAND_XD + 6); }
 
-// workspace of the band engine: [B] u32 sort keys | [B][4] i32 arrival counters | [B][NB_MAX * 22] f64 exchange records
+// workspace of the band engine: [B] u32 sort keys | [B][4] u64 tagged arrival words | [B][NB_MAX * 22] f64 exchange records
 inline size_t band_keys_bytes(int B) { return ((size_t)B * 4 + 255) & ~(size_t)255; }
-inline size_t band_workspace_bytes(int B) { return band_keys_bytes(B) + (size_t)B * 16 + (size_t)B * band_xch_doubles(BAND_NB_MAX) * 8 + 256; }
+inline size_t band_workspace_bytes(int B) { return band_keys_bytes(B) + (size_t)B * 32 + (size_t)B * band_xch_doubles(BAND_NB_MAX) * 8 + 256; }
 
 inline bool band_frame_ok(int H, int W, int nb) {
   if (W % 32 != 0 || (long long)H * W % 16 != 0) return false;
@@ -3447,8 +3462,9 @@ inline int band_count(const FitParams& p) {
   return nb;
 }
 
-// u8 planes, 16-byte aligned, full-mask mode.  By default the band engine takes 48 <= B <= 256: below, it ties with the split
-// engine (33-38 us per call either way over two measurement sets) and the split engine stays; above, the instance engine - since the
+// u8 planes, 16-byte aligned, full-mask mode.  By default the band engine takes 16 <= B <= 256: below, it ties with the split
+// engine (32-34 us per call either way) and the split engine stays (us per call, split | four bands, once the band launch lost its
+// memset: B = 1: 32.2 | 32.3; 4: 32.9 | 33.3; 16: 34.9 | 33.9; 32: 36.0 | 34.0; 48: 39.5 | 35.9; 64: 42.1 | 36.6); above, the instance engine - since the
 // end of round 4 with the staggered start and without a helper launch - is as fast or faster (us per call, instance | two bands | four
 // bands: B = 256: 59.7 | 58.6 | 60.0; 288: 61.4 | 62.9 | 66.2; 320: 64.5 | 62.4 | 69.9; 384: 63.4 | 66.2 | 78.1; 448: 63.4 | 70.6 |
 // 83.3; until then the bands held up to 400).  LA3D_ENGINE=band / opt_engine pins it for any batch, LA3D_BAND_MAXB moves the limit.
@@ -3481,11 +3497,15 @@ int launch_fit_bands(const FitParams& p_in, hipStream_t s, void* workspace) {
   p.mask_lds_bytes = (int)region;
   unsigned char* w = static_cast<unsigned char*>(workspace);
   unsigned* keys = reinterpret_cast<unsigned*>(w);
-  p.band_arrive = reinterpret_cast<int*>(w + band_keys_bytes(p.B));
-  p.band_xch = reinterpret_cast<double*>(w + band_keys_bytes(p.B) + (size_t)p.B * 16);
+  p.band_arrive = reinterpret_cast<unsigned long long*>(w + band_keys_bytes(p.B));
+  p.band_xch = reinterpret_cast<double*>(w + band_keys_bytes(p.B) + (size_t)p.B * 32);
+  {
+    const unsigned long long t = (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
+    p.band_tag = (((t * 0x9E3779B97F4A7C15ull) >> 13) ^ (unsigned long long)reinterpret_cast<uintptr_t>(workspace)) & 0xffffffffffffull;
+    if (p.band_tag == 0) p.band_tag = 1;   // (zeroed words - a captured call's memset - never look like this call's)
+  }
   p.order_nch = 0; p.order_keys = nullptr; p.order_resident = 0; p.order_shift = 0;
   p.order_self = 0; p.order_flags = nullptr; p.order_nonce = 0; p.est_step = 1;
-  bool zeroed = false;
   if (p.B > 256 && p.B <= ORDER_MAX_B && balance_enabled(p) && p.B <= balance_max_rounds() * 4 * 256) {
     // largest instances first (chunk-local ranking as in the instance engine; no per-CU pairing: an instance's bands sit on NB CUs)
     p.order_nch = (p.B + ORDER_CHUNK - 1) / ORDER_CHUNK;
@@ -3499,12 +3519,17 @@ int launch_fit_bands(const FitParams& p_in, hipStream_t s, void* workspace) {
       int shift = 0;
       while ((amax >> shift) > 0x3ffff) ++shift;
       hipLaunchKernelGGL(size_estimate_kernel, dim3((p.B + 3) / 4), dim3(256), 0, s, p.mask, nullptr, nullptr, nullptr, nullptr, nullptr,
-                         p.B, p.HW, step, shift, keys, p.band_arrive);
+                         p.B, p.HW, step, shift, keys, nullptr);
       p.order_keys = keys;
-      zeroed = true;
     }
   }
-  if (!zeroed && hipMemsetAsync(p.band_arrive, 0, (size_t)p.B * 16, s) != hipSuccess) return check_launch("band engine memset");
+  {
+    // a call captured into a HIP graph replays with the same tag: its arrival words are cleared by a memset node of the graph
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+    (void)hipGetLastError();
+    if (capturing && hipMemsetAsync(p.band_arrive, 0, (size_t)p.B * 32, s) != hipSuccess) return check_launch("band engine memset");
+  }
   const int grid = ((p.B + 7) / 8) * 8 * NB;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), region + fixed, s, p);
   return check_launch("fit_bands_kernel");
@@ -3701,7 +3726,7 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   // polygons: the side stage sits behind Shared, where the tile list / rank prefix go later (disjoint in time)
   const size_t poly_stage = poly ? (size_t)POLY_STAGE_BYTES : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (band_eligible(p, vec, sample)) {   // u8 planes, 48 <= B <= 256 (or pinned): two / four workgroups per instance, ONE launch
+  if (band_eligible(p, vec, sample)) {   // u8 planes, 16 <= B <= 256 (or pinned): two / four workgroups per instance, ONE launch
     return band_count(p) == 4 ? launch_fit_bands<4>(p, s, workspace) : launch_fit_bands<2>(p, s, workspace);
   }
   if (!sample && split_eligible(p, vec, ldsmask)) {

@@ -501,7 +501,8 @@ struct FitParams {
   // band engine (fit_bands_kernel): tile rows per band (the last band takes the remainder), arrival counters [B][4] (zeroed before
   // the launch) and the exchange area [B][NB * 22] doubles, both in the workspace
   int band_trows;
-  int* band_arrive;
+  unsigned long long* band_arrive;   // [B][4] arrival words: 48-bit per-call tag | 16-bit count (tagged_arrive in la3d.hip): never cleared
+  unsigned long long band_tag;
   double* band_xch;
   double* out;
   int* status;

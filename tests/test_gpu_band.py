@@ -107,7 +107,7 @@ def test_band_engine_full_batch_is_deterministic_and_order_free(la, monkeypatch)
     idx = np.random.RandomState(0).choice(B, 24, replace=False)
     ref, rst, _, _ = O.fit_instances(np_(depth[idx]), np_(masks[idx]).astype(bool), np.broadcast_to(K640, (24, 3, 3)))
     assert_records(np_(runs[0][0])[idx], ref, "band/config2", gap=np_(runs[0][2])[idx, 3])
-    # the default dispatch takes the band engine for 48 <= B <= 256 u8 planes (four bands): same records as the pinned call
+    # the default dispatch takes the band engine for 16 <= B <= 256 u8 planes (four bands): same records as the pinned call
     for Bs in (64, 256):
         fs = InstanceFitter(Bs, bench.H, bench.W, dev, slots=2)
         a = fs.run(depth[:Bs], masks[:Bs], K, slot=0)
