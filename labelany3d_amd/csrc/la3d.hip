@@ -1091,7 +1091,11 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
     // 66.9 / 74.8 / 99.7 / 118.2 / 170.0; config-5 masks B = 512 / 1024 / 2048: 75.1 / 91.4 / 144.1 -> 69.9 / 83.2 / 139.6; neutral
     // from 4096 up.  Speed only: records do not depend on it.  (Run-length / polygon input has no stream to spread: slower there.)
     const unsigned long long t0 = wall_clock64();
-    const unsigned long long w = (unsigned long long)p.stagger_ticks * (blockIdx.x >> 8);
+    // (delays 0 / 0.81 / 1.81 / 2.94 periods: the later - smaller - groups wait a little longer each; against equal steps of one
+    // period: config 2 at B = 1024 95.1 -> 94.0 us, at 1536 125.6 -> 124.5, config 5 at 1024 equal; equal steps of 10 us are as good on
+    // config 2 and 2.7 us worse on config 5 - profiles/r04/r04_stagger.txt, run 5)
+    const unsigned g = blockIdx.x >> 8;
+    const unsigned long long w = (unsigned long long)p.stagger_ticks * (g == 1 ? 13u : (g == 2 ? 29u : (g == 3 ? 47u : 0u))) / 16u;
     while (wall_clock64() - t0 < w) __builtin_amdgcn_s_sleep(32);
   }
   if (RET > 0 && SRC == 0 && p.stagger_ticks > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
