@@ -12,7 +12,7 @@ the timed region.  Full-mask mode, ground=None, K=[[500,0,320],[0,500,240],[0,0,
 
 N > 1: one process per GPU, instances sharded across ranks (weak scaling: 1024 per rank, no data-path
 collective); the only communication is ONE gather of every rank's (steps*B, 39) box tensor + status to
-rank 0 over RCCL after the K timed fit steps (timed on its own: gather_ms).  Rank 0 prints one JSON line.
+rank 0 over RCCL after the K fit steps, inside the timed region (gather_ms / value_fit_only split it).  Rank 0 prints one JSON line.
 
 Other modes (never the headline): --config4 IMAGES = the north_star partitioning (one global metadata list -> plan_shards -> every
 rank materialises and fits only its image range -> one gather; strong scaling, per-rank fit times); --end-to-end IMAGES = host-resident
@@ -167,7 +167,7 @@ def measured_stream_ceiling(masks, min_ms=30.0):
         total_ms += ms
         reps += 1
         best = max(best, nbytes * iters / (ms * 1e-3) / 1e9)
-    return best, int(counts.sum())
+    return best, int(counts.sum()), 5 + reps * iters
 
 
 def traffic_mode_key(args, B):
@@ -651,28 +651,7 @@ def main():
 
     # measured read-only stream ceiling of THIS run (also what brings the chip to its working clocks before the warm-up steps:
     # a 20-step timed region entered from an idle chip reads ~5 % slower, profiles/r03/exp_step_ramp.py)
-    stream_GBps, _ = measured_stream_ceiling(masks)
-    # secondary figure, before the warm-up: the SAME serial step in a long back-to-back loop (>= 40 ms of GPU time, HIP events on
-    # the launch stream) - what a caller that keeps fitting batches sees.  It also leaves the chip in the power / clock state of
-    # this kernel rather than of the pure reader above: a 20-step region entered after 5 warm-up steps otherwise reads 2-4 us per
-    # step slower than the same 20 steps after 50 (profiles/r04/exp_driver_overhead.py; the timed K steps below are unchanged).
-    steady = None
-    if not args.config3 and len(streams) == 1 and not args.no_steady:
-        se0, se1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n_ss, tot_ms, best_ms = 0, 0.0, None
-        for _ in range(4):
-            torch.cuda.synchronize()
-            se0.record(stream)
-            for _k in range(100):
-                run(slot=0, stream=stream)
-            se1.record(stream)
-            torch.cuda.synchronize()
-            ms = se0.elapsed_time(se1) / 100
-            n_ss += 100; tot_ms += ms * 100
-            best_ms = ms if best_ms is None else min(best_ms, ms)
-            if tot_ms >= 40.0:
-                break
-        steady = (best_ms, n_ss)
+    stream_GBps, _, ceiling_launches = measured_stream_ceiling(masks)
     for _ in range(warmup):
         run(slot=0, stream=stream)
     if dist is not None:  # warm the communicator outside the timed region
@@ -692,18 +671,41 @@ def main():
         for st in streams[1:]:
             stream.wait_stream(st)
     ev1.record(stream)
-    barrier()
-    t1 = time.perf_counter()
-    # the job's one collective: every rank's (steps x B, 39) records + status to rank 0.  Timed on its own (round 4): at
-    # 20 steps it is 8 x 6.5 MB into one GPU inside a 2.3 ms window and would read as scaling loss; `value` / ms_per_step are
-    # the K fit steps between the two barriers above, `gather_ms` stands beside them, `value_incl_gather` has both.
+    # The job's one collective - every rank's (steps x B, 39) records + status to rank 0 (north_star: "RCCL ... only for a final
+    # result gather") - is INSIDE the timed region again (rounds 1-3 protocol; round 4 had moved it out): `value` is the whole
+    # job between the two barriers, `value_fit_only` / `gather_ms` split it.  One rank: no collective, nothing to time.
     gathered, gather_s = None, 0.0
     if dist is not None:
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
         # (every rank fits steps x B instances: the counts are known, so there is exactly ONE collective)
         gathered = gather_boxes(fitter.boxes.reshape(-1, 39), fitter.status.reshape(-1), dst=0,
                                 counts=[fitter.boxes.shape[0] * B] * world)
-        barrier()
-        gather_s = time.perf_counter() - t1
+        torch.cuda.synchronize()
+        gather_s = time.perf_counter() - tg
+    barrier()
+    t1 = time.perf_counter()
+
+    # secondary figure, AFTER the timed region (round 5; round 4 ran it before the warm-up, which conditioned the chip's clocks for
+    # the timed steps - 2-4 us per step of the round-4 headline): the SAME serial step in back-to-back loops of 100 (>= 40 ms of
+    # GPU time, HIP events on the launch stream) - what a caller that keeps fitting batches sees.
+    steady = None
+    if not args.config3 and len(streams) == 1 and not args.no_steady:
+        se0, se1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n_ss, tot_ms, best_ms = 0, 0.0, None
+        for _ in range(4):
+            torch.cuda.synchronize()
+            se0.record(stream)
+            for _k in range(100):
+                run(slot=0, stream=stream)
+            se1.record(stream)
+            torch.cuda.synchronize()
+            ms = se0.elapsed_time(se1) / 100
+            n_ss += 100; tot_ms += ms * 100
+            best_ms = ms if best_ms is None else min(best_ms, ms)
+            if tot_ms >= 40.0:
+                break
+        steady = (best_ms, n_ss)
 
     # secondary figure, same run: the same K steps PIPELINED - issued round-robin on two HIP streams (batch k+1 is enqueued
     # while batch k runs), launch order off FOR THESE CALLS (it assumes an idle chip; la3d_fit_args::opt_launch_order).  What a
@@ -804,7 +806,12 @@ def main():
             "warmup": warmup,
             "ms_per_step": elapsed / steps * 1e3,
             "gather_ms": (gather_s * 1e3) if dist is not None else None,
-            "value_incl_gather": (world * steps * B / (elapsed + gather_s)) if dist is not None else None,
+            "value_fit_only": (world * steps * B / (kern_ms * 1e-3 * steps)) if dist is not None else None,
+            "untimed_launches_before_timed_region": {"fit_steps": warmup, "other_kernels": ceiling_launches,
+                                                     "other_kernels_what": "la3d_mask_counts (the pure-reader stream ceiling, a different kernel)"},
+            "methodology": "r05: stream-ceiling measurement, W warm-up steps, then the K timed steps between two barriers (N > 1: the one "
+                           "final gather inside the region, as in rounds 1-3); steady-state and pipelined loops run AFTER the timed region "
+                           "(round 4 ran 100-400 steady-state steps before the warm-up)",
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -834,6 +841,9 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
+                "frac_required": achieved / HBM_PEAK_GBPS,
+                "frac_traffic": (traffic / step_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                "frac_algorithmic_model": alg_bytes / step_s / 1e9 / HBM_PEAK_GBPS,
                 "required_bytes_per_launch": req_bytes,
                 "byte_model": "B*H*W mask bytes once + 1024 B x (32 px x 8 row tiles holding a mask pixel; shared depth planes: "
                               "union per image) depth once + 312 B x B records; computed from the generated masks in this run",
@@ -850,7 +860,7 @@ def main():
                 "valu": valu,
                 "traffic_mode": mode,
                 "traffic_kernel_avg_ns_under_rocprof": traffic_kernel_ns,
-                "note": "frac = required bytes (byte_model) / avg_launch_ms / 8 TB/s, where avg_launch_ms is the HIP-EVENT time per step on "
+                "note": "frac = frac_required = required bytes (byte_model) / avg_launch_ms / 8 TB/s; frac_traffic = PMC-measured bytes / avg_launch_ms / 8 TB/s; frac_algorithmic_model = SURVEY 8d's H*W*5+312 B/box / avg_launch_ms / 8 TB/s (above 1: not a fraction of anything physical); avg_launch_ms is avg_launch_ms is the HIP-EVENT time per step on "
                         "the launch stream (max over ranks); `value` and ms_per_step are on the WALL clock between the two barriers (a few "
                         "us per step more at K = 20). measured_stream_GBps = la3d_mask_counts (a pure 16-byte-load reader) over the same "
                         "mask planes, HIP events, same run, before the warm-up. "
@@ -867,7 +877,7 @@ def main():
             out["steady_state"] = {
                 "value": world * B / (steady[0] * 1e-3), "unit": "boxes/s", "ms_per_step": steady[0], "steps_run": steady[1],
                 "note": "secondary: the same serial step (one batch after the other on one stream) in back-to-back loops of 100, HIP events, "
-                        "best loop, run BEFORE the W warm-up steps (rank 0's figure x ranks); the headline `value` is the K steps the driver asked for",
+                        "best loop, run AFTER the timed region (rank 0's figure x ranks); the headline `value` is the K steps the driver asked for",
             }
         if pipelined is not None:
             out["pipelined"] = {

@@ -73,6 +73,8 @@ const Config& config() {
     k.split_grid = (e && atoi(e) > 0) ? atoi(e) : 0;
     e = getenv("LA3D_SPLIT_SUB");
     k.split_sub = (e && atoi(e) > 0) ? atoi(e) : 0;
+    e = getenv("LA3D_BAND_TEST");
+    k.band_test = e ? atoi(e) : 0;
     return k;
   }();
   return c;
@@ -1571,7 +1573,8 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
 // Waiting happens once per instance (for the partner's moments) and is deadlock free as long as the partner is resident or
 // will become resident without anybody waiting for this workgroup: partners are 8 blocks apart in dispatch order (same XCD: the
 // exchange stays in one L2), so at any time all but the last few dispatched workgroups have their partners on the chip and
-// finish.  A watchdog turns a partner that never shows up into status LA3D_BOX_UNSUPPORTED instead of a hang.
+// finish.  A watchdog turns a partner that never shows up into a takeover (round 5): the band that timed out first fits the whole instance
+// itself (band_takeover) - never a hang, never a dropped box.
 // Records: deterministic run to run and under any launch order; the fp64 partial sums are grouped by band, so they agree with
 // the instance engine to rounding (like the split engine), not bit for bit.  u8 planes, tiled frames, full-mask mode only.
 // ------------------------------------------------------------------------------------------
@@ -1583,11 +1586,27 @@ template <int NB>
 __device__ inline double* band_xch(const FitParams& p, int inst) { return p.band_xch + (long long)inst * (NB * (2 * BAND_XD + 6)); }
 
 // Ordering of the exchange: every exchanged word is written and read with AGENT-scope relaxed atomics - single instructions that
-// are coherent at the L2 / memory side by themselves (sc1) - so all that is needed between "my record" and "my arrival" (and
-// between "their arrival" and "their record") is that the earlier instructions have completed: a workgroup-scope fence, i.e.
-// s_waitcnt.  An agent-scope FENCE would write back and invalidate the XCD's whole L2 - in the middle of everybody's streams:
-// measured 409 us instead of 107 us per 1024-instance call with four of them per workgroup (profiles/r04/r04_band.txt).
-__device__ inline void band_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+// are coherent at the L2 / memory side by themselves (sc1) - so what is needed between "my record" and "my arrival" is that the
+// record's stores have been ACKNOWLEDGED before the arrival is issued, and between "their arrival" and "their record" that the
+// poll's load has returned before the record's loads are issued.  Round 5 makes both explicit: band_release() = s_waitcnt
+// vmcnt(0) (gfx9 counts stores in vmcnt too) in front of the arrival, band_acquire() = the same wait behind the poll; both are
+// compiler barriers as well.  (Round 4 had a workgroup-scope FENCE here, which on gfx950 does not wait for outstanding global
+// stores: the order held only because tagged_arrive's own load in front of its CAS forced a vmcnt(0) - ADVICE round 4.)  An
+// agent-scope fence / release would also write back and invalidate the XCD's whole L2 - in the middle of everybody's streams:
+// measured 409 us instead of 107 us per 1024-instance call with four of them per workgroup (profiles/r04/r04_band.txt) - and is
+// not needed: nothing here relies on PLAIN stores becoming visible.  No assumption about which XCD a block lands on is made
+// (LA3D_BAND_TEST=2 permutes the blocks so that the bands of an instance sit on different XCDs: tests/test_gpu_band.py).
+__device__ inline void band_release() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+__device__ inline void band_acquire() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// internal states of a band workgroup after a watchdog timeout (never written to p.status)
+constexpr int BAND_ST_TAKEOVER = 100;   // this band claimed the instance: it fits the WHOLE instance on its own (band_takeover)
+constexpr int BAND_ST_ABANDON = 101;    // another band of the instance claimed it: leave without writing anything
 // Arrival counters that nobody has to clear (round 4, late: the band engine is ONE launch - no memset in front): a word holds the
 // call's 48-bit tag and a 16-bit count; the first arrival of a call finds another tag and starts the count at one.  (Calls captured
 // into a HIP graph replay with the same tag: there the words are cleared by a memset node, as before.)
@@ -1638,16 +1657,17 @@ __device__ inline void band_moments_to_axis(Shared* sh, const FitParams& p, int 
 #pragma unroll
       for (int k = 0; k < 5; ++k) st_agent(mine + k, s[k]);
       st_agent(mine + 5, (double)n); st_agent(mine + 6, (double)nm);
-      band_fence();                                        // the record is complete (acknowledged) before the arrival
+      band_release();                                      // the record's stores are acknowledged before the arrival is issued
       unsigned long long* arrive = p.band_arrive + (long long)inst * 4 + round;
+      const unsigned spin_max = p.band_test == 1 ? (1u << 10) : BAND_SPIN_MAX;
       unsigned spins = 0;
       if (tagged_arrive(arrive, p.band_tag) < (unsigned)NB)
-      while (tagged_count(arrive, p.band_tag) < (unsigned)NB && spins < BAND_SPIN_MAX) {
+      while (tagged_count(arrive, p.band_tag) < (unsigned)NB && spins < spin_max) {
         __builtin_amdgcn_s_sleep(4);
         ++spins;
       }
-      const bool timeout = spins >= BAND_SPIN_MAX;
-      band_fence();                                        // the other bands' records are read after their arrivals
+      const bool timeout = spins >= spin_max;
+      band_acquire();                                      // the other bands' records are read after their arrivals were seen
       double t[5] = {0, 0, 0, 0, 0}, tn = 0, tm = 0;
 #pragma unroll 1   // (unrolled, the compiler keeps all NB records in flight: 56 registers at NB = 4 -> spills)
       for (int hb = 0; hb < NB; ++hb) {                    // band order: the same sum in every band of the instance
@@ -1659,7 +1679,10 @@ __device__ inline void band_moments_to_axis(Shared* sh, const FitParams& p, int 
       const int nt = (int)tn;
       double gap = NAN;
       int st = LA3D_BOX_OK;
-      if (timeout) st = LA3D_BOX_UNSUPPORTED;
+      // A partner that never showed up (round 5): the first band to time out claims the instance through the fourth arrival
+      // word and fits it on its own - band_takeover; the others leave.  The claimer never arrives at the extents counter, so no
+      // other band can write the record.
+      if (timeout) st = tagged_arrive(p.band_arrive + (long long)inst * 4 + 3, p.band_tag) == 1u ? BAND_ST_TAKEOVER : BAND_ST_ABANDON;
       else if (sh->bad_ground) st = LA3D_BOX_BAD_GROUND;
       else if (nt == 0) st = LA3D_BOX_EMPTY;
       else if (nt == 1) st = LA3D_BOX_TOO_FEW;
@@ -1677,9 +1700,9 @@ __device__ inline void band_moments_to_axis(Shared* sh, const FitParams& p, int 
   }
   __syncthreads();
   if (sh->redo) return;   // uniform
-  // rejected instance: band 0 writes the outputs, every band returns (a watchdog timeout - the only source of UNSUPPORTED here -
-  // is reported by whichever band ran into it: the others may never learn)
-  if (tid == 0 && (h == 0 || sh->st == LA3D_BOX_UNSUPPORTED) && sh->st != LA3D_BOX_OK) {
+  // rejected instance: band 0 writes the outputs, every band returns (a band that took the instance over after a watchdog
+  // timeout writes them itself: band_takeover)
+  if (tid == 0 && h == 0 && sh->st != LA3D_BOX_OK && sh->st < BAND_ST_TAKEOVER) {
     if (p.aux) {
       double* a = p.aux + (long long)inst * LA3D_AUX;
       a[0] = atan2(sh->syaw, sh->cyaw); a[1] = (double)sh->n_valid; a[2] = (double)sh->nm; a[3] = sh->gap;
@@ -1688,6 +1711,42 @@ __device__ inline void band_moments_to_axis(Shared* sh, const FitParams& p, int 
     write_nan_box(p.out + (long long)inst * LA3D_REC);
     if (p.proj) { for (int j = 0; j < 8; ++j) p.proj[(long long)inst * 8 + j] = NAN; }
   }
+}
+
+// Watchdog fallback of the band engine (round 5; ADVICE / VERDICT round 4: a timeout used to drop a fittable box as
+// LA3D_BOX_UNSUPPORTED): the band that claimed the instance fits ALL of it with the generic row-linear walk - mask bytes and depth
+// straight from memory, no bit image, no tile list, so the band's LDS layout does not matter - and writes the record.  Slow
+// (one workgroup re-reads the whole plane twice) and practically never taken: partners are dispatched within a few blocks of
+// each other.  The sums are grouped like the untiled instance engine's, so the record agrees with the other engines to rounding.
+__device__ inline void band_takeover(Shared* sh, const FitParams& p, int inst, int tid, int wave, int lane) {
+  __syncthreads();
+  const int img = p.image_index ? p.image_index[inst] : inst;
+  if (tid == NT - 1) {   // M in FRAME rows again (the band kernel keeps band-local rows); Rg and bad_ground stand
+    double Kinv[9];
+    inv3_cofactor(p.K + (long long)img * p.k_stride, Kinv);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) sh->M[i * 3 + j] = sh->Rg[i] * Kinv[j] + sh->Rg[3 + i] * Kinv[3 + j] + sh->Rg[6 + i] * Kinv[6 + j];
+  }
+  __syncthreads();
+  double Mg[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Mg[i] = uniform_f64(sh->M[i]);
+  const float* dpl = p.depth + (long long)img * p.depth_plane_stride;
+  const unsigned char* mpl = p.mask + (long long)inst * p.HW;
+  double acc[5] = {0, 0, 0, 0, 0};
+  int cnt = 0, nmask = 0;
+  sweep<true, false, 0>(p, dpl, mpl, nullptr, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, &nmask);
+  stage_moments_to_axis(sh, p, inst, acc, cnt, nmask, tid, wave, lane, false);
+  if (sh->st != LA3D_BOX_OK) return;
+  double ext[6] = {INFINITY, -INFINITY, INFINITY, -INFINITY, INFINITY, -INFINITY};
+  double N0[3], N2[3];
+  yaw_rows(sh, Mg, N0, N2);
+  int d0 = 0, d1 = 0;
+  sweep<true, false, 1>(p, dpl, mpl, nullptr, N0, Mg + 3, N2, wave, lane, ext, &d0, &d1);
+  stage_extents_to_box(sh, p, inst, ext, tid, wave, lane);
+  stage_status_aux(sh, p, inst, tid);
 }
 
 template <int NB>
@@ -1699,9 +1758,11 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_bands_kernel(const FitParams 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // block -> (instance slot, band): partners are 8 blocks apart, i.e. on the same XCD (the dispatcher places block b on XCD b % 8)
-  const int bx = (int)blockIdx.x;
+  int bx = (int)blockIdx.x;
+  if (p.band_test == 2) bx ^= (bx >> 3) & 7;   // test hook: a bijection of the grid that puts the bands of an instance on different XCDs
   const int slot = ((bx >> 3) / NB) * 8 + (bx & 7), h = (bx >> 3) % NB;
   if (slot >= p.B) return;   // (grid padded to a multiple of 8 * NB)
+  if (p.band_test == 1 && h == 1 && slot % 3 == 0) return;   // test hook: a partner that never shows up (the others take over)
   const int inst = p.order_nch > 0 ? order_select(p, slot, sh, wave, lane) : xcd_remap(slot, p.B);
   if (tid == 0) sh->order_inst = inst;
   const int img = p.image_index ? p.image_index[inst] : inst;
@@ -1860,6 +1921,10 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_bands_kernel(const FitParams 
   }
   cnt = nmask;   // optimistic pass: valid pixels = mask pixels
   band_moments_to_axis<NB>(sh, p, inst_p, h, 0, acc, cnt, nmask, tid, wave, lane, true);
+  if (sh->st >= BAND_ST_TAKEOVER) {   // uniform: watchdog timeout
+    if (sh->st == BAND_ST_TAKEOVER) band_takeover(sh, p, inst_p, tid, wave, lane);
+    return;
+  }
   if (sh->redo) {   // uniform, and the same in every band of the instance: the summed moments decide
     __syncthreads();
 #pragma unroll
@@ -1869,6 +1934,10 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_bands_kernel(const FitParams 
     if (cull) sweep_tiled<0, true, 0, true>(pb, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, nullptr, nullptr, compact, rng_words);
     else sweep_tiled<0, true, 0>(pb, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, keep, nullptr, nullptr, compact, rng_words);
     band_moments_to_axis<NB>(sh, p, inst_p, h, 1, acc, cnt, nmask, tid, wave, lane, false);
+    if (sh->st >= BAND_ST_TAKEOVER) {   // uniform
+      if (sh->st == BAND_ST_TAKEOVER) band_takeover(sh, p, inst_p, tid, wave, lane);
+      return;
+    }
   }
   if (sh->st != LA3D_BOX_OK) return;
 
@@ -1910,9 +1979,9 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_bands_kernel(const FitParams 
   if (lane == 0) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) { st_agent(xe + h * 6 + 2 * k, lo[k]); st_agent(xe + h * 6 + 2 * k + 1, hi[k]); }
-    band_fence();
+    band_release();
     last = tagged_arrive(p.band_arrive + (long long)inst_p * 4 + 2, p.band_tag) == (unsigned)NB ? 1 : 0;
-    band_fence();
+    band_acquire();
   }
   last = __builtin_amdgcn_readfirstlane(last);
   if (!last) return;
@@ -3702,6 +3771,8 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   p.order_self = 0; p.order_flags = nullptr; p.order_nonce = 0; p.est_step = 1;
   p.lds_keep_off = 0;
   p.stagger_ticks = 0;
+  p.band_test = config().band_test;
+  p.band_trows = 0; p.band_arrive = nullptr; p.band_tag = 0; p.band_xch = nullptr;
   p.cull_min = config().cull_min > 0 ? config().cull_min : (mask != nullptr ? config().cull_min_u8 : CULL_MIN);
   p.filter_boundary = -1; p.filter_min_area = 0; p.filter_max_edge = 0; p.filter_stats = nullptr;
   p.proj = proj ? proj->out : nullptr; p.proj_w = proj ? proj->width : 0; p.proj_h = proj ? proj->height : 0;

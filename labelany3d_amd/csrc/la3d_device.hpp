@@ -45,6 +45,8 @@ struct Config {
   double stagger_us;   // LA3D_STAGGER_US (< 0: the computed default)
   int split_grid;      // LA3D_SPLIT_GRID (0: by batch size)
   int split_sub;       // LA3D_SPLIT_SUB (0: by batch size)
+  int band_test;       // LA3D_BAND_TEST (tests only): 1 = band 1 of every third instance never arrives and the watchdog is short (the
+                       // takeover path runs); 2 = blocks permuted so that the bands of an instance sit on different XCDs
 };
 const Config& config();
 
@@ -504,6 +506,7 @@ struct FitParams {
   unsigned long long* band_arrive;   // [B][4] arrival words: 48-bit per-call tag | 16-bit count (tagged_arrive in la3d.hip): never cleared
   unsigned long long band_tag;
   double* band_xch;
+  int band_test;       // Config::band_test
   double* out;
   int* status;
   double* aux;
