@@ -353,7 +353,39 @@ def config4_metadata(P, seed):
     return {"img": img, "hh": hh, "ww": ww, "r0": r0, "c0": c0, "area": np.pi / 4 * hh * ww, "P": P, "B": B, "seed": seed}
 
 
-def config4_materialize(meta, shard, device):
+def config4_annotations(meta, kind):
+    """The metadata's ellipses as COCO-style annotation dicts, identical on every rank: kind "poly" = one 24-vertex outline per
+    instance (what the reference's COCONut converter writes, src/download_coconut.py:178-199), "rle" = uncompressed column-major run
+    lengths of the same ellipse (its :167-176).  ``area`` is the annotation's own field: what plan_shards balances by."""
+    anns = []
+    ang = np.linspace(0, 2 * np.pi, 24, endpoint=False)
+    ca, sa = np.cos(ang), np.sin(ang)
+    for n in range(meta["B"]):
+        hh, ww, r0, c0 = meta["hh"][n], meta["ww"][n], meta["r0"][n], meta["c0"][n]
+        cy, cx = r0 + hh / 2, c0 + ww / 2
+        if kind == "poly":
+            xs, ys = cx + ww / 2 * ca, cy + hh / 2 * sa
+            seg = [np.stack([xs, ys], 1).reshape(-1).tolist()]
+        else:
+            cols = np.arange(W)
+            t = 1.0 - ((cols - cx) / (ww / 2)) ** 2
+            half = np.sqrt(np.clip(t, 0, None)) * hh / 2
+            lo = np.clip(np.ceil(cy - half), 0, H).astype(np.int64)
+            hi = np.clip(np.floor(cy + half) + 1, 0, H).astype(np.int64)
+            on = (t > 0) & (hi > lo)
+            counts, pos = [], 0
+            for c in np.nonzero(on)[0]:
+                s_, e_ = c * H + lo[c], c * H + hi[c]
+                counts += [int(s_ - pos), int(e_ - s_)]
+                pos = e_
+            counts.append(int(H * W - pos))
+            seg = {"size": [H, W], "counts": counts}
+        anns.append({"id": n, "image_id": int(meta["img"][n]), "category_id": 1, "iscrowd": 0, "bbox": [float(c0), float(r0), float(ww), float(hh)],
+                     "area": float(meta["area"][n]), "segmentation": seg})
+    return anns
+
+
+def config4_materialize(meta, shard, device, with_masks=True):
     """ONLY this rank's tensors: the depth planes of images [img_lo, img_hi) - plane i is a function of (seed, i), so any rank
     would build the same plane - and the u8 masks of instances [inst_lo, inst_hi).  Returns (depth, masks, K, None, None), the
     load_fn contract of fit_instances_sharded."""
@@ -364,6 +396,9 @@ def config4_materialize(meta, shard, device):
         g.manual_seed(meta["seed"] * 1000003 + i)
         depth[i - ilo].uniform_(0.5, 10.0, generator=g)
     n = nhi - nlo
+    K = torch.tensor(K640, dtype=torch.float64, device=device)
+    if not with_masks:   # annotation formats (--poly / --rle): no u8 plane exists on any rank
+        return depth[:ihi - ilo], None, K, None, None
     masks = torch.empty((max(n, 1), H, W), dtype=torch.uint8, device=device)
     rows = torch.arange(H, device=device, dtype=torch.float32).view(1, H, 1)
     cols = torch.arange(W, device=device, dtype=torch.float32).view(1, 1, W)
@@ -388,18 +423,61 @@ def run_config4(args, dist, rank, world, device, red_dev):
     dist_ = dist
     plan = plan_shards(meta["img"], P, world, areas=meta["area"], frame_pixels=H * W)
     loaded = {}
+    ann_mode = args.poly or args.rle
 
     def load_fn(sh):   # materialised once, outside the timed steps (inputs resident in HBM, like the headline)
         if "t" not in loaded:
-            loaded["t"] = config4_materialize(meta, sh, device)
+            loaded["t"] = config4_materialize(meta, sh, device, with_masks=not ann_mode)
         return loaded["t"]
 
     load_fn(plan[rank])
+    if ann_mode:
+        # round 5: the same job on the reference's ANNOTATION formats (src/util.py:336-383): the global metadata list becomes a list of
+        # COCO-style annotation dicts (24-vertex polygon outlines of the ellipses, or run lengths), every rank packs and uploads ONLY
+        # the segmentations of its own image range (outside the timed jobs, like the depth planes) and fits them with
+        # fit_instances_poly / fit_instances_rle: no u8 plane exists on any rank
+        from labelany3d_amd import fit_instances_ex, pack_polygons, pack_rle
+        from labelany3d_amd.shard import fit_annotations_sharded
+        anns = config4_annotations(meta, "rle" if args.rle else "poly")
+        packed = {}
+
+        def depth_loader(sh):
+            d, _, k, _, _ = load_fn(sh)
+            return d, k
+
+        def ann_fit(annotations, image_size, d, K, ground=None, image_index=None, filter=None):
+            if "p" not in packed:   # first (warm-up) job: pack + upload this rank's segmentations once
+                segs = [a["segmentation"] for a in annotations]
+                if args.rle:
+                    c, o, hh, ww = pack_rle(segs)
+                    packed["p"] = dict(rles=(torch.as_tensor(c, device=device), torch.as_tensor(o, device=device), hh, ww))
+                else:
+                    xy, ro, ir, hh, ww = pack_polygons(segs, H, W)
+                    packed["p"] = dict(polys=tuple(torch.as_tensor(x, device=device) for x in (xy, ro, ir)) + (hh, ww))
+                packed["ii"] = torch.as_tensor(image_index, device=device)
+                packed["hint"] = torch.as_tensor(np.asarray([a["area"] for a in annotations]).astype(np.int32), device=device)
+            r = fit_instances_ex(d, K, image_index=packed["ii"], area_hint=packed["hint"], device=device, **packed["p"])
+            return r["boxes"], r["status"]
     best = None
     for it in range(args.warmup_jobs + args.jobs):
         torch.cuda.synchronize()
         tm = {}
-        if dist_ is None:   # one process: the same plan / load / fit, no collective to run
+        if ann_mode:
+            if dist_ is not None:
+                dist_.barrier()
+            t0 = time.perf_counter()
+            if dist_ is None:
+                sh = plan[0]
+                d, k = depth_loader(sh)
+                b, st = ann_fit(anns[sh.inst_lo:sh.inst_hi], (W, H), d, k, image_index=(meta["img"][sh.inst_lo:sh.inst_hi] - sh.img_lo).astype(np.int32))
+                torch.cuda.synchronize()
+                tm.update(fit_s=time.perf_counter() - t0, gather_s=0.0)
+                out = (b, st, [B])
+            else:
+                out = fit_annotations_sharded(anns, (W, H), meta["img"], P, depth_loader, areas=meta["area"], fit_fn=ann_fit, timings=tm)
+                torch.cuda.synchronize()
+                dist_.barrier()
+        elif dist_ is None:   # one process: the same plan / load / fit, no collective to run
             from labelany3d_amd import fit_instances
             sh = plan[0]
             d, m, k, _, _ = load_fn(sh)
@@ -427,6 +505,7 @@ def run_config4(args, dist, rank, world, device, red_dev):
     if rank == 0:
         boxes, status, counts = best_out
         assert boxes.shape == (B, 39) and int((status == 0).sum()) == B, (boxes.shape, int((status != 0).sum()))
+        mask_input = "u8 planes" if not ann_mode else ("COCO run lengths" if args.rle else "polygon parts (24-vertex outlines)")
         if args.dump:   # tests: the gathered records in global instance order
             np.save(args.dump, boxes.cpu().numpy())
         fit = [float(v[0]) for v in allv]
@@ -437,9 +516,9 @@ def run_config4(args, dist, rank, world, device, red_dev):
             "warmup": args.warmup_jobs, "ms_per_step": job * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BASELINE config 4 partitioning: {P} images with a shared 480x640 depth plane each, {B} instances "
-                                   "(~Poisson(7) per image, elliptical u8 masks, log-uniform area 400..100k px), ONE global metadata list, "
+                                   f"(~Poisson(7) per image, elliptical masks as {mask_input}, log-uniform area 400..100k px), ONE global metadata list, "
                                    "plan_shards -> every rank materialises and fits only its contiguous image range -> one gather of (n_i,39) records",
-                       "images": P, "instances": B, "instances_per_rank": [p[3] - p[2] for p in plan], "images_per_rank": [p[1] - p[0] for p in plan],
+                       "mask_input": mask_input, "images": P, "instances": B, "instances_per_rank": [p[3] - p[2] for p in plan], "images_per_rank": [p[1] - p[0] for p in plan],
                        "sharding": "per image, cost-balanced contiguous ranges (reference --start_index/--end_index, whole.py:25-27,42)"},
             "per_rank_fit_ms": [f * 1e3 for f in fit], "fit_ms_max": max(fit) * 1e3, "fit_ms_min": min(fit) * 1e3,
             "imbalance_max_over_mean": max(fit) / (sum(fit) / len(fit)), "gather_ms": max(gat) * 1e3,

@@ -95,8 +95,9 @@ int la3d_mask_counts(const uint8_t* mask, int B, int H, int W, int32_t* counts, 
                                          pipelined callers pass LA3D_ORDER_OFF, as labelany3d_amd/pipeline.py does */
 #define LA3D_ORDER_OFF 1              /* a caller pipelining independent batches on several streams wants it off (measured +20 %) */
 #define LA3D_ORDER_ON 2
-#define LA3D_BUILD_DEFAULT 0          /* the plain build (since the end of round 4) */
-#define LA3D_BUILD_PLAIN 1            /* 64 VGPRs, four workgroups per CU, pass-B tile culling */
+#define LA3D_BUILD_DEFAULT 0          /* 64 VGPRs, four workgroups per CU; un-grounded, skew-free cameras take the separable SINGLE pass
+                                         (round 5: one walk over the depth, extents from per-column depth ranges), every other call two passes */
+#define LA3D_BUILD_PLAIN 1            /* the same build pinned to its two-pass form (pass-B tile culling) for every camera */
 #define LA3D_BUILD_RETAINING 2        /* 128 VGPRs, two workgroups per CU, depth tiles kept in registers between the passes */
 
 /* Bytes of device scratch la3d_fit_instances needs for (B,H,W); may be 0. */
@@ -299,6 +300,24 @@ int la3d_unproject_matches(const float* depth, int H, int W, const double* uv, i
 int la3d_fit_points(const double* points, const int64_t* offsets, const double* ground,
                     const int32_t* sample_idx, int method, int B,
                     double* out, int32_t* status, double* aux, void* stream);
+
+/* Host-pointer single calls (round 5): the reference's own calling pattern is one object / one image per call on NumPy arrays.
+ * One C call = upload + kernel + download, synchronous, on a private stream of the calling thread; the staging memory (pinned and
+ * device-mapped for the cloud, device scratch for the frame) belongs to the library, is per thread and per device, grows on demand
+ * and is kept until la3d_host_release() / process exit.  ALL pointers are HOST pointers.
+ *
+ * la3d_estimate_bbox_host replaces estimate_bbox(in_pc, cat_name, ground_equ, method) for ONE cloud — reference
+ * src/util_3dbox.py:106-178, call site :273-278.  points f64 [n][3] (the caller has already drawn its 500 rows when n > 500,
+ * exactly where the reference draws them, :123-125); ground4 NULL or a NaN first entry = "ground_equ is None"; out39 / aux4 /
+ * status as la3d_fit_points writes them (aux4 may be NULL).  PCA: the arithmetic of la3d_fit_points with
+ * LA3D_HINT_SMALL_CLOUDS, bit for bit.
+ *
+ * la3d_unproject_host replaces depth_to_points(depth[None], K) for ONE frame — reference src/util.py:52-75, call site
+ * src/batch_scripts/depth.py:154: depth f32 [H][W] -> out f64 / f32 [H][W][3], same arithmetic as la3d_unproject. */
+int la3d_estimate_bbox_host(const double* points, int64_t n, const double* ground4, int method, double* out39, double* aux4,
+                            int32_t* status);
+int la3d_unproject_host(const float* depth, const double* K9, const double* Rt12, int H, int W, void* out, int out_is_f64);
+void la3d_host_release(void);   /* frees the calling thread's staging memory and stream (optional) */
 
 /* Host-side helper exported for tests: float64 -> float16 (round-to-nearest-even, as NumPy's
  * astype(float16), reference src/util_3dbox.py:165) -> float64, the same routine the kernels use. */

@@ -75,6 +75,8 @@ const Config& config() {
     k.split_sub = (e && atoi(e) > 0) ? atoi(e) : 0;
     e = getenv("LA3D_BAND_TEST");
     k.band_test = e ? atoi(e) : 0;
+    e = getenv("LA3D_SEP");               // 0: no separable single pass (the two-pass plain build everywhere)
+    k.sep = !(e && e[0] == '0');
     return k;
   }();
   return c;
@@ -475,6 +477,140 @@ __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__
 #pragma unroll
   for (int i = 0; i < (PASS == 0 ? 5 : 6); ++i) acc[i] = sv[i];
   if (PASS == 0) *cnt = n;
+}
+
+// ------------------------------------------------------------------------------------------
+// Separable single pass (round 5) - the un-grounded, skew-free camera, i.e. every call without a ground vector (BASELINE configs
+// 2-5).  Then M = K^-1 = [[a00, 0, a02], [0, a11, a12], [0, 0, 1]] and a point is (x, y, z) = d * (r0(u), ry(v), 1): the x ray
+// depends on the COLUMN only, the y ray on the ROW only, z is the depth itself.  Two consequences:
+//   moments  Sx = sum_u r0(u) S1[u], Sxx = sum_u r0(u)^2 S2[u], Sxz = sum_u r0(u) S2[u], Sz = sum S1, Szz = sum S2 with the
+//            per-column sums S1 = sum_v d, S2 = sum_v d^2: a lane that owns ONE column of a tile (4 rows) needs a conversion, an
+//            add and an fma per pixel and nine operations per tile - 21 fp64 operations per tile and lane instead of 34;
+//   extents  in the yaw frame x' = d * (cy r0(u) + sy), z' = d * (-sy r0(u) + cy): per column, a product of the depth with a
+//            constant - monotone under rounding - so the column's extremes are attained at its smallest / largest depth.  Pass A
+//            leaves [dmin, dmax] per column in LDS (non-negative floats order like unsigned integers: one ds_min_u32 + one
+//            ds_max_u32 per lane and tile); after the axis, W columns x two products replace the whole of pass B.  The y extent
+//            does not depend on the yaw at all and is taken per pixel in the same pass.
+// So the depth is read ONCE (traffic = required bytes), there is no pass B, no depth range per tile, no cull plan (four barriers),
+// no survivor list, no tile kept in LDS.  Lane = (half h = lane >> 5, column c = lane & 31) owns rows 4h .. 4h + 3 of column c of
+// a 32 x 8 tile: four global_load_dword per tile (each instruction = two whole 128-byte lines), the tile's eight row words from
+// the compacted bit image (one ds_read_b128 per lane).
+// Optimistic like pass A: only the mask bit gates a pixel.  A NaN / inf depth turns the sums non-finite (stage_moments_to_axis
+// sets sh->redo), a negative one would break the unsigned ordering (sh->sep_bad) - either way the workgroup re-runs the general
+// two-pass path.  The rays are the canonical r0(u) = fma(a00, u, a02), ry(v) = fma(a11, v - v % 4, a12) + (v % 4) a11: pure
+// functions of the column / row, used by every lane that meets them.  Sums are grouped per (lane, tile), so the records agree
+// with the two-pass path to rounding (1e-12 relative), not bit for bit.
+// ------------------------------------------------------------------------------------------
+__device__ inline unsigned min3_u32(unsigned a, unsigned b, unsigned c) {
+  unsigned r;
+  asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ inline unsigned max3_u32(unsigned a, unsigned b, unsigned c) {
+  unsigned r;
+  asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// LDS words of the per-column depth range behind the compacted entries: colmin[W] | colmax[W], 16-byte granules
+__device__ __host__ inline int sep_col_words(int W) { return (2 * W + 3) & ~3; }
+
+// acc[0..4] += Sx, Sz, Sxx, Sxz, Szz of this wave's tiles; yext = [ymin, ymax]; *unsafe = max over the valid depth bit patterns
+// (>= 0x7f800000: a NaN, an infinity or a negative depth under the mask).  col = colmin (colmax = col + W), initialised to
+// 0xffffffff / 0 before the barrier in front of this call.
+__device__ inline void sweep_sep(const FitParams& p, const float* __restrict__ dpl, const unsigned* bits,
+                                 const unsigned short* list, int nactive, const double* Mg, unsigned* col, int wave, int lane,
+                                 double* acc, double* yext, unsigned* unsafe) {
+  const int c = lane & 31, h4 = (lane >> 5) * 4;
+  const double a00 = Mg[0], a02 = Mg[2], a11 = Mg[4], a12 = Mg[5];
+  unsigned loff[4];   // byte offsets of this lane's four pixels inside a tile (uniform tile origin + 32-bit vector offset: the saddr form)
+#pragma unroll
+  for (int k = 0; k < 4; ++k) loff[k] = (unsigned)((h4 + k) * p.W + c) * 4u;
+  unsigned* colq = col + c;
+  double s0 = acc[0], s1 = acc[1], s2 = acc[2], s3 = acc[3], s4 = acc[4];
+  double ylo = yext[0], yhi = yext[1];
+  unsigned bad = *unsafe;
+  for (int j0 = wave * TG; j0 < nactive; j0 += NWAVE * TG) {
+    unsigned dq[TG][4];
+    unsigned pk = 0;
+    int tcs[TG];
+    // stage 1: mask bits of this lane's column, then all depth loads back to back
+#pragma unroll
+    for (int g = 0; g < TG; ++g) {
+      const int e = j0 + g;
+      tcs[g] = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) asm volatile("" : "=v"(dq[g][k]));   // (defined without an instruction: every use is gated by the mask bit)
+      if (e < nactive) {   // uniform
+        const unsigned t = __builtin_amdgcn_readfirstlane((unsigned)list[e]);
+        tcs[g] = (int)t;
+        const uint4 w = *reinterpret_cast<const uint4*>(bits + e * 8 + h4);
+        const unsigned nib = ((w.x >> c) & 1u) | (((w.y >> c) & 1u) << 1) | (((w.z >> c) & 1u) << 2) | (((w.w >> c) & 1u) << 3);
+        pk |= nib << (4 * g);
+        if (nib) {
+          // uniform tile origin in scalar registers + the lane's constant byte offsets
+          const unsigned char* tp = reinterpret_cast<const unsigned char*>(dpl + ((long long)((t >> 8) * 8u) * p.W + (t & 0xffu) * 32u));
+#pragma unroll
+          for (int k = 0; k < 4; ++k) dq[g][k] = *reinterpret_cast<const unsigned*>(tp + loff[k]);
+        }
+      }
+    }
+    // stage 2: the pixel math, tile after tile (the scheduling barriers keep the tiles' temporaries from overlapping: the kernel
+    // lives in 64 registers)
+#pragma unroll
+    for (int g = 0; g < TG; ++g) {
+      if (j0 + g >= nactive) continue;   // uniform
+      const int tx = tcs[g] & 0xff, ty = tcs[g] >> 8;
+      const unsigned nib = (pk >> (4 * g)) & 0xFu;
+      double ry = fma(a11, (double)(ty * 8 + h4), a12);
+      double c1 = 0.0, c2 = 0.0;
+      unsigned cmin = 0xffffffffu, cmax = 0u;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int m = -(int)((nib >> k) & 1u);                    // 0 / -1
+        const unsigned v = dq[g][k] & (unsigned)m;                 // invalid -> +0.0 (sums), 0 (unsigned max)
+        unsigned w;
+        asm("v_bfi_b32 %0, %1, %2, -1" : "=v"(w) : "v"(m), "v"(dq[g][k]));   // invalid -> 0xffffffff (unsigned min)
+        cmin = min(cmin, w); cmax = max(cmax, v);
+        const double d = (double)__uint_as_float(v);
+        if (k == 0) { c1 = d; c2 = d * d; }
+        else { c1 += d; c2 = fma(d, d, c2); }
+        // y extent: per pixel (the row ray), invalid pixels as NaN (ignored by v_min / v_max_f64)
+        const double y = d * ry;
+        const double ym = __hiloint2double(__double2hiint(y) | ~m, __double2loint(y));
+        ylo = dmin(ylo, ym); yhi = dmax(yhi, ym);
+        ry += a11;
+      }
+      // the column's ray, once per tile
+      const double r0 = fma(a00, (double)(tx * 32 + c), a02);
+      const double t1 = r0 * c1, t2 = r0 * c2;
+      s0 += t1; s1 += c1; s2 = fma(r0, t2, s2); s3 += t2; s4 += c2;
+      // depth range of this lane's column in this tile -> the per-column arrays (a lane without a mask bit sends the identities)
+      bad = max(bad, cmax);
+      atomicMin(colq + tx * 32, cmin);
+      atomicMax(colq + tx * 32 + p.W, cmax);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  acc[0] = s0; acc[1] = s1; acc[2] = s2; acc[3] = s3; acc[4] = s4;
+  yext[0] = ylo; yext[1] = yhi;
+  *unsafe = bad;
+}
+
+// x / z extents in the yaw frame from the per-column depth ranges: threads over the columns.  rho0(u) = fma(N0[0], u, N0[2]),
+// rho2(u) = fma(N2[0], u, N2[2]) (rows 0 and 2 of rotate_y(yaw) @ M; their middle entries are zero here).
+__device__ inline void sep_col_extents(const unsigned* col, int W, const double* N0, const double* N2, int tid, double* ext) {
+  double xlo = INFINITY, xhi = -INFINITY, zlo = INFINITY, zhi = -INFINITY;
+  for (int u = tid; u < W; u += NT) {
+    const unsigned lo = col[u], hi = col[W + u];
+    if (lo <= hi) {   // the column holds a mask pixel
+      const double dlo = (double)__uint_as_float(lo), dhi = (double)__uint_as_float(hi), ud = (double)u;
+      const double q0 = fma(N0[0], ud, N0[2]), q2 = fma(N2[0], ud, N2[2]);
+      const double xa = dlo * q0, xb = dhi * q0, za = dlo * q2, zb = dhi * q2;
+      xlo = fmin(xlo, fmin(xa, xb)); xhi = fmax(xhi, fmax(xa, xb));
+      zlo = fmin(zlo, fmin(za, zb)); zhi = fmax(zhi, fmax(za, zb));
+    }
+  }
+  ext[0] = xlo; ext[1] = xhi; ext[4] = zlo; ext[5] = zhi;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1012,6 +1148,14 @@ __device__ inline int cull_plan(Shared* sh, const FitParams& p, const float* __r
   return nsurv;
 }
 
+// the thread index rebuilt from the wave's scalar index and the lane, opaque to common-subexpression elimination (every use gets
+// its own short-lived register)
+__device__ inline int tid_here(int wave, int lane) {
+  int t = (wave << 6) | lane;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+
 // ------------------------------------------------------------------------------------------
 // instance engine: one workgroup per instance
 // ------------------------------------------------------------------------------------------
@@ -1029,8 +1173,13 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
   // TILED only: compacted list of active tile ids
   unsigned short* list = reinterpret_cast<unsigned short*>(smem + p.mask_lds_bytes + sizeof(Shared));
 
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: lives in an SGPR
+  // (builds that carry the separable pass take the lane from the execution mask, not from threadIdx.x - the workgroup's waves are
+  // full -, and rebuild the thread index where it is used: neither then keeps the kernel's input register alive across the passes)
+  constexpr bool REBUILD_TID = LA3D_LDSKEEP0 && TILED && !SAMPLE && RET == 0;
+  const int tid_in = threadIdx.x;
+  const int lane = REBUILD_TID ? (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) : (tid_in & 63);
+  const int wave = __builtin_amdgcn_readfirstlane(tid_in >> 6);  // wave-uniform: lives in an SGPR
+  const int tid = REBUILD_TID ? ((wave << 6) | lane) : tid_in;
 #ifdef LA3D_TIMELINE
   const unsigned long long t_entry = wall_clock64();   // before the first memory access of the workgroup
 #endif
@@ -1053,7 +1202,7 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
 #else
   const int inst = p.order_nch > 0 ? order_select(p, (int)blockIdx.x, sh, wave, lane) : xcd_remap(blockIdx.x, p.B);
 #endif
-  if (tid == 0) sh->order_inst = inst;   // (re-read after the mask stage, see below)
+  if (tid == 0) { sh->order_inst = inst; sh->sep_bad = 0; }   // (the instance is re-read after the mask stage, see below)
   const int img = p.image_index ? p.image_index[inst] : inst;
   const int HW = p.HW;
   const float* dpl = p.depth + (long long)img * p.depth_plane_stride;
@@ -1063,7 +1212,7 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
     // per-instance geometry (reference src/util.py:56, src/util_3dbox.py:128-134), one lane, overlapped with the
     // mask stream of everyone else: Kinv, Rg, M = Rg^T Kinv
     double Kinv[9], Rg[9];
-    inv3_cofactor(p.K + (long long)img * p.k_stride, Kinv);
+    inv3_camera(p.K + (long long)img * p.k_stride, Kinv);
     sh->bad_ground = ground_rotation(p.ground ? p.ground + (long long)inst * 4 : nullptr, Rg);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -1196,6 +1345,11 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
   // (from here on the instance index is re-read from LDS: live across the decode stage it costs the polygon build a spilled
   // register pair)
   const int inst_p = __builtin_amdgcn_readfirstlane(sh->order_inst);
+  // (and from here on the thread index is rebuilt where it is used - one v_lshl_or from the wave's scalar index and the lane -
+  // instead of staying live from kernel entry: with the separable pass in the kernel the allocator otherwise spills it to scratch,
+  // and a kernel with scratch launches its waves visibly slower: round 5, B = 8192 590 -> 670 us)
+  const int tid_plain = tid;
+#define tid (REBUILD_TID ? tid_here(wave, lane) : tid_plain)
   if (SRC != 0 && LDSMASK && p.filter_boundary >= 0) {   // uniform
     // the reference's instance filter (src/util.py:375) on the bit image just built: a dropped instance costs no passes
     int st4[4];
@@ -1239,6 +1393,9 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
   // depth tiles between the passes (sweep_tiled)
   constexpr bool LK = LA3D_LDSKEEP0 && TILED && !SAMPLE && RET == 0;
   int compact = 0;
+  // separable single pass (sweep_sep): no ground rotation, no skew - x ray by column, y ray by row, z = depth
+  bool sep = false;
+  const bool sep_cam = LK && !p.sep_off && Mg[1] == 0.0 && Mg[3] == 0.0 && Mg[6] == 0.0 && Mg[7] == 0.0 && Mg[8] == 1.0;   // uniform
   if (TILED && !sampled) {
     const int ntiles = p.ntx * p.nty, per = p.tiles_per_wave;
     const int tbeg = wave * per, tend = min(tbeg + per, ntiles);
@@ -1322,6 +1479,12 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
             }
             off += __popcll(bal[k]);
           }
+          if (sep_cam && nactive * 32 + sep_col_words(p.W) * 4 <= p.mask_lds_bytes) {   // uniform
+            sep = true;   // per-column depth range behind the entries: [min | max], the identities of unsigned min / max
+            unsigned* col = bits + nactive * 8;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+            for (int u = tid; u < p.W; u += NT) { col[u] = 0xffffffffu; col[p.W + u] = 0u; }
+          }
         }
       }
     } else {
@@ -1358,6 +1521,36 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
     __syncthreads();
   }
 
+  // ---- separable single pass: moments, y extent and per-column depth ranges in ONE walk; x / z extents from the ranges -------
+  if constexpr (LK) {
+    if (sep) {   // uniform
+      LA3D_STAMP(2);
+      unsigned* col = bits + nactive * 8;
+      double sacc[5] = {0, 0, 0, 0, 0}, yx[2] = {INFINITY, -INFINITY};
+      unsigned unsafe = 0u;
+      sweep_sep(p, dpl, bits, list, nactive, Mg, col, wave, lane, sacc, yx, &unsafe);
+      if (__ballot(unsafe >= 0x7f800000u) != 0ull && lane == 0) sh->sep_bad = 1;   // NaN / inf / negative depth under the mask
+      // (the wave's y extent waits in scalar registers while the axis is computed: four vector registers fewer across that stage)
+      const double ylo_w = uniform_f64(wave_min(yx[0])), yhi_w = uniform_f64(wave_max(yx[1]));
+      LA3D_STAMP(3);
+      stage_moments_to_axis(sh, p, inst_p, sacc, nmask, nmask, tid, wave, lane, true);
+      LA3D_STAMP(4);
+      if (!(sh->redo || sh->sep_bad)) {   // uniform
+        if (sh->st != LA3D_BOX_OK) return;
+        double N0[3], N2[3], ext[6];
+        yaw_rows(sh, Mg, N0, N2);
+        sep_col_extents(col, p.W, N0, N2, tid, ext);
+        ext[2] = ylo_w; ext[3] = yhi_w;
+        LA3D_STAMP(5);
+        stage_extents_to_box(sh, p, inst_p, ext, tid, wave, lane);
+        stage_status_aux(sh, p, inst_p, tid);
+        LA3D_STAMP(6);
+        return;
+      }
+      __syncthreads();   // everyone has read redo / sep_bad and the partials: on to the general two-pass path
+    }
+  }
+
   // pass-B tile culling (see cull_plan): instances with enough active tiles record every tile's depth range in pass A
   bool cull = false;
   int rng_words = 0;
@@ -1368,6 +1561,8 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
       cull = nactive >= p.cull_min && nactive <= CULL_MAXT;
       if (!cull) {
         unsigned short* surv = reinterpret_cast<unsigned short*>(bits + nactive * 8);
+        // (vectorised, the index vector tid + {0, 512, 1024, 1536} becomes a 128-bit register tuple that lives from kernel entry: a spill)
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
         for (int t = tid; t < nactive; t += NT) surv[t] = (unsigned short)t;   // (visible after the barriers of the axis stage)
       }
     }
@@ -1560,6 +1755,7 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
   stage_status_aux(sh, p, inst_p, tid);
   LA3D_STAMP(6);
 }
+#undef tid
 
 // ------------------------------------------------------------------------------------------
 // band engine (round 4): NB workgroups per instance, one per band of tile rows - the work item finer than an instance
@@ -1723,7 +1919,7 @@ __device__ inline void band_takeover(Shared* sh, const FitParams& p, int inst, i
   const int img = p.image_index ? p.image_index[inst] : inst;
   if (tid == NT - 1) {   // M in FRAME rows again (the band kernel keeps band-local rows); Rg and bad_ground stand
     double Kinv[9];
-    inv3_cofactor(p.K + (long long)img * p.k_stride, Kinv);
+    inv3_camera(p.K + (long long)img * p.k_stride, Kinv);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -1776,7 +1972,7 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_bands_kernel(const FitParams 
   if (tid == NT - 1) {
     // per-instance geometry as in the instance engine, in BAND-LOCAL pixel rows: v = v' + row0 folds into the constant column
     double Kinv[9], Rg[9];
-    inv3_cofactor(p.K + (long long)img * p.k_stride, Kinv);
+    inv3_camera(p.K + (long long)img * p.k_stride, Kinv);
     sh->bad_ground = ground_rotation(p.ground ? p.ground + (long long)inst * 4 : nullptr, Rg);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -1902,6 +2098,7 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_bands_kernel(const FitParams 
     cull = LA3D_CULL && nactive >= p.cull_min && nactive <= CULL_MAXT;
     if (!cull) {
       unsigned short* surv = reinterpret_cast<unsigned short*>(bits + nactive * 8);
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
       for (int t = tid; t < nactive; t += NT) surv[t] = (unsigned short)t;
     }
   }
@@ -2325,17 +2522,14 @@ __global__ __launch_bounds__(NTP) void fit_points_kernel(const PtsParams p) {
 // lives in its wave: the ground rotation and the axis are computed redundantly by all lanes (their inputs are wave-uniform), the
 // reductions are DPP wave reductions, the box is written lane-parallel - no LDS, no barrier.  The second walk re-reads the points
 // (12 KB per 500-point cloud: cache hits).  Same arithmetic per point as fit_points_kernel; the sums associate differently.
-__global__ __launch_bounds__(NTP) void fit_points_wave_kernel(const PtsParams p) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * (NTP / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (c >= p.B) return;   // wave-uniform
-  const long long off = p.offsets[c];
-  const long long n_in = p.offsets[c + 1] - off;
-  const bool sampled = p.sample_idx != nullptr && n_in > LA3D_NSAMPLE;  // reference :123
+// one cloud by one wave (all 64 lanes): `pts` = the cloud's rows (global memory, or LDS for la3d_estimate_bbox_host - after inlining
+// the address space is static)
+__device__ __forceinline__ void fit_cloud_wave(const double* pts, long long n_in, const int* sidx, const double* ground, double* out,
+                                      int* status, double* aux, int lane) {
+  const bool sampled = sidx != nullptr;
   const long long m = sampled ? LA3D_NSAMPLE : n_in;
-  const int* sidx = sampled ? p.sample_idx + (long long)c * LA3D_NSAMPLE : nullptr;
   double Rg[9];
-  const int bad_ground = ground_rotation(p.ground ? p.ground + (long long)c * 4 : nullptr, Rg);
+  const int bad_ground = ground_rotation(ground, Rg);
   double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, ylo = INFINITY, yhi = -INFINITY;
   int n = 0, ninf = 0;
   for (long long i = lane; i < m; i += 64) {
@@ -2344,7 +2538,7 @@ __global__ __launch_bounds__(NTP) void fit_points_wave_kernel(const PtsParams p)
       const long long r = sidx[i];
       row = r < 0 ? 0 : (r >= n_in ? n_in - 1 : r);
     }
-    const double* q = p.points + (off + row) * 3;
+    const double* q = pts + row * 3;
     const double a = q[0], b = q[1], cc = q[2];
     const double x = a * Rg[0] + b * Rg[3] + cc * Rg[6];                 // rotated = in_pc @ Rg   (:136)
     const double y = a * Rg[1] + b * Rg[4] + cc * Rg[7];
@@ -2367,12 +2561,9 @@ __global__ __launch_bounds__(NTP) void fit_points_wave_kernel(const PtsParams p)
   double cy = NAN, sy = NAN, gap = NAN;
   if (st == LA3D_BOX_OK) axis_from_sums((double)nn, s0, s1, s2, s3, s4, &cy, &sy, &gap);
   if (lane == 0) {
-    if (p.aux) {
-      double* a = p.aux + (long long)c * LA3D_AUX;
-      a[0] = atan2(sy, cy); a[1] = (double)nn; a[2] = (double)n_in; a[3] = gap;
-    }
-    p.status[c] = st;
-    if (st != LA3D_BOX_OK) write_nan_box(p.out + (long long)c * LA3D_REC);
+    if (aux) { aux[0] = atan2(sy, cy); aux[1] = (double)nn; aux[2] = (double)n_in; aux[3] = gap; }
+    *status = st;
+    if (st != LA3D_BOX_OK) write_nan_box(out);
   }
   if (st != LA3D_BOX_OK) return;   // wave-uniform
   double xlo = INFINITY, xhi = -INFINITY, zlo = INFINITY, zhi = -INFINITY;
@@ -2382,7 +2573,7 @@ __global__ __launch_bounds__(NTP) void fit_points_wave_kernel(const PtsParams p)
       const long long r = sidx[i];
       row = r < 0 ? 0 : (r >= n_in ? n_in - 1 : r);
     }
-    const double* q = p.points + (off + row) * 3;
+    const double* q = pts + row * 3;
     const double a = q[0], b = q[1], cc = q[2];
     const double x = a * Rg[0] + b * Rg[3] + cc * Rg[6];
     const double y = a * Rg[1] + b * Rg[4] + cc * Rg[7];
@@ -2393,7 +2584,55 @@ __global__ __launch_bounds__(NTP) void fit_points_wave_kernel(const PtsParams p)
     }
   }
   const double xmin = wave_min(xlo), xmax = wave_max(xhi), zmin = wave_min(zlo), zmax = wave_max(zhi);
-  write_box_wave(p.out + (long long)c * LA3D_REC, Rg, cy, sy, xmin, xmax, ymin, ymax, zmin, zmax, lane);
+  write_box_wave(out, Rg, cy, sy, xmin, xmax, ymin, ymax, zmin, zmax, lane);
+}
+
+__global__ __launch_bounds__(NTP) void fit_points_wave_kernel(const PtsParams p) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * (NTP / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (c >= p.B) return;   // wave-uniform
+  const long long off = p.offsets[c];
+  const long long n_in = p.offsets[c + 1] - off;
+  const bool sampled = p.sample_idx != nullptr && n_in > LA3D_NSAMPLE;  // reference :123
+  fit_cloud_wave(p.points + off * 3, n_in, sampled ? p.sample_idx + (long long)c * LA3D_NSAMPLE : nullptr,
+                 p.ground ? p.ground + (long long)c * 4 : nullptr, p.out + (long long)c * LA3D_REC, p.status + c,
+                 p.aux ? p.aux + (long long)c * LA3D_AUX : nullptr, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// la3d_estimate_bbox_host (round 5): ONE cloud that lives in HOST memory - the reference's own calling pattern, estimate_bbox once
+// per object on a NumPy array (src/util_3dbox.py:273-278).  The block is the library's pinned, device-mapped staging buffer:
+// [0] offsets (unused) | [32] ground 4 f64 | [64] record 39 f64 | [376] aux 4 f64 | [408] status i32 | [416] done u32 |
+// [512] points n x 3 f64.  The kernel pulls the cloud over the host link into LDS with 16-byte loads (one round trip for a
+// 500-point cloud), fits it there - PCA: the arithmetic of fit_points_wave_kernel, bit for bit - writes the record straight back
+// into the block and stores the call's sequence number into `done` with a system-scope release: the host polls that word.
+// ------------------------------------------------------------------------------------------
+constexpr int HOSTFIT_MAXN = 1024;          // rows staged through LDS (24 KiB); larger clouds are read in place
+constexpr size_t HOSTFIT_HDR = 512;
+__global__ __launch_bounds__(NTP) void fit_points_host_kernel(unsigned char* blk, long long n, int has_ground, unsigned seq) {
+  __shared__ __attribute__((aligned(16))) double stage[HOSTFIT_MAXN * 3];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const double* pts = reinterpret_cast<const double*>(blk + HOSTFIT_HDR);
+  const bool staged = n <= HOSTFIT_MAXN;
+  if (staged) {
+    const int n16 = (int)((n * 24 + 15) / 16);   // (the staging buffer is padded: reading the last partial 16 bytes is safe)
+    const u32x4* src = reinterpret_cast<const u32x4*>(pts);
+    u32x4* dst = reinterpret_cast<u32x4*>(stage);
+    for (int i = tid; i < n16; i += NTP) dst[i] = src[i];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const double* ground = has_ground ? reinterpret_cast<const double*>(blk + 32) : nullptr;
+    double* out = reinterpret_cast<double*>(blk + 64);
+    double* aux = reinterpret_cast<double*>(blk + 376);
+    int* status = reinterpret_cast<int*>(blk + 408);
+    if (staged) fit_cloud_wave(stage, n, nullptr, ground, out, status, aux, lane);
+    else fit_cloud_wave(pts, n, nullptr, ground, out, status, aux, lane);
+    // every lane's stores are complete and visible to the host before the flag
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(reinterpret_cast<unsigned*>(blk + 416), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3772,6 +4011,7 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   p.lds_keep_off = 0;
   p.stagger_ticks = 0;
   p.band_test = config().band_test;
+  p.sep_off = (config().sep == 0 || (opts && opts->build == LA3D_BUILD_PLAIN)) ? 1 : 0;
   p.band_trows = 0; p.band_arrive = nullptr; p.band_tag = 0; p.band_xch = nullptr;
   p.cull_min = config().cull_min > 0 ? config().cull_min : (mask != nullptr ? config().cull_min_u8 : CULL_MIN);
   p.filter_boundary = -1; p.filter_min_area = 0; p.filter_max_edge = 0; p.filter_stats = nullptr;
@@ -4250,5 +4490,151 @@ int la3d_fit_points(const double* points, const int64_t* offsets, const double* 
     hipLaunchKernelGGL(fit_points_kernel<false>, dim3(B), dim3(NTP), 0, static_cast<hipStream_t>(stream), p);
   return check_launch("fit_points_kernel");
 }
+
+
+// ------------------------------------------------------------------------------------------
+// Host-pointer single calls (round 5): the reference calls estimate_bbox once per object on a NumPy cloud
+// (src/util_3dbox.py:273-278) and depth_to_points once per image on a NumPy frame (src/batch_scripts/depth.py:154).  One C call =
+// upload + kernel + download on a private stream of the calling thread; the staging memory (pinned + device-mapped for the cloud,
+// device scratch for the frame) belongs to the library, is per thread and per device, grows on demand and is kept.
+// ------------------------------------------------------------------------------------------
+namespace {
+struct HostCtx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  unsigned char* pin = nullptr;      // pinned host block, mapped into the device's address space
+  unsigned char* pin_dev = nullptr;  // ... its device address
+  size_t pin_bytes = 0;
+  unsigned char* dev = nullptr;      // device scratch
+  size_t dev_bytes = 0;
+  unsigned seq = 0;
+};
+thread_local HostCtx t_host;
+
+void host_ctx_release(HostCtx& c) {
+  if (c.stream) { (void)hipStreamSynchronize(c.stream); (void)hipStreamDestroy(c.stream); }
+  if (c.pin) (void)hipHostFree(c.pin);
+  if (c.dev) (void)hipFree(c.dev);
+  c = HostCtx();
+  (void)hipGetLastError();
+}
+
+int host_ctx(HostCtx** out, size_t pin_need, size_t dev_need, const char* who) {
+  HostCtx& c = t_host;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { snprintf(g_err, sizeof(g_err), "%s: no device", who); (void)hipGetLastError(); return LA3D_ERR_HIP; }
+  if (c.device != dev) {
+    if (c.device >= 0) {   // the thread moved to another GPU: the old context's memory belongs to the old device
+      int cur = dev;
+      (void)hipSetDevice(c.device);
+      host_ctx_release(c);
+      (void)hipSetDevice(cur);
+    }
+    c.device = dev;
+    if (hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) != hipSuccess) {
+      snprintf(g_err, sizeof(g_err), "%s: hipStreamCreate failed", who); (void)hipGetLastError(); c = HostCtx(); return LA3D_ERR_HIP;
+    }
+  }
+  auto grow = [](size_t need) { size_t n = 64 * 1024; while (n < need) n *= 2; return n; };
+  if (pin_need > c.pin_bytes) {
+    (void)hipStreamSynchronize(c.stream);
+    if (c.pin) (void)hipHostFree(c.pin);
+    c.pin = nullptr; c.pin_bytes = 0;
+    const size_t n = grow(pin_need);
+    void* h = nullptr; void* d = nullptr;
+    if (hipHostMalloc(&h, n, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+      if (h) (void)hipHostFree(h);
+      snprintf(g_err, sizeof(g_err), "%s: cannot allocate %zu bytes of pinned staging memory", who, n); (void)hipGetLastError(); return LA3D_ERR_HIP;
+    }
+    memset(h, 0, HOSTFIT_HDR);
+    c.pin = static_cast<unsigned char*>(h); c.pin_dev = static_cast<unsigned char*>(d); c.pin_bytes = n;
+  }
+  if (dev_need > c.dev_bytes) {
+    (void)hipStreamSynchronize(c.stream);
+    if (c.dev) (void)hipFree(c.dev);
+    c.dev = nullptr; c.dev_bytes = 0;
+    const size_t n = grow(dev_need);
+    void* d = nullptr;
+    if (hipMalloc(&d, n) != hipSuccess) {
+      snprintf(g_err, sizeof(g_err), "%s: cannot allocate %zu bytes of device scratch", who, n); (void)hipGetLastError(); return LA3D_ERR_HIP;
+    }
+    c.dev = static_cast<unsigned char*>(d); c.dev_bytes = n;
+  }
+  *out = &c;
+  return LA3D_SUCCESS;
+}
+}  // namespace
+
+int la3d_estimate_bbox_host(const double* points, int64_t n, const double* ground4, int method, double* out39, double* aux4,
+                            int32_t* status) {
+  if (n < 0 || (n > 0 && !points) || !out39 || !status || n > (int64_t)1 << 31) {
+    set_err("la3d_estimate_bbox_host: bad argument");
+    return LA3D_ERR_ARG;
+  }
+  if (method != LA3D_METHOD_PCA && method != LA3D_METHOD_CONVEX_HULL) {
+    set_err("la3d_estimate_bbox_host: unknown method");
+    return LA3D_ERR_ARG;
+  }
+  HostCtx* c = nullptr;
+  const int rc = host_ctx(&c, HOSTFIT_HDR + (size_t)n * 24 + 16, 0, "la3d_estimate_bbox_host");
+  if (rc != LA3D_SUCCESS) return rc;
+  if (n > 0) memcpy(c->pin + HOSTFIT_HDR, points, (size_t)n * 24);
+  const int has_ground = ground4 != nullptr && ground4[0] == ground4[0];   // NULL or a NaN first entry: "ground_equ is None"
+  if (has_ground) memcpy(c->pin + 32, ground4, 32);
+  *reinterpret_cast<int32_t*>(c->pin + 408) = -1;
+  if (method == LA3D_METHOD_PCA) {
+    if (++c->seq == 0) c->seq = 1;
+    volatile unsigned* done = reinterpret_cast<volatile unsigned*>(c->pin + 416);
+    hipLaunchKernelGGL(fit_points_host_kernel, dim3(1), dim3(NTP), 0, c->stream, c->pin_dev, (long long)n, has_ground, c->seq);
+    const int lrc = check_launch("fit_points_host_kernel");
+    if (lrc != LA3D_SUCCESS) return lrc;
+    // the kernel stores the sequence number last (system-scope release): poll it for a while, then fall back to the runtime's wait
+    bool seen = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0; !seen; ++spins) {
+      seen = *done == c->seq;
+      if (!seen && (spins & 255u) == 255u &&
+          std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > 2000) break;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (!seen && hipStreamSynchronize(c->stream) != hipSuccess) return check_launch("la3d_estimate_bbox_host");
+  } else {
+    long long* offs = reinterpret_cast<long long*>(c->pin);
+    offs[0] = 0; offs[1] = n;
+    PtsParams p;
+    p.points = reinterpret_cast<const double*>(c->pin_dev + HOSTFIT_HDR); p.offsets = reinterpret_cast<const long long*>(c->pin_dev);
+    p.ground = has_ground ? reinterpret_cast<const double*>(c->pin_dev + 32) : nullptr; p.sample_idx = nullptr; p.B = 1; p.method = method;
+    p.out = reinterpret_cast<double*>(c->pin_dev + 64); p.status = reinterpret_cast<int*>(c->pin_dev + 408);
+    p.aux = reinterpret_cast<double*>(c->pin_dev + 376);
+    hipLaunchKernelGGL(fit_points_kernel<true>, dim3(1), dim3(NTP), 0, c->stream, p);
+    const int lrc = check_launch("fit_points_kernel");
+    if (lrc != LA3D_SUCCESS) return lrc;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return check_launch("la3d_estimate_bbox_host");
+  }
+  memcpy(out39, c->pin + 64, LA3D_REC * sizeof(double));
+  if (aux4) memcpy(aux4, c->pin + 376, LA3D_AUX * sizeof(double));
+  *status = *reinterpret_cast<const int32_t*>(c->pin + 408);
+  return LA3D_SUCCESS;
+}
+
+int la3d_unproject_host(const float* depth, const double* K9, const double* Rt12, int H, int W, void* out, int out_is_f64) {
+  if (!depth || !K9 || !out || H <= 0 || W <= 0 || (long long)H * W > 0x7fffffffLL / 4) {
+    set_err("la3d_unproject_host: bad argument");
+    return LA3D_ERR_ARG;
+  }
+  const size_t in_bytes = (size_t)H * W * 4, out_bytes = (size_t)H * W * 3 * (out_is_f64 ? 8 : 4);
+  const size_t out_off = (in_bytes + 255) & ~(size_t)255;
+  HostCtx* c = nullptr;
+  int rc = host_ctx(&c, 0, out_off + out_bytes, "la3d_unproject_host");
+  if (rc != LA3D_SUCCESS) return rc;
+  if (hipMemcpyAsync(c->dev, depth, in_bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) return check_launch("la3d_unproject_host: upload");
+  rc = la3d_unproject(reinterpret_cast<const float*>(c->dev), K9, Rt12, H, W, c->dev + out_off, out_is_f64, c->stream);
+  if (rc != LA3D_SUCCESS) return rc;
+  if (hipMemcpyAsync(out, c->dev + out_off, out_bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return check_launch("la3d_unproject_host: download");
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return check_launch("la3d_unproject_host");
+  return LA3D_SUCCESS;
+}
+
+void la3d_host_release(void) { host_ctx_release(t_host); }
 
 }  // extern "C"

@@ -45,6 +45,7 @@ struct Config {
   double stagger_us;   // LA3D_STAGGER_US (< 0: the computed default)
   int split_grid;      // LA3D_SPLIT_GRID (0: by batch size)
   int split_sub;       // LA3D_SPLIT_SUB (0: by batch size)
+  int sep;             // LA3D_SEP=0: the separable single pass off (two passes for every camera)
   int band_test;       // LA3D_BAND_TEST (tests only): 1 = band 1 of every third instance never arrives and the watchdog is short (the
                        // takeover path runs); 2 = blocks permuted so that the bands of an instance sit on different XCDs
 };
@@ -138,6 +139,14 @@ __device__ inline void inv3_cofactor(const double* A, double* X) {
   X[0] = c00 * inv; X[1] = (c * h - b * i) * inv; X[2] = (b * f - c * e) * inv;
   X[3] = c01 * inv; X[4] = (a * i - c * g) * inv; X[5] = (c * d - a * f) * inv;
   X[6] = c02 * inv; X[7] = (b * g - a * h) * inv; X[8] = (a * e - b * d) * inv;
+}
+
+// Camera intrinsics: the cofactor inverse, with the last row exact for an affine camera (K's last row (0, 0, 1): the true inverse
+// has exactly (0, 0, 1) there, and so has LAPACK's - back substitution divides 1 by 1 -, while (a e) * (1 / (a e)) may round to
+// 1 - ulp).  z = depth EXACTLY for an un-grounded call is what the separable single pass of la3d.hip keys on.
+__device__ inline void inv3_camera(const double* A, double* X) {
+  inv3_cofactor(A, X);
+  if (A[6] == 0.0 && A[7] == 0.0 && A[8] == 1.0) { X[6] = 0.0; X[7] = 0.0; X[8] = 1.0; }
 }
 
 // Rg of reference src/util_3dbox.py:128-134 (+ :20-25, :37-55).  ground == nullptr or a NaN
@@ -507,6 +516,7 @@ struct FitParams {
   unsigned long long band_tag;
   double* band_xch;
   int band_test;       // Config::band_test
+  int sep_off;         // 1: never take the separable single pass (LA3D_SEP=0, opt_build = LA3D_BUILD_PLAIN)
   double* out;
   int* status;
   double* aux;
@@ -532,7 +542,8 @@ struct alignas(16) Shared {
   int nm;          // mask pixels (aux[2])
   int order_inst;  // the instance this workgroup fits (size-balanced launch order)
   unsigned qhead;  // pass B: head of the LDS work queue over the not-retained part of the active-tile list
-  unsigned qpad[3];
+  int sep_bad;     // separable single pass: a NaN / inf / negative depth under the mask - re-run the general path
+  unsigned qpad[2];
 #ifdef LA3D_TIMELINE
   double* tl;      // measurement build: this workgroup's stamp row (profiles/timeline.py)
 #endif

@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 from . import options
-from ._lib import AUX, REC, check, lib
+from ._lib import AUX, BOX_FILTERED, REC, check, lib
 from .batched import InstanceFitter, _as_dev, _bulk, _dev, _ptr, _record, _stream, _upload_many
 
 
@@ -376,6 +376,56 @@ def fit_annotations(annotations, image_size, depth, K, ground=None, boundary_thr
     pt = torch.as_tensor(pos, device=dev)
     return ([annotations[i]["bbox"] for i in kept], kept, [annotations[i]["category_id"] for i in kept],
             boxes_c.index_select(0, pt), status_c.index_select(0, pt))
+
+
+def split_annotations(annotations):
+    """Annotations by segmentation kind, as ``read_bounding_boxes_segmentations`` treats them (reference src/util.py:355-367):
+    crowd annotations and annotations without a segmentation are skipped; a dict with ``counts`` is a run-length mask, anything
+    else a list of polygon parts.  Returns {"rle": (indices, segmentations), "poly": (indices, segmentations)}."""
+    groups = {"rle": ([], []), "poly": ([], [])}
+    for i, a in enumerate(annotations):
+        if a.get("iscrowd") or "segmentation" not in a:
+            continue
+        seg = a["segmentation"]
+        kind = "rle" if isinstance(seg, dict) and "counts" in seg else "poly"
+        groups[kind][0].append(i)
+        groups[kind][1].append({"size": seg["size"], "counts": seg["counts"]} if kind == "rle" else seg)
+    return groups
+
+
+def annotation_areas(annotations, default: float = 0.0) -> np.ndarray:
+    """The ``area`` field of every annotation (COCO: the mask area in pixels) - the per-instance cost ``plan_shards`` balances by,
+    known from the annotation file alone."""
+    return np.asarray([float(a.get("area", default) or default) for a in annotations], dtype=np.float64)
+
+
+def fit_annotations_all(annotations, image_size, depth, K, ground=None, image_index=None, filter=None, device=None):
+    """The fit of ``fit_annotations`` with one record per ANNOTATION, in annotation order, on the GPU: ``(boxes (n,39) f64,
+    status (n,) i32)``.  Skipped annotations (crowd, no segmentation) and - with ``filter`` (a dict of ``boundary_threshold`` /
+    ``scale_threshold``, or True for the reference's 10 / 100) - the ones the keep rule drops carry status 6 and a NaN record.
+    One launch per segmentation kind present; the segmentations are decoded / rasterised inside the fit kernel (no u8 plane
+    exists anywhere).  This is the rank-local step of ``shard.fit_annotations_sharded``."""
+    W_img, H_img = int(image_size[0]), int(image_size[1])
+    dev = _dev(device)
+    n = len(annotations)
+    boxes = torch.full((n, REC), float("nan"), dtype=torch.float64, device=dev)
+    status = torch.full((n,), int(BOX_FILTERED), dtype=torch.int32, device=dev)
+    flt = None
+    if filter:
+        flt = {"boundary_threshold": 10, "scale_threshold": 100} if filter is True else dict(filter)
+    for kind, (idx, segs) in split_annotations(annotations).items():
+        if not idx:
+            continue
+        sel = np.asarray(idx, np.int64)
+        sel_t = torch.as_tensor(sel, device=dev)
+        take = lambda v: None if v is None else (v.to(dev)[sel_t] if isinstance(v, torch.Tensor) else np.asarray(v)[sel])  # noqa: E731
+        ar = [annotations[i].get("area") for i in idx]
+        hint = None if any(v is None for v in ar) else np.clip(np.asarray(ar, dtype=np.float64), 0, 2**31 - 1).astype(np.int32)
+        kw = dict(rles=segs) if kind == "rle" else dict(polys=pack_polygons(segs, H_img, W_img))
+        res = fit_instances_ex(depth, K, ground=take(ground), image_index=take(image_index), device=dev, filter=flt, area_hint=hint, **kw)
+        boxes.index_copy_(0, sel_t, res["boxes"])
+        status.index_copy_(0, sel_t, res["status"])
+    return boxes, status
 
 
 def segmentations_to_masks(segmentations, H: int, W: int, device=None) -> torch.Tensor:

@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import numpy as np
 
+from ._lib import check, lib
 from .batched import unproject
 
 
@@ -29,4 +30,14 @@ def depth_to_points(depth, K=None, R=None, t=None):
     d = np.asarray(depth)
     if d.ndim != 3:
         raise ValueError("depth must be (B, H, W)")
-    return unproject(np.ascontiguousarray(d[0], dtype=np.float32), K, R, t).cpu().numpy()
+    # host frame in, host points out: ONE C call (la3d_unproject_host: upload, kernel, download on the library's private stream)
+    d0 = np.ascontiguousarray(d[0], dtype=np.float32)
+    k = np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(3, 3))
+    rt = None
+    if R is not None or t is not None:
+        rt = np.concatenate([(np.eye(3) if R is None else np.asarray(R, dtype=np.float64)).reshape(-1),
+                             (np.zeros(3) if t is None else np.asarray(t, dtype=np.float64)).reshape(-1)])
+    out = np.empty(d0.shape + (3,), np.float64)
+    check(lib.la3d_unproject_host(d0.ctypes.data, k.ctypes.data, None if rt is None else rt.ctypes.data, d0.shape[0], d0.shape[1],
+                                  out.ctypes.data, 1), "la3d_unproject_host")
+    return out

@@ -8,6 +8,7 @@ on 3-vectors that callers use to prepare inputs — and stay NumPy.
 """
 from __future__ import annotations
 
+import ctypes as C
 import json
 import math
 import os
@@ -22,6 +23,7 @@ _CORNER_SIGNS = np.array(
     dtype=np.float64,
 )  # corner order of reference :83-92
 
+_METHODS = {"pca": _lib.METHOD_PCA, "convex_hull": _lib.METHOD_CONVEX_HULL}
 _MESSAGES = {
     _lib.BOX_EMPTY: "No valid points after removing NaN values",  # reference :143
     _lib.BOX_BAD_GROUND: "No valid points after removing NaN values",  # NaN rotation -> every row NaN -> :143
@@ -85,11 +87,18 @@ def _fit_one(in_pc, ground_equ, method, subsample=True):
     ground = None if ground_equ is None else np.asarray(ground_equ, dtype=np.float64).reshape(-1)[:4][None]
     if ground is not None and ground.shape[1] < 4:
         ground = np.concatenate([ground, np.zeros((1, 4 - ground.shape[1]))], axis=1)  # only [:3] is used (:129)
-    # one upload (points | offsets | ground), one launch, one read-back (record | aux | status)
-    *_, packed = fit_points([pc.astype(np.float64, copy=False)], ground, None, method, _packed=True)
-    host = packed.cpu().numpy()
-    rec, aux = host[:_lib.REC], host[_lib.REC:_lib.REC + _lib.AUX]
-    st = int(host[_lib.REC + _lib.AUX:].view(np.int32)[0])
+    if ground is not None:
+        ground = np.ascontiguousarray(ground, dtype=np.float64)
+    # ONE C call on host pointers (la3d_estimate_bbox_host, round 5): the library's pinned block is the staging area, the kernel
+    # pulls the cloud over the link, writes the record back and raises a flag the call polls - no torch tensor in between
+    pts = np.ascontiguousarray(pc, dtype=np.float64)
+    host = np.empty(_lib.REC + _lib.AUX, np.float64)
+    st_c = C.c_int32(-1)
+    _lib.check(_lib.lib.la3d_estimate_bbox_host(pts.ctypes.data, pts.shape[0], None if ground is None else ground.ctypes.data,
+                                                _METHODS[method], host.ctypes.data, host[_lib.REC:].ctypes.data, C.byref(st_c)),
+               "la3d_estimate_bbox_host")
+    rec, aux = host[:_lib.REC], host[_lib.REC:]
+    st = int(st_c.value)
     if st != _lib.BOX_OK:
         raise ValueError(_MESSAGES[st])
     if method == "convex_hull" and aux[3] >= 0:  # no 2-D hull: the kernel took the reference's PCA fallback (:222-224)

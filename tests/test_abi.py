@@ -256,7 +256,7 @@ def test_upload_many_packs_host_arrays_into_one_buffer():
 def test_scheduling_is_per_call_not_process_state():
     """SURVEY 8b 're-entrant ... no global state': two threads issue fits with DIFFERENT per-call scheduling (launch order on / off,
     plain / retaining build of the instance kernel) at the same time, each on its own stream and workspace; both get the records
-    a lone default call gets, bit for bit.  (ABI 1 had a process-wide la3d_set_launch_order; ABI 2 carries the choice in
+    a lone two-pass call gets, bit for bit.  (ABI 1 had a process-wide la3d_set_launch_order; ABI 2 carries the choice in
     la3d_fit_args::opt_*.)"""
     import threading
 
@@ -271,7 +271,7 @@ def test_scheduling_is_per_call_not_process_state():
     B = 600
     depth, masks, K, _, _ = bench.make_inputs(B, dev, 77)
     ref_f = InstanceFitter(B, bench.H, bench.W, dev)
-    with scheduling(engine="instance"):
+    with scheduling(engine="instance", build="plain"):   # (the default build takes the separable single pass here: equal to rounding only)
         want = tuple(t.clone() for t in ref_f.run(depth, masks, K))
     torch.cuda.synchronize()
     results, errors = {}, []

@@ -166,29 +166,40 @@ b, s, a = f.run(depth, masks, K, image_index=ii)
 torch.cuda.synchronize()
 assert int((s != 0).sum()) == 0, s
 print("SHA", hashlib.sha1(b.cpu().numpy().tobytes() + s.cpu().numpy().tobytes() + a.cpu().numpy().tobytes()).hexdigest())
+np.save(sys.argv[1], b.cpu().numpy())
 """
 
 
-def test_speed_knobs_leave_the_records_alone(la):
+def test_speed_knobs_leave_the_records_alone(la, tmp_path):
     import os
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    shas = {}
+    shas, recs = {}, {}
+    two = {"LA3D_SEP": "0"}   # the two-pass plain build (round 5: un-grounded calls take the separable single pass by default)
     for name, env in (("default", {}), ("no stagger", {"LA3D_STAGGER_US": "0"}), ("long stagger", {"LA3D_STAGGER_US": "23"}),
-                      ("cull everything", {"LA3D_CULL_MIN": "1"}), ("cull nothing", {"LA3D_CULL_MIN": "100000"}),
-                      ("retaining build", {"LA3D_RETAIN": "1"}), ("no launch order", {"LA3D_BALANCE": "0"}),
+                      ("no launch order", {"LA3D_BALANCE": "0"}),
                       # the self-estimating launch (no helper kernel): off, and with every seventh workgroup withholding its key,
                       # so that the waiting workgroups time out and compute the missing keys themselves
-                      ("helper kernel", {"LA3D_ORDER_SELF": "0"}), ("self-estimate fallback", {"LA3D_ORDER_SELF": "2"})):
+                      ("helper kernel", {"LA3D_ORDER_SELF": "0"}), ("self-estimate fallback", {"LA3D_ORDER_SELF": "2"}),
+                      ("two-pass", two), ("two-pass, cull everything", dict(two, LA3D_CULL_MIN="1")),
+                      ("two-pass, cull nothing", dict(two, LA3D_CULL_MIN="100000")), ("two-pass, no stagger", dict(two, LA3D_STAGGER_US="0")),
+                      ("retaining build", {"LA3D_RETAIN": "1"})):
         e = dict(os.environ, LA3D_ENGINE="instance", **env)
-        r = subprocess.run([sys.executable, "-c", _KNOB_SCRIPT % root], env=e, capture_output=True, text=True, timeout=600)
+        out = str(tmp_path / (name.replace(" ", "_").replace(",", "") + ".npy"))
+        r = subprocess.run([sys.executable, "-c", _KNOB_SCRIPT % root, out], env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (name, r.stderr[-2000:])
         shas[name] = [ln for ln in r.stdout.splitlines() if ln.startswith("SHA")][0]
-    # the plain build's partial sums are grouped alike whatever the knobs; the retaining build groups them like the plain one as long
-    # as the active tiles fit the plain build's list (rectangles below 400 x 500 px do)
-    assert len(set(shas.values())) == 1, shas
+        recs[name] = np.load(out)
+    # the single pass groups its sums alike whatever the knobs; so does the two-pass plain build, and the retaining build groups them
+    # like the two-pass plain one as long as the active tiles fit the plain build's list (rectangles below 400 x 500 px do)
+    single = {k: v for k, v in shas.items() if not k.startswith("two-pass") and k != "retaining build"}
+    double = {k: v for k, v in shas.items() if k.startswith("two-pass") or k == "retaining build"}
+    assert len(set(single.values())) == 1, single
+    assert len(set(double.values())) == 1, double
+    np.testing.assert_allclose(recs["default"][:, :15], recs["two-pass"][:, :15], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(recs["default"][:, 15:], recs["two-pass"][:, 15:], rtol=0, atol=2e-2)   # fp16-quantised corners
 
 
 @pytest.mark.parametrize("B", [1024, 1500, 2600])

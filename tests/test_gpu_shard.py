@@ -199,19 +199,29 @@ def test_pipelined_batches_and_retaining_build_give_the_same_records(la, monkeyp
             if k >= 1:
                 assert torch.equal(views[k - 1][0], want[k - 1][0])
         assert SCHED().launch_order is True      # fit_batches did not touch the caller's setting
-    monkeypatch.setattr(SCHED(), "build", "retaining")
+    # the retaining build = the two-pass plain build bit for bit; the default build takes the separable single pass for these
+    # un-grounded calls (round 5): equal to rounding
     for (depth, masks, K), w in zip(batches[:2], want[:2]):
+        monkeypatch.setattr(SCHED(), "build", "plain")
+        w2 = tuple(t.clone() for t in la.fit_instances(depth, masks, K))
+        monkeypatch.setattr(SCHED(), "build", "retaining")
         b, s, a = la.fit_instances(depth, masks, K)
-        assert torch.equal(b, w[0]) and torch.equal(s, w[1]) and torch.equal(a, w[2])
+        assert torch.equal(b, w2[0]) and torch.equal(s, w2[1]) and torch.equal(a, w2[2])
+        assert torch.equal(s, w[1])
+        torch.testing.assert_close(b[:, :15], w[0][:, :15], rtol=1e-11, atol=1e-11)
     # a batch with masks above the retained capacity (160 tiles per instance) and a non-finite depth (checked re-run)
     depth, masks, K, _, _ = bench.make_config5(600, dev, 9)
     depth[3, 200, 300] = float("inf")
     masks[3, 190:260, 280:400] = 1
-    monkeypatch.setattr(SCHED(), "build", None)
+    monkeypatch.setattr(SCHED(), "build", "plain")
     w = la.fit_instances(depth, masks, K)
     monkeypatch.setattr(SCHED(), "build", "retaining")
     g = la.fit_instances(depth, masks, K)
     assert torch.equal(g[0], w[0]) and torch.equal(g[1], w[1])
+    monkeypatch.setattr(SCHED(), "build", None)       # default: single pass; instance 3 (inf under the mask) re-runs the two-pass path
+    d = la.fit_instances(depth, masks, K)
+    assert torch.equal(d[1], w[1]) and torch.equal(d[0][3], w[0][3])
+    torch.testing.assert_close(d[0][:, :15], w[0][:, :15], rtol=1e-11, atol=1e-11, equal_nan=True)
 
 
 def test_subsample_mode_on_config5_mix(la):
@@ -239,11 +249,18 @@ def test_subsample_mode_on_config5_mix(la):
     SCHED().engine = "instance"
     try:
         bs, ss, as_ = la.fit_instances(depth, masks, K, sample_idx=idx)
+        SCHED().build = "plain"     # the two-pass walk the subsample build uses for its small masks: bit for bit
         bf, sf, af = la.fit_instances(depth, masks, K)
+        SCHED().build = None        # the default full-mask call takes the separable single pass (round 5): equal to rounding
+        bd, sd, _ = la.fit_instances(depth, masks, K)
     finally:
         SCHED().engine = None
+        SCHED().build = None
     small = torch.as_tensor(counts <= 500, device=dev)
     assert torch.equal(bs[small], bf[small]) and torch.equal(ss[small], sf[small]) and torch.equal(as_[small], af[small])
+    wide = small & (as_[:, 3] > 1e-4)      # (a few of the smallest masks are nearly isotropic: their axis is conditioned like 1 / gap)
+    assert torch.equal(sd, sf)
+    torch.testing.assert_close(bd[wide][:, :15], bf[wide][:, :15], rtol=1e-9, atol=1e-9)
     assert int((ss != 0).sum()) == 0
     order = np.argsort(counts)
     pick = np.unique(np.concatenate([[7, 8, 9], order[:4], order[-4:], order[:: B // 24]]))

@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from labelany3d_amd.shard import Shard, fit_instances_sharded, gather_boxes, partition_contiguous, plan_shards
+from labelany3d_amd.shard import Shard, fit_annotations_sharded, fit_instances_sharded, gather_boxes, partition_contiguous, plan_shards
 
 
 def test_partition_contiguous_balances_cost():
@@ -126,6 +126,38 @@ def _worker(rank, world, port, q):
         out3 = fit_instances_sharded(depth, masks[:3], np.eye(3), img1, fit_fn=_fake_fit)
         if rank == 0:
             assert sorted(out3[2]) == [0, 3] and out3[0].shape == (3, 39)
+        # round 5: the same partitioning on the reference's ANNOTATION formats - every rank holds the annotation list (metadata) and
+        # loads only its own depth planes; the plan balances by the annotations' "area" fields
+        anns = []
+        for n, im in enumerate(img):
+            seg = ([[float(n), 1.0, n + 3.0, 1.0, n + 3.0, 5.0]] if n % 3 else {"size": [H, W], "counts": [n % 7, 5, H * W - 5 - n % 7]})
+            anns.append({"id": 100 + n, "image_id": int(im), "category_id": 1 + n % 5, "bbox": [0, 0, 3, 3], "area": float(10 + 7 * n),
+                         "iscrowd": int(n == 4), "segmentation": seg})
+        loaded = {}
+
+        def depth_loader(sh):
+            loaded["shard"] = sh
+            return depth[sh.img_lo:sh.img_hi].clone(), np.eye(3)
+
+        def fake_ann_fit(annotations, image_size, d, K, ground=None, image_index=None, filter=None):
+            assert image_size == (W, H) and d.shape[0] > int(np.asarray(image_index).max(initial=-1))
+            rec = torch.zeros((len(annotations), 39), dtype=torch.float64)
+            rec[:, 0] = d[torch.as_tensor(np.asarray(image_index), dtype=torch.long), 2, 2].double()   # the plane each annotation saw
+            rec[:, 1] = torch.tensor([a["id"] for a in annotations], dtype=torch.float64)
+            st = torch.tensor([6 if a["iscrowd"] else 0 for a in annotations], dtype=torch.int32)
+            return rec, st
+
+        out4 = fit_annotations_sharded(anns, (W, H), img, P, depth_loader, fit_fn=fake_ann_fit)
+        want_plan = plan_shards(img, P, world, areas=np.array([a["area"] for a in anns]), frame_pixels=H * W)
+        assert loaded["shard"] == want_plan[rank]                         # areas came from the annotations themselves
+        if rank == 0:
+            b4, s4, c4 = out4
+            assert c4 == [p.inst_hi - p.inst_lo for p in want_plan] and b4.shape == (Bt, 39)
+            assert b4[:, 0].tolist() == img.astype(float).tolist()        # every annotation saw its own image's depth plane
+            assert b4[:, 1].tolist() == [100.0 + n for n in range(Bt)]    # global annotation order
+            assert s4.tolist() == [6 if n == 4 else 0 for n in range(Bt)]
+        with pytest.raises(ValueError):
+            fit_annotations_sharded(anns[:-1], (W, H), img, P, depth_loader, fit_fn=fake_ann_fit)
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         import traceback
