@@ -913,9 +913,10 @@ def main():
             "roofline": {
                 "bound": "hbm",
                 "kernel": ("fit_instances_kernel<VEC,LDSMASK,SAMPLE=1> (instance engine, reference-subsample mode)" if args.subsample else
-                           "fit_instances_kernel<VEC,LDSMASK,SAMPLE=0,TILED,SRC,RET=0> (instance engine, plain build: 64 VGPRs, four workgroups per CU, "
-                           "pass-B tile culling; the 128-VGPR retaining build RET=4 is opt-in since round 4; u8 planes with "
-                           "16 <= B <= 256 take the band engine fit_bands_kernel<NB>, smaller u8 batches and B <= 288 run lengths / polygons the split engine)"),
+                           "fit_instances_kernel<VEC,LDSMASK,SAMPLE=0,TILED,SRC,RET=0> (instance engine: 64 VGPRs, four workgroups per CU; round 5: "
+                           "un-grounded, skew-free cameras - every BASELINE config - take the SEPARABLE SINGLE PASS: one walk over the depth, moments "
+                           "factorised per column, x / z extents from per-column depth ranges in LDS, no pass B; grounded calls keep the two-pass "
+                           "form with pass-B tile culling)"),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",

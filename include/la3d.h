@@ -319,6 +319,18 @@ int la3d_estimate_bbox_host(const double* points, int64_t n, const double* groun
 int la3d_unproject_host(const float* depth, const double* K9, const double* Rt12, int H, int W, void* out, int out_is_f64);
 void la3d_host_release(void);   /* frees the calling thread's staging memory and stream (optional) */
 
+/* The reference's per-scene box file from packed records, on the HOST (round 5; labelany3d_amd/csrc/la3d_json.cpp): the text
+ * json.dump([{"obj_id", "category_name", "center_cam", "R_cam", "dimensions", "bbox3D_cam"}, ...], f) writes - reference
+ * src/util_3dbox.py:283-292 - byte for byte (floats as float.__repr__ prints them), for S scenes in one call, without a Python
+ * object per record.  records host f64 [*][39]; scene s owns entries [scene_off[s], scene_off[s+1]) of rows (record row) / obj_ids /
+ * name_ids (index into names_json: UTF-8, already JSON-escaped and quoted); out: host buffer of `cap` bytes
+ * (la3d_3dbbox_json_bound(entries, total name bytes, S)); text_off [S+1]: scene s's text = out[text_off[s] .. text_off[s+1]).
+ * Returns the bytes written, -1 if cap is too small or an argument is missing. */
+int64_t la3d_3dbbox_json_bound(int64_t n, int64_t name_bytes, int64_t S);
+int64_t la3d_format_3dbbox_json(const double* records, const int64_t* rows, const int32_t* obj_ids, const int32_t* name_ids,
+                                const int64_t* scene_off, int32_t S, const char* const* names_json, char* out, int64_t cap,
+                                int64_t* text_off);
+
 /* Host-side helper exported for tests: float64 -> float16 (round-to-nearest-even, as NumPy's
  * astype(float16), reference src/util_3dbox.py:165) -> float64, the same routine the kernels use. */
 double la3d_f16_round_host(double x);

@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "la3d.hip")
-SOURCES = [SRC, os.path.join(HERE, "csrc", "la3d_split.hip")]
+SOURCES = [SRC, os.path.join(HERE, "csrc", "la3d_split.hip"), os.path.join(HERE, "csrc", "la3d_json.cpp")]
 HEADERS = [os.path.join(HERE, "csrc", "la3d_device.hpp"), os.path.join(HERE, "csrc", "la3d_poly.hpp"), os.path.join(ROOT, "include", "la3d.h")]
 LIB = os.environ.get("LA3D_LIB") or os.path.join(HERE, "lib", "libla3d.so")  # LA3D_LIB: experiment builds only
 INCLUDE = os.path.join(ROOT, "include")

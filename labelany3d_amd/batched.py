@@ -60,10 +60,12 @@ def _as_dev(x, dtype, device, cache: bool = False) -> torch.Tensor:
     return torch.as_tensor(np.ascontiguousarray(a), device=device).to(dtype).contiguous()
 
 
-def _upload_many(arrays, device):
+def _upload_many(arrays, device, pinned: Optional[torch.Tensor] = None):
     """Several small host arrays -> device tensors with ONE host-to-device copy (each separate upload costs ~17 us of launch
     overhead on this stack; the per-image wrappers have six to eight of them).  ``arrays``: list of (ndarray | None, torch dtype);
-    None stays None.  The views share one device buffer (16-byte aligned pieces)."""
+    None stays None.  The views share one device buffer (16-byte aligned pieces).  ``pinned``: a pinned uint8 staging buffer of at
+    least the packed size - the copy is then asynchronous on the current stream (the caller keeps the buffer untouched until that
+    stream has passed the copy)."""
     metas, total = [], 0
     for a, dt in arrays:
         if a is None:
@@ -77,11 +79,19 @@ def _upload_many(arrays, device):
         total += (h.nbytes + 15) & ~15
     if total == 0:
         return [None if m is None else torch.empty(m[0].shape, dtype=arrays[i][1], device=device) for i, m in enumerate(metas)]
-    buf = np.empty(total, np.uint8)
+    if pinned is not None and pinned.numel() >= total:
+        buf = pinned.numpy()[:total]
+    else:
+        pinned = None
+        buf = np.empty(total, np.uint8)
     for m in metas:
         if m is not None and m[0].nbytes:
             buf[m[1]:m[1] + m[0].nbytes] = m[0].reshape(-1).view(np.uint8)
-    dbuf = torch.as_tensor(buf, device=device)
+    if pinned is not None:
+        dbuf = torch.empty(total, dtype=torch.uint8, device=device)
+        dbuf.copy_(pinned[:total], non_blocking=True)
+    else:
+        dbuf = torch.as_tensor(buf, device=device)
     out = []
     for (a, dt), m in zip(arrays, metas):
         if m is None:

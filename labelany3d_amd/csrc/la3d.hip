@@ -69,6 +69,8 @@ const Config& config() {
     k.order_self = e ? atoi(e) : 1;
     e = getenv("LA3D_STAGGER_US");
     k.stagger_us = e ? atof(e) : -1.0;
+    e = getenv("LA3D_STAGGER_NOMASK_US");   // run-length / polygon input: stagger period of the resident groups (0 / unset: none)
+    k.stagger_nomask_us = e ? atof(e) : 0.0;
     e = getenv("LA3D_SPLIT_GRID");
     k.split_grid = (e && atoi(e) > 0) ? atoi(e) : 0;
     e = getenv("LA3D_SPLIT_SUB");
@@ -1232,7 +1234,7 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : (SRC == 2 ? LA3D_POLY_WAVE
 #define LA3D_STAMP(k) do { } while (0)
 #endif
   LA3D_STAMP(0);
-  if (RET == 0 && SRC == 0 && !SAMPLE && p.stagger_ticks > 0 && p.order_nch > 0 && blockIdx.x < 1024) {
+  if (RET == 0 && !SAMPLE && p.stagger_ticks > 0 && p.order_nch > 0 && blockIdx.x < 1024) {
     // Plain build, u8 planes, size-ordered launch (round 4): the four groups of 256 workgroups that fill the chip start one
     // stagger period apart, the group of the 256 LARGEST instances first (group g of the launch order = blocks [256 g, 256 g + 256)).
     // Every instance streams the same H*W mask bytes whatever its size; started together, the 1024 streams share the bandwidth and
@@ -4041,10 +4043,20 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   // polygons: the side stage sits behind Shared, where the tile list / rank prefix go later (disjoint in time)
   const size_t poly_stage = poly ? (size_t)POLY_STAGE_BYTES : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (band_eligible(p, vec, sample)) {   // u8 planes, 16 <= B <= 256 (or pinned): two / four workgroups per instance, ONE launch
+  // Round 5: a call WITHOUT a ground array on a frame the one-pass tile list covers takes the instance engine at EVERY batch size - its
+  // separable single pass (no pass B, no cull plan: a chain of three short phases per workgroup) is faster than the chain of six
+  // launches of the split engine and than the band engine's exchange from B = 1 on, for all three mask formats
+  // (profiles/r05/r05_small_batches.txt: B = 1 / 16 / 64 / 256, u8 planes: 27.7 / 32.1 / 36.8 / 45.1 us vs 31.7 / 34.8 / 37.9 / 59.8;
+  // run lengths 31.2 / 35.6 / 36.4 / 40.0 vs 34.3 / 37.9 / 43.3 / 57.4).  A skewed K (not separable) still takes this route - the
+  // kernel then runs its two passes -; a call WITH a ground array keeps the old choice below (two passes either way).
+  const bool single_pass_call = ground == nullptr && !sample && !p.sep_off && ldsmask && vec && W % 32 == 0 && W / 32 <= 255 &&
+                                (H + 7) / 8 <= 255 && ((W / 32) * ((H + 7) / 8) + NWAVE - 1) / NWAVE <= 256 &&
+                                (p.opt_engine != LA3D_ENGINE_DEFAULT ? p.opt_engine : config().engine) == LA3D_ENGINE_DEFAULT &&
+                                (p.opt_build != LA3D_BUILD_DEFAULT ? p.opt_build : config().retain) != LA3D_BUILD_RETAINING;
+  if (!single_pass_call && band_eligible(p, vec, sample)) {   // u8 planes, 16 <= B <= 256 (or pinned): two / four workgroups per instance, ONE launch
     return band_count(p) == 4 ? launch_fit_bands<4>(p, s, workspace) : launch_fit_bands<2>(p, s, workspace);
   }
-  if (!sample && split_eligible(p, vec, ldsmask)) {
+  if (!single_pass_call && !sample && split_eligible(p, vec, ldsmask)) {
     const int rc = split_fit(p, workspace, s);   // (the split engine's final kernel does not project: one small follow-up launch)
     if (rc != LA3D_SUCCESS || !p.proj) return rc;
     hipLaunchKernelGGL(project_boxes_kernel, dim3((B + 127) / 128), dim3(128), 0, s, out, K, k_stride, image_index, B, p.proj_w, p.proj_h,
@@ -4126,6 +4138,7 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
         if (config().stagger_us >= 0) us = config().stagger_us;
         p.stagger_ticks = (int)(us * 100.0);
       }
+      if (mask == nullptr && B > 256 && config().stagger_nomask_us > 0) p.stagger_ticks = (int)(config().stagger_nomask_us * 100.0);   // (experiment switch)
       return launch_fit<true, true, false, true>(p, fixed + ((size_t)cap * 2 > poly_stage ? (size_t)cap * 2 : poly_stage), s, workspace);
     }
   }

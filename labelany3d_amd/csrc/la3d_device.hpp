@@ -43,6 +43,7 @@ struct Config {
   int cull_min, cull_min_u8;   // LA3D_CULL_MIN (all inputs; 0: defaults), LA3D_CULL_MIN_U8 (u8 planes, default 128)
   int order_self;      // LA3D_ORDER_SELF=0: keep the estimate kernel in front of ordered launches of up to one resident set
   double stagger_us;   // LA3D_STAGGER_US (< 0: the computed default)
+  double stagger_nomask_us;   // LA3D_STAGGER_NOMASK_US: the same for run-length / polygon input (default 0: off)
   int split_grid;      // LA3D_SPLIT_GRID (0: by batch size)
   int split_sub;       // LA3D_SPLIT_SUB (0: by batch size)
   int sep;             // LA3D_SEP=0: the separable single pass off (two passes for every camera)

@@ -27,6 +27,7 @@ segmentation kind for the whole batch) and its records come back through pinned 
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import queue
@@ -39,6 +40,7 @@ import numpy as np
 import torch
 
 from .batched import _dev, _upload_many, draw_sample_idx
+from .jsonout import SceneRecords, format_scenes
 from .masks import fit_instances_ex, mask_stats_poly, mask_stats_rle, pack_polygons, pack_rle
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -50,17 +52,25 @@ def scene_dir_name(file_name: str) -> str:
     return file_name.split(".")[0].replace("/", "_").replace("-", "_")
 
 
+_TABLE: Dict[int, str] = {}
+
+
 def category_names(categories=None) -> Dict[int, str]:
-    """id -> name: the annotation file's ``categories`` when it has them, else the reference's built-in table (data emitted by
-    tests/golden/make_golden_scenes.py from src/util.py:419-451)."""
+    """id -> name.  Default (``categories`` None): the reference's built-in COCO / COCONut table - its reader maps ids through that
+    table whatever the annotation file says and prints "unknown" for ids outside it (``replace_categories_with_supercategories``,
+    src/util.py:419-462; data emitted by tests/golden/make_golden_scenes.py).  Passing the file's ``categories`` block is the explicit
+    opt-in to the file's own names (``load_annotations(file_categories=True)``, ``--file-categories``)."""
     if categories:
         return {int(c["id"]): c["name"] for c in categories}
-    with open(os.path.join(_HERE, "data", "coco_category_names.json")) as f:
-        return {int(k): v for k, v in json.load(f).items()}
+    if not _TABLE:
+        with open(os.path.join(_HERE, "data", "coco_category_names.json")) as f:
+            _TABLE.update({int(k): v for k, v in json.load(f).items()})
+    return _TABLE
 
 
-def load_annotations(path_or_dict):
-    """COCO-format file / dict -> (images in file order, {image_id: [annotations in file order]}, {category_id: name})."""
+def load_annotations(path_or_dict, file_categories: bool = False):
+    """COCO-format file / dict -> (images in file order, {image_id: [annotations in file order]}, {category_id: name}).  The names are
+    the reference's built-in table unless ``file_categories`` asks for the file's own ``categories`` block."""
     if isinstance(path_or_dict, (str, os.PathLike)):
         with open(path_or_dict) as f:
             data = json.load(f)
@@ -69,7 +79,7 @@ def load_annotations(path_or_dict):
     by_image: Dict[int, list] = {}
     for a in data.get("annotations", []):
         by_image.setdefault(a["image_id"], []).append(a)
-    return data.get("images", []), by_image, category_names(data.get("categories"))
+    return data.get("images", []), by_image, category_names(data.get("categories") if file_categories else None)
 
 
 def _ground_files(scene_dir: str) -> Dict[int, str]:
@@ -86,11 +96,11 @@ def _ground_files(scene_dir: str) -> Dict[int, str]:
 
 
 def scenes_from_disk(scenes_dir: str, annotations, start_index: int = 0, end_index: Optional[int] = None, skip_done: bool = False,
-                     out_name: str = OUT_NAME) -> Iterator[dict]:
+                     out_name: str = OUT_NAME, file_categories: bool = False) -> Iterator[dict]:
     """One dict per image of the annotation file in [start_index, end_index) (the reference's --start_index / --end_index sharding,
     whole.py:25-27,42) whose scene folder holds ``depth_map.npy`` and ``cam_params.json``.  Depth and K are loaded later, by the
     pipeline's loader threads."""
-    images, by_image, names = load_annotations(annotations)
+    images, by_image, names = load_annotations(annotations, file_categories)
     for im in images[start_index:end_index]:
         d = os.path.join(scenes_dir, scene_dir_name(im["file_name"]))
         if not (os.path.exists(os.path.join(d, "depth_map.npy")) and os.path.exists(os.path.join(d, "cam_params.json"))):
@@ -111,12 +121,43 @@ def _load_scene(scene: dict, depth_out: np.ndarray, k_out: np.ndarray) -> None:
             K = json.load(f)["K"]
     if d.shape != depth_out.shape:
         raise ValueError(f"{scene['name']}: depth_map {d.shape} does not match the image size {depth_out.shape} of the annotation file")
-    np.copyto(depth_out, d, casting="same_kind")
+    if isinstance(d, np.ndarray) and d.dtype == np.float32 and d.flags.c_contiguous and depth_out.flags.c_contiguous:
+        # one memmove through ctypes: foreign calls release the GIL, np.copyto does not for this case - sixteen loader threads then
+        # copy in PARALLEL instead of taking turns (round 5: the staging copies ran at 21 GB/s in aggregate, 1.3 GB/s per thread)
+        C.memmove(depth_out.ctypes.data, d.ctypes.data, d.nbytes)
+    else:
+        np.copyto(depth_out, d, casting="same_kind")
     k_out[:] = np.asarray(K, dtype=np.float64).reshape(9)
 
 
-_PINNED: Dict[tuple, torch.Tensor] = {}   # pinned host buffers by (shape, dtype, tag): pinning costs far more than the copy it serves,
-                                            # so they outlive a pipeline object (a tool run creates one; bench.py several)
+# Pinned host buffers outlive a pipeline object (pinning costs far more than the copy it serves; a tool run creates one pipeline,
+# bench.py several).  Two kinds: the (P, H, W) depth / K staging buffers, keyed by shape and ring slot and NEVER evicted, and the
+# record read-back buffers, keyed by kind and ring slot and sized by CAPACITY (grown to the next power of two, sliced per batch:
+# the number of annotations changes with every batch).  One lock: the producer thread and the caller's thread both come here.
+_PINNED: Dict[tuple, torch.Tensor] = {}
+_PINNED_LOCK = threading.Lock()
+
+
+def _pinned(key, shape, dtype):
+    with _PINNED_LOCK:
+        t = _PINNED.get(key)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
+            _PINNED[key] = t
+        return t
+
+
+def _pinned_rows(key, rows, cols, dtype):
+    """a (rows, cols) view of a pinned buffer with at least ``rows`` rows (capacity doubles when it has to grow)"""
+    with _PINNED_LOCK:
+        t = _PINNED.get(key)
+        if t is None or t.shape[0] < rows or t.dtype != dtype or tuple(t.shape[1:]) != tuple(cols):
+            cap = 256
+            while cap < rows:
+                cap *= 2
+            t = torch.empty((cap,) + tuple(cols), dtype=dtype, pin_memory=True)
+            _PINNED[key] = t
+        return t[:rows]
 
 
 class _Prepared:
@@ -124,8 +165,9 @@ class _Prepared:
 
 
 class ScenePipeline:
-    """See the module docstring.  ``run(scenes)`` yields ``(scene, records)`` with ``records`` the list of dicts of the scene's
-    ``3dbbox.json`` (also written to ``scene['dir']`` when the scene has one and ``write=True``)."""
+    """See the module docstring.  ``run(scenes)`` yields ``(scene, records)`` with ``records`` a ``SceneRecords``: the text of the scene's
+    ``3dbbox.json`` (``.text``, also written to ``scene['dir']`` when the scene has one and ``write=True``) that behaves like the list
+    of its dicts (parsed on first access)."""
 
     def __init__(self, device=None, batch_images: int = 256, subsample: bool = False, boundary_threshold: int = 10,
                  scale_threshold: int = 100, loader_threads: int = 16, write: bool = True, out_name: str = OUT_NAME, rng=None,
@@ -141,22 +183,14 @@ class ScenePipeline:
         for k in ("load_s", "pack_s", "h2d_bytes", "h2d_s", "fit_s", "d2h_s", "write_s", "images", "instances", "boxes", "batches"):
             self.t.setdefault(k, 0.0)
         self._busy: Dict[tuple, torch.cuda.Event] = {}
+        self._fitters: Dict[tuple, object] = {}
 
     # ---- stage 1 (background thread): load, pack, start the uploads ------------------------------------------------------------
-    def _pin(self, shape, dtype, tag):
-        """a pinned host buffer per (shape, dtype, tag), allocated once (pinning costs far more than the copy it serves)"""
-        key = (tuple(shape), dtype, tag)
-        if key not in _PINNED:
-            if len(_PINNED) >= 48:
-                _PINNED.pop(next(iter(_PINNED)))
-            _PINNED[key] = torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
-        return _PINNED[key]
-
     def _pinned_depth(self, P, H, W, parity):
         ev = self._busy.get((P, H, W, parity))
         if ev is not None:
             ev.synchronize()   # the upload that last read these buffers (three batches ago) has long finished; make it certain
-        return self._pin((P, H, W), torch.float32, parity), self._pin((P, 9), torch.float64, parity)
+        return _pinned(("depth", P, H, W, parity), (P, H, W), torch.float32), _pinned(("K", P, parity), (P, 9), torch.float64)
 
     def _prepare(self, scenes: List[dict], parity: int) -> _Prepared:
         H, W = scenes[0]["height"], scenes[0]["width"]
@@ -173,11 +207,10 @@ class ScenePipeline:
         def load_range(t):
             for i in range(cuts[t], cuts[t + 1]):
                 _load_scene(scenes[i], dnp[i], knp[i])
-        list(self.pool.map(load_range, range(nthr)))
-        pr.t_load = time.perf_counter() - t0
-        t0 = time.perf_counter()
+        loads = [self.pool.submit(load_range, t) for t in range(nthr)]   # np.load / np.copyto release the GIL: they run WHILE this thread packs
+        tp0 = time.perf_counter()
         # the reference's reader: crowd annotations and annotations without a segmentation are skipped (src/util.py:355-358)
-        groups = {"rle": {"seg": [], "img": [], "ann": [], "area": []}, "poly": {"seg": [], "img": [], "ann": [], "area": []}}
+        groups = {"rle": {"seg": [], "img": [], "ann": [], "area": [], "cat": []}, "poly": {"seg": [], "img": [], "ann": [], "area": [], "cat": []}}
         for p, sc in enumerate(scenes):
             for j, a in enumerate(sc["annotations"]):
                 if a.get("iscrowd") or "segmentation" not in a:
@@ -186,7 +219,7 @@ class ScenePipeline:
                 kind = "rle" if isinstance(seg, dict) and "counts" in seg else "poly"
                 g = groups[kind]
                 g["seg"].append({"size": seg["size"], "counts": seg["counts"]} if kind == "rle" else seg)
-                g["img"].append(p); g["ann"].append(j); g["area"].append(a.get("area"))
+                g["img"].append(p); g["ann"].append(j); g["area"].append(a.get("area")); g["cat"].append(int(a["category_id"]))
         pr.grounds = [(_ground_files(sc["dir"]) if "dir" in sc else {}) if "ground" not in sc else sc["ground"] for sc in scenes]
         packed = {}
         for kind, g in groups.items():
@@ -203,7 +236,10 @@ class ScenePipeline:
                 arrays = [(xy, torch.int32), (ro, torch.int64), (ir, torch.int64)]
             arrays += [(np.asarray(g["img"], np.int32), torch.int32), (hint, torch.int32)]
             packed[kind] = (arrays, g)
-        pr.t_pack = time.perf_counter() - t0
+        pr.t_pack = time.perf_counter() - tp0
+        for f in loads:
+            f.result()
+        pr.t_load = time.perf_counter() - t0      # (wall time of the loads, the packing above included: they overlap)
         # uploads on the copy stream: the depth planes from pinned memory (asynchronous), the small arrays in one copy per kind
         pr.nbytes = dpin.numel() * 4
         with torch.cuda.stream(self.copy_stream):
@@ -215,7 +251,8 @@ class ScenePipeline:
             pr.K.copy_(kpin, non_blocking=True)
             pr.groups = {}
             for kind, (arrays, g) in packed.items():
-                up = _upload_many(arrays, self.dev)
+                up = _upload_many(arrays, self.dev, pinned=_pinned_rows(("small", kind, parity), sum((np.asarray(a).nbytes + 15) & ~15 for a, _ in arrays if a is not None) or 16,
+                                                                     (), torch.uint8))
                 pr.nbytes += sum(int(np.asarray(a).nbytes) for a, _ in arrays if a is not None)
                 pr.groups[kind] = (up, g)
             pr.ready = torch.cuda.Event(enable_timing=True)
@@ -223,6 +260,19 @@ class ScenePipeline:
         self._busy[(P, H, W, parity)] = pr.ready
         pr.parity = parity
         return pr
+
+    def _fitter(self, kind, parity, B, H, W):
+        """output buffers + workspace of a fit call, kept per (kind, ring slot, frame size) and sized by capacity (the number of
+        annotations changes with every batch; a fresh InstanceFitter per call cost ~1 ms of allocations)"""
+        from .batched import InstanceFitter
+        key = (kind, parity, H, W)
+        f = self._fitters.get(key)
+        if f is None or f.B < B:
+            cap = 256
+            while cap < B:
+                cap *= 2
+            f = self._fitters[key] = InstanceFitter(cap, H, W, self.dev)
+        return f
 
     # ---- stage 2 (caller's thread): fit, download --------------------------------------------------------------------------------
     def _fit(self, pr: _Prepared):
@@ -243,7 +293,8 @@ class ScenePipeline:
             masks_kw = dict(rles=(up[0], up[1], H, W)) if kind == "rle" else dict(polys=(up[0], up[1], up[2], H, W))
             ii, hint = up[-2], up[-1]
             if not two_phase:
-                res = fit_instances_ex(pr.depth, K, image_index=ii, filter=self.flt, area_hint=hint, device=self.dev, **masks_kw)
+                res = fit_instances_ex(pr.depth, K, image_index=ii, filter=self.flt, area_hint=hint, device=self.dev,
+                                       _fitter=self._fitter(kind, pr.parity, len(g["seg"]), H, W), **masks_kw)
                 results[kind] = (res["boxes"], res["status"], g)
             else:
                 # the keep rule first (its statistics also give N for the subsample draw), then the fit of the whole group with
@@ -255,8 +306,8 @@ class ScenePipeline:
             results = self._second_phase(pr, results, K)
         out = {}
         for kind, (boxes, status, g) in results.items():
-            hb = self._pin(boxes.shape, boxes.dtype, ("out", kind, pr.parity))
-            hs = self._pin(status.shape, status.dtype, ("out", kind, pr.parity))
+            hb = _pinned_rows(("boxes", kind, pr.parity), boxes.shape[0], boxes.shape[1:], boxes.dtype)
+            hs = _pinned_rows(("status", kind, pr.parity), status.shape[0], (), status.dtype)
             hb.copy_(boxes, non_blocking=True); hs.copy_(status, non_blocking=True)
             out[kind] = (hb, hs, g)
         e1.record(cur)
@@ -306,34 +357,49 @@ class ScenePipeline:
 
     # ---- stage 3: records per scene -----------------------------------------------------------------------------------------------
     def _finish(self, pr: _Prepared, out) -> List[tuple]:
-        per_scene: List[list] = [[] for _ in pr.scenes]
+        """Per scene the text of its ``3dbbox.json`` (C writer, jsonout.format_scenes: the bytes json.dump writes for the reference's
+        list of six-key dicts, src/util_3dbox.py:283-292) wrapped in a lazy ``SceneRecords``.  Everything per record is array work:
+        kept rows in (image, annotation) order, the object id = index among the image's kept instances, category names through the
+        unique ids.  No Python object per record (round 4: 0.112 s of a 0.223 s run went into building them)."""
+        S = len(pr.scenes)
+        recs, img, ann, st, cat = [], [], [], [], []
         for kind, (hb, hs, g) in out.items():
-            b, s = hb.numpy(), hs.numpy()
-            kept = np.nonzero(s != 6)[0]          # 6 = dropped by the instance filter
-            # the numbers of all kept records of the batch become Python floats in ONE call (per-record tolist() calls cost more
-            # than the fit)
-            cen, dim = b[kept, 0:3].tolist(), b[kept, 3:6].tolist()
-            rot, ver = b[kept, 6:15].reshape(-1, 3, 3).tolist(), b[kept, 15:39].reshape(-1, 8, 3).tolist()
-            st = s[kept].tolist()
-            for n, r in enumerate(kept.tolist()):
-                per_scene[g["img"][r]].append((g["ann"][r], st[n], cen[n], rot[n], dim[n], ver[n]))
-        res = []
-        for sc, rows in zip(pr.scenes, per_scene):
-            rows.sort(key=lambda x: x[0])
-            names = sc.get("names") or category_names()
-            recs = []
-            for k, (j, st, cen, rot, dim, ver) in enumerate(rows):   # k = index among the kept instances = the reference's object id
-                if st != 0:                            # the reference prints the exception and skips the object (src/util_3dbox.py:279-281)
-                    continue
-                recs.append({"obj_id": str(k), "category_name": names.get(int(sc["annotations"][j]["category_id"]), "unknown"),
-                             "center_cam": cen, "R_cam": rot, "dimensions": dim, "bbox3D_cam": ver})
-            res.append((sc, recs))
-        return res
+            recs.append(hb.numpy()); st.append(hs.numpy())
+            img.append(np.asarray(g["img"], np.int64)); ann.append(np.asarray(g["ann"], np.int64)); cat.append(np.asarray(g["cat"], np.int64))
+        if not recs:
+            return [(sc, SceneRecords(b"[]", 0)) for sc in pr.scenes]
+        R = recs[0] if len(recs) == 1 else np.concatenate(recs)
+        img, ann, st, cat = (v[0] if len(v) == 1 else np.concatenate(v) for v in (img, ann, st, cat))
+        kept = np.nonzero(st != 6)[0]                                  # 6 = dropped by the instance filter
+        kept = kept[np.lexsort((ann[kept], img[kept]))]                # kept-instance order: image, then annotation order
+        first = np.searchsorted(img[kept], np.arange(S + 1))           # the image's slice of the kept list
+        obj = np.arange(len(kept)) - first[img[kept]]                  # index among the image's kept instances = the reference's object id
+        ok = st[kept] == 0       # a failed fit is skipped but keeps its id (the reference prints the exception and goes on, :279-281)
+        rows, obj = kept[ok], obj[ok].astype(np.int32)
+        scene_off = np.searchsorted(img[rows], np.arange(S + 1)).astype(np.int64)
+        # category names: one lookup per distinct (names table, id) - normally ONE table, the annotation file's / the reference's
+        tables = [sc.get("names") or category_names() for sc in pr.scenes]
+        names: List[str] = []
+        name_ids = np.zeros(len(rows), np.int32)
+        if all(t is tables[0] for t in tables):
+            u, inv = np.unique(cat[rows], return_inverse=True)
+            names = [tables[0].get(int(c), "unknown") for c in u]
+            name_ids = inv.astype(np.int32)
+        else:
+            index: Dict[str, int] = {}
+            ci, ii = cat[rows], img[rows]
+            for n in range(len(rows)):
+                nm = tables[ii[n]].get(int(ci[n]), "unknown")
+                name_ids[n] = index.setdefault(nm, len(index))
+            names = list(index)
+        texts = format_scenes(R, rows, obj, name_ids, scene_off, names)
+        counts = np.diff(scene_off)
+        return [(sc, SceneRecords(texts[i], int(counts[i]))) for i, sc in enumerate(pr.scenes)]
 
     def _write(self, sc, recs):
         if self.write and "dir" in sc:
-            with open(os.path.join(sc["dir"], self.out_name), "w") as f:
-                json.dump(recs, f)
+            with open(os.path.join(sc["dir"], self.out_name), "wb") as f:
+                f.write(recs.text)
 
     def _batches(self, scenes: Iterable[dict]) -> Iterator[List[dict]]:
         pending: Dict[tuple, list] = {}
@@ -381,7 +447,8 @@ class ScenePipeline:
                 t0 = time.perf_counter()
                 for sc, recs in self._finish(ppr, out):
                     self.t["boxes"] += len(recs)
-                    writers.append(self.pool.submit(self._write, sc, recs))
+                    if self.write and "dir" in sc:
+                        writers.append(self.pool.submit(self._write, sc, recs))
                     yield sc, recs
                 self.t["write_s"] += time.perf_counter() - t0
             inflight = nxt
@@ -479,6 +546,8 @@ def main(argv=None) -> int:
     ap.add_argument("--subsample", action="store_true", help="the reference's 500-point subsample for masks above 500 px (global NumPy RNG)")
     ap.add_argument("--seed", type=int, default=None, help="np.random.seed before the first draw (--subsample)")
     ap.add_argument("--skip-done", action="store_true", help="skip scenes that already hold the output file (whole.py:61-62)")
+    ap.add_argument("--file-categories", action="store_true", help="category names from the annotation file's own `categories` block "
+                                                                   "(default: the reference's built-in COCO / COCONut table, src/util.py:419-462)")
     ap.add_argument("--make-synthetic", type=int, default=0, metavar="N", help="first write a synthetic tree of N scenes into --scenes")
     args = ap.parse_args(argv)
     if args.make_synthetic:
@@ -491,7 +560,8 @@ def main(argv=None) -> int:
     pipe = ScenePipeline(device=torch.device("cuda", args.gpu_idx), batch_images=args.batch_images, subsample=args.subsample, timings=timings)
     t0 = time.perf_counter()
     n_scenes = n_boxes = 0
-    for sc, recs in pipe.run(scenes_from_disk(args.scenes, ann, args.start_index, args.end_index, args.skip_done)):
+    for sc, recs in pipe.run(scenes_from_disk(args.scenes, ann, args.start_index, args.end_index, args.skip_done,
+                                              file_categories=args.file_categories)):
         n_scenes += 1
         n_boxes += len(recs)
     dt = time.perf_counter() - t0

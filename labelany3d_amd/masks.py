@@ -22,6 +22,7 @@ instances, src/download_coconut.py:275-280) — take ``create_boolean_mask_from_
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -249,7 +250,9 @@ def fit_instances_ex(depth, K, masks=None, rles=None, polys=None, ground=None, s
     with torch.cuda.device(dev):
         # (_fitter / _stats: buffers a per-image caller keeps between calls - fit_annotations - instead of allocating them per call)
         f = _fitter if _fitter is not None else InstanceFitter(B, H, W, dev)
-        out.update(boxes=f.boxes[0], status=f.status[0], aux=f.aux[0])
+        if f.B < B or (f.H, f.W) != (H, W):
+            raise ValueError("_fitter too small for this call")
+        out.update(boxes=f.boxes[0][:B], status=f.status[0][:B], aux=f.aux[0][:B])   # (a kept fitter may have more rows than this call)
         if filter:
             out["stats"] = _stats if _stats is not None else torch.zeros((B, 4), dtype=torch.int32, device=dev)
         if image_size is not None:
@@ -282,16 +285,23 @@ def fit_instances_ex(depth, K, masks=None, rles=None, polys=None, ground=None, s
 _ANN_CACHE: dict = {}   # (B, H, W, device) -> (InstanceFitter, stats, pinned read-back buffer): the per-image pattern repeats a few shapes
 
 
+_ANN_LOCK = threading.Lock()
+
+
 def _ann_buffers(B, H, W, dev, kind):
-    key = (B, H, W, kind, dev.index if dev.index is not None else torch.cuda.current_device())
-    ent = _ANN_CACHE.get(key)
-    if ent is None:
-        if len(_ANN_CACHE) >= 64:
+    # per THREAD: two threads calling fit_annotations with equal shapes must not share a fitter, its statistics
+    # buffer and its pinned read-back buffer; the dict itself is guarded by a lock
+    key = (B, H, W, kind, dev.index if dev.index is not None else torch.cuda.current_device(), threading.get_ident())
+    with _ANN_LOCK:
+        ent = _ANN_CACHE.get(key)
+        if ent is None and len(_ANN_CACHE) >= 64:
             _ANN_CACHE.pop(next(iter(_ANN_CACHE)))
+    if ent is None:
         f = InstanceFitter(B, H, W, dev)
         # the pinned buffer mirrors the head of the fitter's arena: boxes | aux | status (256-aligned pieces), without the workspace
         ent = (f, torch.empty((B, 4), dtype=torch.int32, device=dev), torch.empty(f._arena.numel() - f.workspace.numel(), dtype=torch.uint8, pin_memory=True))
-        _ANN_CACHE[key] = ent
+        with _ANN_LOCK:
+            _ANN_CACHE[key] = ent
     return ent
 
 

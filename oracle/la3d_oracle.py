@@ -14,7 +14,7 @@ against those fixtures.
 
 Every function cites the reference lines it follows (paths relative to /root/reference).
 The one third-party piece on the path is scikit-learn's ``PCA(2).fit`` (reference pins
-scikit-learn==1.5.0, requirements.txt:19; call site src/util_3dbox.py:181-186).  Its
+scikit-learn==1.5.0, requirements.txt:23; call site src/util_3dbox.py:181-186).  Its
 published algorithm for 2 features is restated in ``yaw_pca_closed_form``:
     n >= 20 -> 'covariance_eigh' solver: C = X^T X - n mu mu^T, C /= n-1, eigh, sort
                descending;  n < 20 -> LAPACK SVD of the centred data;

@@ -14,8 +14,9 @@ import bench  # noqa: E402
 
 SIMDS = 256 * 4
 CLOCK_GHZ = 2.4
-files = {"config2": "r04_config2_summary.md", "config2_rle": "r04_config2_rle_sq_summary.md", "config2_poly": "r04_config2_poly_sq_summary.md",
-         "config2_B8192": "r04_config2_B8192_sq_summary.md"}
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
+files = {"config2": f"{TAG}_config2_summary.md", "config2_rle": f"{TAG}_config2_rle_sq_summary.md", "config2_poly": f"{TAG}_config2_poly_sq_summary.md",
+         "config2_B8192": f"{TAG}_config2_B8192_sq_summary.md"}
 out = {}
 for mode, fn in files.items():
     p = os.path.join(ROOT, "profiles", fn)

@@ -107,13 +107,21 @@ def test_band_engine_full_batch_is_deterministic_and_order_free(la, monkeypatch)
     idx = np.random.RandomState(0).choice(B, 24, replace=False)
     ref, rst, _, _ = O.fit_instances(np_(depth[idx]), np_(masks[idx]).astype(bool), np.broadcast_to(K640, (24, 3, 3)))
     assert_records(np_(runs[0][0])[idx], ref, "band/config2", gap=np_(runs[0][2])[idx, 3])
-    # the default dispatch takes the band engine for 16 <= B <= 256 u8 planes (four bands): same records as the pinned call
+    # the default dispatch takes the band engine for 16 <= B <= 256 u8 planes (four bands) when the call carries a ground array
+    # (round 5: a call without one takes the instance engine's single pass at every batch size): same records as the pinned call
     for Bs in (64, 256):
-        fs = InstanceFitter(Bs, bench.H, bench.W, dev, slots=2)
-        a = fs.run(depth[:Bs], masks[:Bs], K, slot=0)
-        b = fs.run(depth[:Bs], masks[:Bs], K, slot=1, engine="band")
+        fs = InstanceFitter(Bs, bench.H, bench.W, dev, slots=3)
+        g = torch.as_tensor(np.array([[0.05, -0.97, 0.1, 1.2]] * Bs) + 0.02 * np.random.RandomState(Bs).randn(Bs, 4), device=dev)
+        a = fs.run(depth[:Bs], masks[:Bs], K, ground=g, slot=0)
+        b = fs.run(depth[:Bs], masks[:Bs], K, ground=g, slot=1, engine="band")
+        c = fs.run(depth[:Bs], masks[:Bs], K, ground=g, slot=2, engine="instance")
         torch.cuda.synchronize()
-        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and not torch.equal(a[0], c[0])
+        torch.testing.assert_close(a[0][:, :15], c[0][:, :15], rtol=1e-10, atol=1e-10)
+        u = fs.run(depth[:Bs], masks[:Bs], K, slot=0)                       # un-grounded: the default IS the instance engine
+        v = fs.run(depth[:Bs], masks[:Bs], K, slot=1, engine="instance")
+        torch.cuda.synchronize()
+        assert torch.equal(u[0], v[0]) and torch.equal(u[1], v[1])
 
 
 def test_band_engine_shared_depth_planes_and_2d_boxes(la, monkeypatch):
@@ -171,15 +179,17 @@ def test_two_band_calls_running_concurrently(la, monkeypatch):
         for f, (rb, rs_) in zip(fit, ref):
             assert torch.equal(f.status[0], rs_), rep
             assert torch.equal(f.boxes[0], rb), rep
-    # per-image batches (the reference's own calling pattern) pipelined on two streams: the default dispatch takes the band engine
+    # per-image batches (the reference's own calling pattern) pipelined on two streams: with a ground array the default dispatch
+    # takes the band engine for these sizes
     rs = np.random.RandomState(9)
     sizes = [16, 40, 256, 23, 128, 64, 17, 200]
     depth, masks, _, _, _ = bench.make_inputs(sum(sizes), dev, 7)
+    ground = torch.as_tensor(np.array([[0.05, -0.97, 0.1, 1.2]] * sum(sizes)) + 0.02 * rs.randn(sum(sizes), 4), device=dev)
     batches, want, o = [], [], 0
     for n in sizes:
-        batches.append((depth[o:o + n], masks[o:o + n], K))
+        batches.append(dict(depth=depth[o:o + n], masks=masks[o:o + n], K=K, ground=ground[o:o + n]))
         f = InstanceFitter(n, bench.H, bench.W, dev)
-        b, s, _ = f.run(depth[o:o + n], masks[o:o + n], K)
+        b, s, _ = f.run(depth[o:o + n], masks[o:o + n], K, ground=ground[o:o + n], engine="band")
         torch.cuda.synchronize()
         want.append((b.clone(), s.clone()))
         o += n

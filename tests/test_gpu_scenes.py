@@ -96,7 +96,11 @@ def test_scene_pipeline_in_memory_matches_disk(tmp_path):
     disk = {sc["name"]: recs for sc, recs in F.ScenePipeline(batch_images=32).run(F.scenes_from_disk(root, os.path.join(root, "annotations.json")))}
     assert set(mem) == set(disk) == {sc["name"] for sc in scenes}
     for k in mem:
-        assert json.dumps(mem[k]) == json.dumps(disk[k]), k
+        assert mem[k].text == disk[k].text and list(mem[k]) == list(disk[k]), k
+        # the file holds exactly the text Python's own writer would produce for the list of dicts (the reference: json.dump(bbox_list, f))
+        with open(os.path.join(root, k, "3dbbox.json"), "rb") as f:
+            on_disk = f.read()
+        assert on_disk == disk[k].text == json.dumps(list(disk[k])).encode(), k
     assert timings["images"] == 20 and timings["h2d_bytes"] > 20 * 480 * 640 * 4 and timings["fit_s"] > 0
 
 
@@ -129,3 +133,33 @@ def test_scene_pipeline_mixed_frame_sizes_and_rle_strings():
         # concatenated tile list: the same instance in a different batch agrees to rounding, INTEGRATION.md "Bitwise reproducibility")
         np.testing.assert_allclose(flat(alone)[:, :15], flat(both)[:, :15], rtol=1e-10, atol=1e-10, err_msg=sc["name"])
         np.testing.assert_allclose(flat(alone)[:, 15:], flat(both)[:, 15:], rtol=0, atol=2e-2, err_msg=sc["name"])
+
+
+def test_category_names_follow_the_reference_table_unless_asked(tmp_path):
+    """the reference maps category ids through ITS OWN table whatever the annotation file says
+    (replace_categories_with_supercategories, src/util.py:452-462) and writes "unknown" for ids outside it.  A file whose
+    `categories` block disagrees with that table must not change 3dbbox.json - unless the caller opts in."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from labelany3d_amd import fit_scenes as F
+
+    root = str(tmp_path / "scenes")
+    scenes, data = F.synthetic_scenes(6, seed=4, root=root)
+    data["categories"] = [{"id": 1, "name": "human"}, {"id": 3, "name": "automobile"}, {"id": 999, "name": "mystery"}]
+    ann = os.path.join(root, "annotations.json")
+    with open(ann, "w") as f:
+        json.dump(data, f)
+    table = F.category_names()
+    assert table[1] == "person" and table[3] == "car" and 999 not in table and 12 not in table
+    by_ref = {sc["name"]: recs for sc, recs in F.ScenePipeline(batch_images=8, write=False).run(F.scenes_from_disk(root, ann))}
+    by_file = {sc["name"]: recs for sc, recs in F.ScenePipeline(batch_images=8, write=False).run(F.scenes_from_disk(root, ann, file_categories=True))}
+    seen_ref, seen_file = set(), set()
+    for k in by_ref:
+        assert len(by_ref[k]) == len(by_file[k])
+        for a, b in zip(by_ref[k], by_file[k]):
+            assert a["obj_id"] == b["obj_id"] and a["center_cam"] == b["center_cam"]
+            seen_ref.add(a["category_name"]); seen_file.add(b["category_name"])
+    assert "person" in seen_ref and "unknown" in seen_ref and not ({"human", "automobile", "mystery"} & seen_ref)
+    assert {"human", "mystery"} <= seen_file and "person" not in seen_file
