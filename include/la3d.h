@@ -331,6 +331,11 @@ int64_t la3d_format_3dbbox_json(const double* records, const int64_t* rows, cons
                                 const int64_t* scene_off, int32_t S, const char* const* names_json, char* out, int64_t cap,
                                 int64_t* text_off);
 
+/* Host-side staging helper (no device work): n pageable source planes of bytes_each bytes -> consecutive slots of dst (a pinned
+ * buffer), copied by `threads` native threads in one call (labelany3d_amd/fit_scenes.py: the depth_map.npy planes of a batch,
+ * reference src/batch_scripts/whole.py:63-67).  0 on success, -1 on a bad argument. */
+int la3d_gather_planes_host(const void* const* src, int64_t n, int64_t bytes_each, void* dst, int threads);
+
 /* Host-side helper exported for tests: float64 -> float16 (round-to-nearest-even, as NumPy's
  * astype(float16), reference src/util_3dbox.py:165) -> float64, the same routine the kernels use. */
 double la3d_f16_round_host(double x);

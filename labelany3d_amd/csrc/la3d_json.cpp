@@ -8,6 +8,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 #include "la3d.h"
 
@@ -126,6 +128,26 @@ int64_t la3d_format_3dbbox_json(const double* records, const int64_t* rows, cons
   }
   text_off[S] = p - out;
   return p - out;
+}
+
+// Host-side staging helper of the scene pipeline: n source planes (pageable host memory, `bytes_each` bytes each) copied into
+// consecutive slots of one (pinned) destination buffer by `threads` native threads.  One foreign call instead of one Python task per
+// loader thread: the copies neither hold nor fight for the interpreter lock (round 5: sixteen Python loader threads moved 21-40 GB/s
+// in aggregate and slowed every short torch call of the other threads).  Returns 0, -1 on a bad argument.
+int la3d_gather_planes_host(const void* const* src, int64_t n, int64_t bytes_each, void* dst, int threads) {
+  if (n < 0 || bytes_each < 0 || (n > 0 && (!src || !dst))) return -1;
+  if (threads < 1) threads = 1;
+  if (threads > 64) threads = 64;
+  if ((int64_t)threads > n) threads = (int)(n > 0 ? n : 1);
+  auto work = [&](int t) {
+    for (int64_t i = n * t / threads; i < n * (t + 1) / threads; ++i)
+      memcpy(static_cast<char*>(dst) + i * bytes_each, src[i], (size_t)bytes_each);
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
+  work(0);
+  for (auto& th : pool) th.join();
+  return 0;
 }
 
 }  // extern "C"

@@ -39,6 +39,7 @@ from typing import Dict, Iterable, Iterator, List, Optional
 import numpy as np
 import torch
 
+from ._lib import lib
 from .batched import _dev, _upload_many, draw_sample_idx
 from .jsonout import SceneRecords, format_scenes
 from .masks import fit_instances_ex, mask_stats_poly, mask_stats_rle, pack_polygons, pack_rle
@@ -207,7 +208,17 @@ class ScenePipeline:
         def load_range(t):
             for i in range(cuts[t], cuts[t + 1]):
                 _load_scene(scenes[i], dnp[i], knp[i])
-        loads = [self.pool.submit(load_range, t) for t in range(nthr)]   # np.load / np.copyto release the GIL: they run WHILE this thread packs
+        inmem = all("depth" in sc and isinstance(sc["depth"], np.ndarray) and sc["depth"].dtype == np.float32 and sc["depth"].flags.c_contiguous
+                    and sc["depth"].shape == (H, W) for sc in scenes)
+        if inmem:
+            # planes already in host memory: ONE foreign call copies them into the pinned batch buffer on native threads - no Python
+            # task per loader thread, nothing that takes the interpreter lock while this thread packs
+            ptrs = (C.c_void_p * P)(*[sc["depth"].ctypes.data for sc in scenes])
+            for i, sc in enumerate(scenes):
+                knp[i] = np.asarray(sc["K"], dtype=np.float64).reshape(9)
+            loads = [self.pool.submit(lib.la3d_gather_planes_host, ptrs, P, H * W * 4, dnp.ctypes.data, nthr)]
+        else:
+            loads = [self.pool.submit(load_range, t) for t in range(nthr)]   # np.load / memmove release the GIL: they run WHILE this thread packs
         tp0 = time.perf_counter()
         # the reference's reader: crowd annotations and annotations without a segmentation are skipped (src/util.py:355-358)
         groups = {"rle": {"seg": [], "img": [], "ann": [], "area": [], "cat": []}, "poly": {"seg": [], "img": [], "ann": [], "area": [], "cat": []}}

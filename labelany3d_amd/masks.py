@@ -22,6 +22,7 @@ instances, src/download_coconut.py:275-280) — take ``create_boolean_mask_from_
 from __future__ import annotations
 
 import ctypes as C
+import itertools
 import threading
 
 import numpy as np
@@ -53,12 +54,18 @@ def pack_rle(rles):
     if len(sizes) > 1:
         raise ValueError("all masks of one batch must share the frame size")
     H, W = sizes.pop() if sizes else (0, 0)
-    parts = []
-    for r in rles:
-        c = r["counts"]
-        parts.append(rle_from_string(c) if isinstance(c, (str, bytes)) else np.asarray(c, dtype=np.int32))
-    offsets = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
-    counts = np.concatenate(parts).astype(np.int32) if parts and offsets[-1] else np.zeros(1, np.int32)
+    cs = [r["counts"] for r in rles]
+    if cs and all(type(c) is list for c in cs):   # uncompressed run lengths as the JSON holds them: one conversion loop for the batch
+        lens = np.fromiter(map(len, cs), np.int64, len(cs))
+        counts = np.fromiter(itertools.chain.from_iterable(cs), np.int64, int(lens.sum())).astype(np.int32)
+        offsets = np.zeros(len(cs) + 1, np.int64)
+        np.cumsum(lens, out=offsets[1:])
+    else:
+        parts = [rle_from_string(c) if isinstance(c, (str, bytes)) else np.asarray(c, dtype=np.int32) for c in cs]
+        offsets = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
+        counts = np.concatenate(parts).astype(np.int32) if parts and offsets[-1] else np.zeros(1, np.int32)
+    if not len(counts):
+        counts = np.zeros(1, np.int32)
     return counts, offsets, int(H), int(W)
 
 
@@ -117,17 +124,32 @@ def pack_polygons(segmentations, H=None, W=None):
         return segmentations
     if H is None or W is None:
         raise ValueError("pack_polygons needs the frame size (H, W)")
-    pts, ring_off, inst_rings = [], [0], [0]
     for seg in segmentations:
         if not isinstance(seg, (list, tuple)):
             raise TypeError("polygon segmentation must be a list of parts")
-        for polygon in seg:
+    parts = [polygon for seg in segmentations for polygon in seg]
+    inst_rings = np.zeros(len(segmentations) + 1, np.int64)
+    np.cumsum([len(seg) for seg in segmentations], out=inst_rings[1:])
+    plain = all(type(q) is list for q in parts)
+    lens = np.fromiter(map(len, parts), np.int64, len(parts)) if plain else None
+    if plain and len(parts) and not (lens & 1).any():
+        # flat Python lists (what the annotation JSON holds): ONE conversion loop over all coordinates of the batch instead of one
+        # np.array per part (a third of the packing time of a 256-image batch); the truncation is the same astype
+        flat = np.fromiter(itertools.chain.from_iterable(parts), np.float64, int(lens.sum()))
+        xy = flat.reshape(-1, 2).astype(np.int32)
+        ring_off = np.zeros(len(parts) + 1, np.int64)
+        np.cumsum(lens >> 1, out=ring_off[1:])
+    else:   # arrays, nested pairs, or an odd count (np.reshape raises the reference's ValueError)
+        pts, ring = [], [0]
+        for polygon in parts:
             q = np.array(polygon).reshape(-1, 2).astype(np.int32)
             pts.append(q)
-            ring_off.append(ring_off[-1] + len(q))
-        inst_rings.append(len(ring_off) - 1)
-    xy = np.concatenate(pts).astype(np.int32) if pts and ring_off[-1] else np.zeros((1, 2), np.int32)
-    return xy, np.asarray(ring_off, np.int64), np.asarray(inst_rings, np.int64), int(H), int(W)
+            ring.append(ring[-1] + len(q))
+        xy = np.concatenate(pts).astype(np.int32) if pts else np.zeros((0, 2), np.int32)
+        ring_off = np.asarray(ring, np.int64)
+    if not len(xy):
+        xy = np.zeros((1, 2), np.int32)
+    return xy, ring_off, inst_rings, int(H), int(W)
 
 
 def _poly_dev(polys, dev):
