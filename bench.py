@@ -372,14 +372,13 @@ def config4_annotations(meta, kind):
             half = np.sqrt(np.clip(t, 0, None)) * hh / 2
             lo = np.clip(np.ceil(cy - half), 0, H).astype(np.int64)
             hi = np.clip(np.floor(cy + half) + 1, 0, H).astype(np.int64)
-            on = (t > 0) & (hi > lo)
-            counts, pos = [], 0
-            for c in np.nonzero(on)[0]:
-                s_, e_ = c * H + lo[c], c * H + hi[c]
-                counts += [int(s_ - pos), int(e_ - s_)]
-                pos = e_
-            counts.append(int(H * W - pos))
-            seg = {"size": [H, W], "counts": counts}
+            on = np.nonzero((t > 0) & (hi > lo))[0]
+            st, en = on * H + lo[on], on * H + hi[on]            # column-major pixel ranges of the ones-runs, one per column
+            cnt = np.empty(2 * len(on) + 1, np.int64)
+            cnt[0:-1:2] = st - np.concatenate([[0], en[:-1]])      # zeros before every ones-run
+            cnt[1::2] = en - st
+            cnt[-1] = H * W - (en[-1] if len(on) else 0)
+            seg = {"size": [H, W], "counts": cnt.tolist()}
         anns.append({"id": n, "image_id": int(meta["img"][n]), "category_id": 1, "iscrowd": 0, "bbox": [float(c0), float(r0), float(ww), float(hh)],
                      "area": float(meta["area"][n]), "segmentation": seg})
     return anns

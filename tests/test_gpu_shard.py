@@ -365,6 +365,59 @@ def test_bench_config4_mode_two_ranks_one_gpu_equals_one_process(tmp_path):
     np.testing.assert_array_equal(b.cpu().numpy(), outs[1])
 
 
+@pytest.mark.parametrize("fmt", ["--poly", "--rle"])
+def test_bench_config4_annotation_formats_two_ranks_one_gpu_equals_one_process(tmp_path, fmt):
+    """Round 5: the same partitioning on the reference's ANNOTATION formats (bench.py --config4 N --poly | --rle ->
+    shard.fit_annotations_sharded): every rank holds the annotation list, packs and fits only the segmentations of its own image
+    range (no u8 plane anywhere) and joins the one gather.  Two gloo ranks on this box's GPU = the one-process job bit for bit = a
+    direct fit_instances_poly / _rle call over all annotations; against the oracle through the decoded planes."""
+    import json
+    import subprocess
+    import sys
+
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for world in (1, 2):
+        dump = str(tmp_path / f"rec{world}.npy")
+        env = dict(os.environ, LA3D_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+        base = [os.path.join(root, "bench.py"), "--gpus", str(world), "--config4", "40", fmt, "--jobs", "1", "--warmup-jobs", "1", "--dump", dump]
+        cmd = ([sys.executable] + base if world == 1 else
+               [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port())] + base)
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == world and len(d["per_rank_fit_ms"]) == world and "u8" not in d["config"]["mask_input"]
+        assert sum(d["config"]["instances_per_rank"]) == d["config"]["instances"] and sum(d["config"]["images_per_rank"]) == 40
+        outs[world] = np.load(dump)
+    np.testing.assert_array_equal(outs[1], outs[2])
+    import bench
+    import labelany3d_amd as la
+
+    meta = bench.config4_metadata(40, 1234)
+    dev = torch.device("cuda", 0)
+    depth, _, K, _, _ = bench.config4_materialize(meta, (0, 40, 0, meta["B"]), dev, with_masks=False)
+    anns = bench.config4_annotations(meta, "rle" if fmt == "--rle" else "poly")
+    segs = [a["segmentation"] for a in anns]
+    img = meta["img"].astype(np.int32)
+    if fmt == "--rle":
+        b, s, _ = la.fit_instances_rle(depth, segs, K, image_index=img)
+        planes = la.rle_decode(segs).cpu().numpy().astype(bool)
+    else:
+        b, s, _ = la.fit_instances_poly(depth, la.pack_polygons(segs, bench.H, bench.W), K, image_index=img)
+        planes = la.poly_decode(la.pack_polygons(segs, bench.H, bench.W)).cpu().numpy().astype(bool)
+    np.testing.assert_array_equal(b.cpu().numpy(), outs[1])
+    pick = np.arange(0, meta["B"], max(1, meta["B"] // 12))
+    ref, rst, _, _ = O.fit_instances(depth.cpu().numpy(), planes[pick], np.broadcast_to(K.cpu().numpy(), (40, 3, 3)), depth_index=img[pick])
+    assert (s.cpu().numpy()[pick] == rst).all()
+    np.testing.assert_allclose(outs[1][pick][:, :15], ref[:, :15], rtol=0, atol=1e-8)
+
+
 def test_config4_metadata_and_plan_cpu_side():
     """the metadata every rank derives and the plan over it: contiguous, complete, balanced by the cost model (no GPU work)"""
     import bench
