@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "la3d.hip")
-SOURCES = [SRC, os.path.join(HERE, "csrc", "la3d_split.hip"), os.path.join(HERE, "csrc", "la3d_json.cpp")]
+SOURCES = [SRC, os.path.join(HERE, "csrc", "la3d_split.hip"), os.path.join(HERE, "csrc", "la3d_aux.hip"), os.path.join(HERE, "csrc", "la3d_json.cpp")]
 HEADERS = [os.path.join(HERE, "csrc", "la3d_device.hpp"), os.path.join(HERE, "csrc", "la3d_poly.hpp"), os.path.join(ROOT, "include", "la3d.h")]
 LIB = os.environ.get("LA3D_LIB") or os.path.join(HERE, "lib", "libla3d.so")  # LA3D_LIB: experiment builds only
 INCLUDE = os.path.join(ROOT, "include")
@@ -15,16 +15,31 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/la3d.hip for gfx950 into lib/libla3d.so (in-tree, so it travels with the repo)."""
+    """Compile the sources of csrc/ for gfx950 into lib/libla3d.so (in-tree, so it travels with the repo): one object per
+    translation unit, compiled side by side, then one link."""
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     newest = max(os.path.getmtime(f) for f in SOURCES + HEADERS)
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest:
         return LIB
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, *HIPCC_FLAGS, "-I", INCLUDE, *SOURCES, "-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    with tempfile.TemporaryDirectory(prefix="la3d_build_") as tmp:
+        objs = [os.path.join(tmp, os.path.splitext(os.path.basename(src))[0] + ".o") for src in SOURCES]
+        cmds = [[hipcc, *flags, "-I", INCLUDE, "-c", src, "-o", obj] for src, obj in zip(SOURCES, objs)]
+        if verbose:
+            for c in cmds:
+                print(" ".join(c))
+        with ThreadPoolExecutor(max_workers=len(cmds)) as ex:
+            for r in ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), cmds):
+                if r.returncode != 0:
+                    raise RuntimeError("hipcc failed:\n" + r.stderr[-4000:])
+        link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+        if verbose:
+            print(" ".join(link))
+        subprocess.run(link, check=True)
     return LIB
 
 

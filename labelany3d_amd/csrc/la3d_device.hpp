@@ -6,6 +6,9 @@
 #define LA3D_NT 512
 #endif
 #include <hip/hip_runtime.h>
+#include <mutex>
+#include <utility>
+#include <vector>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -496,9 +499,6 @@ struct FitParams {
   int order_nch;       // chunks of consecutive instances (ceil(B / ORDER_CHUNK)), 0 = launch order off
   int order_resident;  // workgroups of the grid that are resident at once
   int order_shift;     // area_hint >> order_shift fits 18 bits
-#ifdef LA3D_DEBUG_ORDER
-  const int* debug_perm;   // measurement build only (profiles/r03/order_search.py): block -> instance table set by la3d_debug_set_block_order
-#endif
   int lds_keep_off;    // retaining build: byte offset in dynamic LDS of the per-wave kept step (0: none)
   int cull_min;        // pass-B culling: instances with at least this many active tiles plan (cull_plan)
   int stagger_ticks;   // u8 planes: resident groups of 256 workgroups start this many 100 MHz ticks apart (0: off; see fit_instances_kernel)
@@ -789,5 +789,21 @@ inline int check_launch(const char* what) {
   }
   return LA3D_SUCCESS;
 }
+
+// Dynamic LDS above the 64 KiB default has to be allowed per kernel AND per device (a process may drive several GPUs): one
+// hipFuncSetAttribute per (kernel, device), remembered in a small table.
+inline void allow_big_lds(const void* fn, int bytes = 160 * 1024) {
+  static std::mutex mu;
+  static std::vector<std::pair<const void*, int>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) (void)hipGetLastError();
+  std::lock_guard<std::mutex> g(mu);
+  for (const auto& d : done)
+    if (d.first == fn && d.second == dev) return;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) (void)hipGetLastError();
+  done.emplace_back(fn, dev);
+}
+
+constexpr int MAX_MASK_LDS = 128 * 1024;  // bit image budget; larger frames re-read the u8 mask instead
 
 }  // namespace la3d
