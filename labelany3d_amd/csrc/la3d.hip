@@ -550,13 +550,12 @@ __device__ inline void sweep_sep(const FitParams& p, const float* __restrict__ d
     for (int g = 0; g < TG; ++g) {
       if (j0 + g >= nactive) continue;   // uniform
       const int tx = tcs[g] & 0xff, ty = tcs[g] >> 8;
-      const unsigned nib = (pk >> (4 * g)) & 0xFu;
       double ry = fma(a11, (double)(ty * 8 + h4), a12);
       double c1 = 0.0, c2 = 0.0;
       unsigned cmin = 0xffffffffu, cmax = 0u;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int m = -(int)((nib >> k) & 1u);                    // 0 / -1
+        const int m = __builtin_amdgcn_sbfe((int)pk, 4 * g + k, 1);   // the pixel's mask bit as 0 / -1: ONE v_bfe_i32
         const unsigned v = dq[g][k] & (unsigned)m;                 // invalid -> +0.0 (sums), 0 (unsigned max)
         unsigned w;
         asm("v_bfi_b32 %0, %1, %2, -1" : "=v"(w) : "v"(m), "v"(dq[g][k]));   // invalid -> 0xffffffff (unsigned min)
@@ -564,9 +563,11 @@ __device__ inline void sweep_sep(const FitParams& p, const float* __restrict__ d
         const double d = (double)__uint_as_float(v);
         if (k == 0) { c1 = d; c2 = d * d; }
         else { c1 += d; c2 = fma(d, d, c2); }
-        // y extent: per pixel (the row ray), invalid pixels as NaN (ignored by v_min / v_max_f64)
+        // y extent: per pixel (the row ray), invalid pixels as NaN (ignored by v_min / v_max_f64): the high word through one v_bfi
         const double y = d * ry;
-        const double ym = __hiloint2double(__double2hiint(y) | ~m, __double2loint(y));
+        int yh;
+        asm("v_bfi_b32 %0, %1, %2, -1" : "=v"(yh) : "v"(m), "v"(__double2hiint(y)));
+        const double ym = __hiloint2double(yh, __double2loint(y));
         ylo = dmin(ylo, ym); yhi = dmax(yhi, ym);
         ry += a11;
       }
