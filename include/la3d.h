@@ -319,6 +319,14 @@ int la3d_estimate_bbox_host(const double* points, int64_t n, const double* groun
 int la3d_unproject_host(const float* depth, const double* K9, const double* Rt12, int H, int W, void* out, int out_is_f64);
 void la3d_host_release(void);   /* frees the calling thread's staging memory and stream (optional) */
 
+/* The reference's per-IMAGE pattern as one foreign call (round 5): the annotations of an image as run lengths or polygon parts ->
+ * decode + the reference's keep rule + fit (la3d_fit_instances_ex with the filter fields) -> records.  `args` is a la3d_fit_args in which
+ * `depth` is a DEVICE pointer (the image's depth plane(s), resident) and EVERY OTHER pointer is a HOST pointer: rle_counts / rle_offsets
+ * or poly_xy / ring_offsets / inst_rings, K, image_index, ground, area_hint in; out / status / aux / stats out.  mask, sample_idx, proj,
+ * workspace and stream must be NULL / are ignored (the library uses the calling thread's staging memory and private stream).
+ * Synchronous.  Replaces read_bounding_boxes_segmentations + the per-object fit for one image: src/util.py:336-383, util_3dbox.py:250-281. */
+int la3d_fit_annotations_host(const la3d_fit_args* args);
+
 /* The reference's per-scene box file from packed records, on the HOST (round 5; labelany3d_amd/csrc/la3d_json.cpp): the text
  * json.dump([{"obj_id", "category_name", "center_cam", "R_cam", "dimensions", "bbox3D_cam"}, ...], f) writes - reference
  * src/util_3dbox.py:283-292 - byte for byte (floats as float.__repr__ prints them), for S scenes in one call, without a Python

@@ -83,6 +83,7 @@ _SIGS = {
     "la3d_estimate_bbox_host": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "la3d_unproject_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "la3d_host_release": (None, []),
+    "la3d_fit_annotations_host": (C.c_int, [C.POINTER(FitArgs)]),
     "la3d_gather_planes_host": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int]),
     "la3d_3dbbox_json_bound": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
     "la3d_format_3dbbox_json": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,

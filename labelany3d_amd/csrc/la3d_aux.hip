@@ -1882,4 +1882,109 @@ int la3d_unproject_host(const float* depth, const double* K9, const double* Rt12
 
 void la3d_host_release(void) { host_ctx_release(t_host); }
 
+// ------------------------------------------------------------------------------------------
+// la3d_fit_annotations_host (round 5): the reference's per-IMAGE pattern - the annotations of one image (or a few), depth plane(s)
+// already resident - as ONE foreign call: every small array (run lengths / polygon parts, offsets, K, ground, area hints, image
+// index) is a HOST pointer, the records come back into HOST arrays.  Inside: one copy of the inputs into the calling thread's
+// pinned block, one asynchronous upload, la3d_fit_instances_ex on the private stream with the outputs pointing INTO the pinned,
+// device-mapped block, a one-lane kernel that raises a flag behind it, and a poll of that flag.  (The convenience wrappers of the
+// Python layer spent ~150 us per image around ~40 us of GPU work: fit_annotations 187-222 us per 8-annotation image.)
+// ------------------------------------------------------------------------------------------
+namespace {
+__global__ void host_flag_kernel(unsigned* flag, unsigned seq) {
+  __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+inline size_t up64(size_t v) { return (v + 63) & ~(size_t)63; }
+}  // namespace
+
+int la3d_fit_annotations_host(const la3d_fit_args* args) {
+  constexpr int32_t V1_SIZE = (int32_t)offsetof(la3d_fit_args, area_hint);
+  if (!args || args->struct_size < V1_SIZE) {
+    set_err("la3d_fit_annotations_host: bad struct_size");
+    return LA3D_ERR_ARG;
+  }
+  la3d_fit_args a;
+  memset(&a, 0, sizeof(a));
+  memcpy(&a, args, (size_t)args->struct_size < sizeof(a) ? (size_t)args->struct_size : sizeof(a));
+  const bool rle = a.rle_counts != nullptr, poly = a.poly_xy != nullptr;
+  if (a.B < 0 || a.H <= 0 || a.W <= 0 || a.mask || rle == poly || (rle && !a.rle_offsets) || (poly && (!a.ring_offsets || !a.inst_rings)) ||
+      !a.depth || !a.K || !a.out || !a.status || a.sample_idx || a.proj || (a.k_stride != 0 && a.k_stride < 9)) {
+    set_err("la3d_fit_annotations_host: bad argument (run lengths or polygon parts, host arrays; depth on the device; no u8 planes, "
+            "sample_idx or proj)");
+    return LA3D_ERR_ARG;
+  }
+  const int B = a.B;
+  if (B == 0) return LA3D_SUCCESS;
+  int64_t P = 1;
+  if (a.image_index) for (int i = 0; i < B; ++i) { if (a.image_index[i] < 0) { set_err("la3d_fit_annotations_host: negative image_index"); return LA3D_ERR_ARG; } if (a.image_index[i] + 1 > P) P = a.image_index[i] + 1; }
+  else if (a.depth_plane_stride != 0 || a.k_stride != 0) P = B;
+  const int64_t R = poly ? a.inst_rings[B] : 0;
+  const int64_t T = rle ? a.rle_offsets[B] : a.ring_offsets[R];
+  if (T < 0 || R < 0) { set_err("la3d_fit_annotations_host: bad offsets"); return LA3D_ERR_ARG; }
+  // block layout: [0] flag | inputs (uploaded) | outputs (written by the kernels through the mapping)
+  size_t off = 64;
+  const size_t o_idx = off;    off += up64(a.image_index ? (size_t)B * 4 : 0);
+  const size_t o_data = off;   off += up64(rle ? (size_t)(T > 0 ? T : 1) * 4 : (size_t)(T > 0 ? T : 1) * 8);
+  const size_t o_off1 = off;   off += up64(rle ? (size_t)(B + 1) * 8 : (size_t)(R + 1) * 8);
+  const size_t o_off2 = off;   off += up64(poly ? (size_t)(B + 1) * 8 : 0);
+  const size_t o_K = off;      off += up64((size_t)(a.k_stride ? P * a.k_stride : 9) * 8);
+  const size_t o_ground = off; off += up64(a.ground ? (size_t)B * 32 : 0);
+  const size_t o_hint = off;   off += up64(a.area_hint ? (size_t)B * 4 : 0);
+  const size_t in_end = off;
+  const size_t o_out = off;    off += up64((size_t)B * LA3D_REC * 8);
+  const size_t o_aux = off;    off += up64((size_t)B * LA3D_AUX * 8);
+  const size_t o_status = off; off += up64((size_t)B * 4);
+  const size_t o_stats = off;  off += up64(a.stats ? (size_t)B * 16 : 0);
+  const size_t ws_bytes = la3d_workspace_bytes(B, a.H, a.W);
+  const size_t d_ws = (in_end + 255) & ~(size_t)255;
+  HostCtx* c = nullptr;
+  const int rc = host_ctx(&c, off, d_ws + ws_bytes + 256, "la3d_fit_annotations_host");
+  if (rc != LA3D_SUCCESS) return rc;
+  unsigned char* h = c->pin;
+  if (a.image_index) memcpy(h + o_idx, a.image_index, (size_t)B * 4);
+  if (T > 0) memcpy(h + o_data, rle ? (const void*)a.rle_counts : (const void*)a.poly_xy, rle ? (size_t)T * 4 : (size_t)T * 8);
+  memcpy(h + o_off1, rle ? (const void*)a.rle_offsets : (const void*)a.ring_offsets, rle ? (size_t)(B + 1) * 8 : (size_t)(R + 1) * 8);
+  if (poly) memcpy(h + o_off2, a.inst_rings, (size_t)(B + 1) * 8);
+  memcpy(h + o_K, a.K, (size_t)(a.k_stride ? P * a.k_stride : 9) * 8);
+  if (a.ground) memcpy(h + o_ground, a.ground, (size_t)B * 32);
+  if (a.area_hint) memcpy(h + o_hint, a.area_hint, (size_t)B * 4);
+  if (hipMemcpyAsync(c->dev + 64, h + 64, in_end - 64, hipMemcpyHostToDevice, c->stream) != hipSuccess) return check_launch("la3d_fit_annotations_host: upload");
+  la3d_fit_args d = a;
+  d.struct_size = (int32_t)sizeof(la3d_fit_args);
+  d.image_index = a.image_index ? reinterpret_cast<const int32_t*>(c->dev + o_idx) : nullptr;
+  if (rle) { d.rle_counts = reinterpret_cast<const int32_t*>(c->dev + o_data); d.rle_offsets = reinterpret_cast<const int64_t*>(c->dev + o_off1); }
+  else { d.poly_xy = reinterpret_cast<const int32_t*>(c->dev + o_data); d.ring_offsets = reinterpret_cast<const int64_t*>(c->dev + o_off1);
+         d.inst_rings = reinterpret_cast<const int64_t*>(c->dev + o_off2); }
+  d.K = reinterpret_cast<const double*>(c->dev + o_K);
+  d.ground = a.ground ? reinterpret_cast<const double*>(c->dev + o_ground) : nullptr;
+  d.area_hint = a.area_hint ? reinterpret_cast<const int32_t*>(c->dev + o_hint) : nullptr;
+  d.out = reinterpret_cast<double*>(c->pin_dev + o_out);
+  d.aux = reinterpret_cast<double*>(c->pin_dev + o_aux);
+  d.status = reinterpret_cast<int32_t*>(c->pin_dev + o_status);
+  d.stats = a.stats ? reinterpret_cast<int32_t*>(c->pin_dev + o_stats) : nullptr;
+  d.workspace = c->dev + d_ws;
+  d.stream = c->stream;
+  const int frc = la3d_fit_instances_ex(&d);
+  if (frc != LA3D_SUCCESS) return frc;
+  if (++c->seq == 0) c->seq = 1;
+  volatile unsigned* done = reinterpret_cast<volatile unsigned*>(c->pin);
+  hipLaunchKernelGGL(host_flag_kernel, dim3(1), dim3(1), 0, c->stream, reinterpret_cast<unsigned*>(c->pin_dev), c->seq);
+  const int lrc = check_launch("host_flag_kernel");
+  if (lrc != LA3D_SUCCESS) return lrc;
+  bool seen = false;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0; !seen; ++spins) {
+    seen = *done == c->seq;
+    if (!seen && (spins & 255u) == 255u &&
+        std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > 5000) break;
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  if (!seen && hipStreamSynchronize(c->stream) != hipSuccess) return check_launch("la3d_fit_annotations_host");
+  memcpy(a.out, h + o_out, (size_t)B * LA3D_REC * 8);
+  if (a.aux) memcpy(a.aux, h + o_aux, (size_t)B * LA3D_AUX * 8);
+  memcpy(a.status, h + o_status, (size_t)B * 4);
+  if (a.stats) memcpy(a.stats, h + o_stats, (size_t)B * 16);
+  return LA3D_SUCCESS;
+}
+
 }  // extern "C"

@@ -342,15 +342,11 @@ def fit_annotations(annotations, image_size, depth, K, ground=None, boundary_thr
     (B, H, W) between calls (the per-image pattern repeats a handful of shapes)."""
     W_img, H_img = int(image_size[0]), int(image_size[1])
     dev = _dev(device)
-    groups = {"rle": ([], []), "poly": ([], [])}
-    for i, a in enumerate(annotations):
-        if a.get("iscrowd") or "segmentation" not in a:
-            continue
-        seg = a["segmentation"]
-        kind = "rle" if isinstance(seg, dict) and "counts" in seg else "poly"
-        groups[kind][0].append(i)
-        groups[kind][1].append({"size": seg["size"], "counts": seg["counts"]} if kind == "rle" else seg)
+    groups = split_annotations(annotations)
     flt = {"boundary_threshold": boundary_threshold, "scale_threshold": scale_threshold}
+    if (to_host and isinstance(depth, torch.Tensor) and depth.is_cuda and depth.dtype == torch.float32 and depth.is_contiguous()
+            and not isinstance(K, torch.Tensor) and not isinstance(ground, torch.Tensor) and not isinstance(image_index, torch.Tensor)):
+        return _fit_annotations_host(annotations, groups, W_img, H_img, depth, K, ground, image_index, flt)
     sels, box_all, st_all, pins = [], [], [], []
     for kind, (idx, segs) in groups.items():
         if not idx:
@@ -458,6 +454,69 @@ def fit_annotations_all(annotations, image_size, depth, K, ground=None, image_in
         boxes.index_copy_(0, sel_t, res["boxes"])
         status.index_copy_(0, sel_t, res["status"])
     return boxes, status
+
+
+def _fit_annotations_host(annotations, groups, W_img, H_img, depth, K, ground, image_index, flt):
+    """``fit_annotations(to_host=True)`` with the depth plane(s) resident and everything else on the host: ONE foreign call per
+    segmentation kind (``la3d_fit_annotations_host``: the small arrays go up through the library's pinned block, the records come back
+    through it, the call polls a completion flag) - no torch tensor, no wrapper layers in between."""
+    from ._lib import FitArgs
+
+    P = depth.shape[0] if depth.dim() == 3 else 1
+    Kh = np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(-1, 9))
+    if Kh.shape[0] not in (1, P):
+        raise ValueError("K must be (3,3) or (P,3,3)")
+    sels, recs, sts = [], [], []
+    for kind, (idx, segs) in groups.items():
+        if not idx:
+            continue
+        sel = np.asarray(idx, np.int64)
+        B = len(idx)
+        a = FitArgs()
+        a.struct_size = C.sizeof(FitArgs)
+        keep = []
+        if kind == "rle":
+            counts, offsets, Hh, Ww = pack_rle(segs)
+            a.rle_counts, a.rle_offsets = counts.ctypes.data, offsets.ctypes.data
+            keep += [counts, offsets]
+        else:
+            xy, ro, ir, Hh, Ww = pack_polygons(segs, H_img, W_img)
+            a.poly_xy, a.ring_offsets, a.inst_rings = xy.ctypes.data, ro.ctypes.data, ir.ctypes.data
+            keep += [xy, ro, ir]
+        if depth.shape[-2:] != (Hh, Ww):
+            raise ValueError(f"depth {tuple(depth.shape[-2:])} does not match the mask size {(Hh, Ww)}")
+        a.B, a.H, a.W = B, Hh, Ww
+        a.depth, a.depth_plane_stride = depth.data_ptr(), (Hh * Ww if P > 1 else 0)
+        if image_index is not None:
+            ii = np.ascontiguousarray(np.asarray(image_index)[sel], np.int32)
+            if ii.size and (ii.min() < 0 or ii.max() >= P):
+                raise ValueError("image_index out of range")
+            a.image_index = ii.ctypes.data; keep.append(ii)
+        elif P > 1 and P != B:
+            raise ValueError("several depth planes need image_index")
+        a.K, a.k_stride = Kh.ctypes.data, (9 if Kh.shape[0] > 1 else 0)
+        if ground is not None:
+            g = np.ascontiguousarray(np.asarray(ground, dtype=np.float64).reshape(-1, 4)[sel])
+            a.ground = g.ctypes.data; keep.append(g)
+        ar = [annotations[i].get("area") for i in idx]
+        if not any(v is None for v in ar):
+            hint = np.clip(np.asarray(ar, dtype=np.float64), 0, 2**31 - 1).astype(np.int32)
+            a.area_hint = hint.ctypes.data; keep.append(hint)
+        a.filter_boundary, a.filter_min_area, a.filter_max_edge = _filter_args(flt)
+        out = np.empty((B, REC), np.float64)
+        st = np.empty(B, np.int32)
+        a.out, a.status = out.ctypes.data, st.ctypes.data
+        check(lib.la3d_fit_annotations_host(C.byref(a)), "la3d_fit_annotations_host")
+        sels.append(sel); recs.append(out); sts.append(st)
+    if not sels:
+        return [], np.zeros(0, np.int64), [], np.zeros((0, REC)), np.zeros(0, np.int32)
+    sel_c = sels[0] if len(sels) == 1 else np.concatenate(sels)
+    st_c = sts[0] if len(sts) == 1 else np.concatenate(sts)
+    rec_c = recs[0] if len(recs) == 1 else np.concatenate(recs)
+    pos = np.nonzero(st_c != BOX_FILTERED)[0]
+    pos = pos[np.argsort(sel_c[pos], kind="stable")]
+    kept = sel_c[pos]
+    return ([annotations[i]["bbox"] for i in kept], kept, [annotations[i]["category_id"] for i in kept], rec_c[pos], st_c[pos])
 
 
 def segmentations_to_masks(segmentations, H: int, W: int, device=None) -> torch.Tensor:

@@ -377,6 +377,83 @@ def test_fit_annotations_one_pass(la):
     assert out[0] == [] and out[3].shape == (0, 39)
 
 
+def test_fit_annotations_host_entry_equals_the_device_route(la):
+    """la3d_fit_annotations_host (``fit_annotations(to_host=True)`` with the depth planes resident and every other argument on the
+    host): ONE foreign call per segmentation kind - inputs through the library's pinned block, records back through it - must
+    return exactly what the tensor route returns: kept set, boxes, categories, records, status; with and without ground planes,
+    one plane or several planes + image_index, per-plane intrinsics."""
+    import ctypes as C
+
+    import torch
+    from labelany3d_amd._lib import FitArgs, lib
+
+    rs = np.random.RandomState(71)
+    H, W, P_ = 240, 320, 3
+    anns = []
+    for i in range(36):
+        seg = _random_segmentation(rs, W, H, i % 8)
+        a = {"iscrowd": int(i % 13 == 0), "bbox": [float(i), 1.0, 2.0, 3.0], "category_id": 1 + i % 5, "segmentation": seg}
+        if i % 2 == 0:
+            a["area"] = float(rs.randint(10, 50000))      # mixed: the hint is only used when every annotation of a kind has one
+        if i % 3 == 0:
+            m, _ = P.create_boolean_mask_from_polygon((W, H), seg)
+            a["segmentation"] = O.rle_encode(m)
+        anns.append(a)
+    anns.append({"iscrowd": 0, "bbox": [0, 0, 1, 1], "category_id": 9})
+    depth = rs.uniform(0.5, 10, (P_, H, W)).astype(np.float32)
+    depth_d = torch.as_tensor(depth, device="cuda")
+    K = np.array([[250.0, 0, 160], [0, 250.0, 120], [0, 0, 1]])
+    Ks = np.stack([K, K * np.array([[1.1], [0.9], [1.0]]), K])
+    ground = np.array([[0.02, -0.97, 0.1, 1.0]] * len(anns)) + 0.02 * rs.randn(len(anns), 4)
+    img = rs.randint(0, P_, len(anns)).astype(np.int32)
+    cases = [dict(depth=0, K=K, ground=None, image_index=None), dict(depth=0, K=K, ground=ground, image_index=None),
+             dict(depth=None, K=K, ground=ground, image_index=img), dict(depth=None, K=Ks, ground=None, image_index=img)]
+    for c in cases:
+        dh = depth[c["depth"]] if c["depth"] is not None else depth
+        dd = depth_d[c["depth"]] if c["depth"] is not None else depth_d
+        kw = dict(ground=c["ground"], image_index=c["image_index"])
+        want = la.fit_annotations(anns, (W, H), dh, c["K"], to_host=True, **kw)            # host depth: the tensor route
+        got = la.fit_annotations(anns, (W, H), dd, c["K"], to_host=True, **kw)             # resident depth: the host entry
+        assert got[0] == want[0] and got[2] == want[2] and len(got[1]) > 5
+        np.testing.assert_array_equal(got[1], want[1])
+        np.testing.assert_array_equal(got[4], want[4])
+        np.testing.assert_array_equal(got[3], want[3])
+        assert isinstance(got[3], np.ndarray) and got[3].dtype == np.float64 and got[4].dtype == np.int32
+    # other thresholds travel
+    w2 = la.fit_annotations(anns, (W, H), depth[0], K, to_host=True, boundary_threshold=30, scale_threshold=2000)
+    g2 = la.fit_annotations(anns, (W, H), depth_d[0], K, to_host=True, boundary_threshold=30, scale_threshold=2000)
+    np.testing.assert_array_equal(g2[1], w2[1]); np.testing.assert_array_equal(g2[3], w2[3])
+    assert len(g2[1]) < len(got[1])
+    out = la.fit_annotations([], (W, H), depth_d[0], K, to_host=True)
+    assert out[0] == [] and out[3].shape == (0, 39)
+    # the C entry itself: aux / stats outputs, error behaviour
+    segs = [a["segmentation"] for a in anns if not a.get("iscrowd") and isinstance(a.get("segmentation"), list)]
+    xy, ro, ir, Hh, Ww = la.pack_polygons(segs, H, W)
+    B = len(segs)
+    a = FitArgs(); a.struct_size = C.sizeof(FitArgs)
+    a.B, a.H, a.W = B, H, W
+    a.depth = depth_d[0].data_ptr()
+    a.poly_xy, a.ring_offsets, a.inst_rings = xy.ctypes.data, ro.ctypes.data, ir.ctypes.data
+    Kc = np.ascontiguousarray(K.reshape(-1)); a.K = Kc.ctypes.data
+    out = np.empty((B, 39)); st = np.empty(B, np.int32); aux = np.empty((B, 4)); stats = np.empty((B, 4), np.int32)
+    a.out, a.status, a.aux, a.stats = out.ctypes.data, st.ctypes.data, aux.ctypes.data, stats.ctypes.data
+    a.filter_boundary, a.filter_min_area, a.filter_max_edge = 10, 100, 10
+    assert lib.la3d_fit_annotations_host(C.byref(a)) == 0
+    b1, s1, a1, st1 = la.fit_instances_poly(depth[0], (xy, ro, ir, H, W), K, filter=True)
+    np.testing.assert_array_equal(out, np_(b1)); np.testing.assert_array_equal(st, np_(s1))
+    np.testing.assert_array_equal(aux, np_(a1)); np.testing.assert_array_equal(stats, np_(st1))
+    a.filter_boundary = -1                                # no filter: every instance fitted
+    assert lib.la3d_fit_annotations_host(C.byref(a)) == 0
+    b0, s0, _ = la.fit_instances_poly(depth[0], (xy, ro, ir, H, W), K)
+    np.testing.assert_array_equal(st, np_(s0)); np.testing.assert_array_equal(out, np_(b0))
+    a.B = 0
+    assert lib.la3d_fit_annotations_host(C.byref(a)) == 0
+    a.B = B; a.depth = None
+    assert lib.la3d_fit_annotations_host(C.byref(a)) != 0 and b"la3d_fit_annotations_host" in lib.la3d_last_error()
+    a.depth = depth_d[0].data_ptr(); a.rle_counts = xy.ctypes.data          # both kinds at once
+    assert lib.la3d_fit_annotations_host(C.byref(a)) != 0
+
+
 def test_fit_instances_ex_projection_in_the_epilogue(la, monkeypatch):
     """la3d_fit_instances_ex: the records' 2-D boxes (bbox2D_proj | bbox2D_trunc, reference src/tools/combine_results.py:105-108,
     :238-252) written by the epilogue that writes the record must equal la3d_project_boxes on the finished records - for u8 planes
