@@ -1458,8 +1458,12 @@ int la3d_unproject_batch(const float* depth, const double* K, int32_t k_stride, 
   for (int i = 0; i < 3; ++i) p.t[i] = Rt12 ? Rt12[9 + i] : 0.0;
   p.H = H; p.W = W; p.HW = H * W; p.rcpW = 1.0f / (float)W;
   int bx = (p.HW + 255) / 256;
-  const int want = (8192 + P - 1) / P;   // enough workgroups over all frames to fill the chip several times
-  if (bx > want) bx = want < 1 ? 1 : want;
+  // enough workgroups over all frames to fill the chip several times - but never fewer than 256 per frame: the ~2000 resident
+  // workgroups then write into ~8 frames at a time instead of 64 (profiles/r05/r05_unproject_sweep.txt: 256 / 1024 frames of 640x480,
+  // f64 out: 4.66 / 5.24 TB/s with 32 workgroups per frame, 5.41 / 5.78 with 256)
+  int want = (8192 + P - 1) / P;
+  if (want < 256) want = 256;
+  if (bx > want) bx = want;
   hipStream_t s = static_cast<hipStream_t>(stream);
   // 16-byte stores need every frame's output base 16-aligned: HW * 3 * sizeof(OutT) a multiple of 16
   const int vec16 = (reinterpret_cast<uintptr_t>(out) & 15) == 0 && ((long long)p.HW * 3 * (out_is_f64 ? 8 : 4)) % 16 == 0;

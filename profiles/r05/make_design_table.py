@@ -9,10 +9,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r05")
 tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_per_launch.json")))["modes"]
-order = ["config2", "config2_twopass", "config2_retaining", "config2_area_hint", "config2_subsample", "config2_rle", "config2_rle_area_hint", "config2_poly", "config2_B256", "config2_B8192",
+order = ["config2", "config2_ground", "config2_twopass", "config2_retaining", "config2_area_hint", "config2_subsample", "config2_rle", "config2_rle_area_hint", "config2_poly", "config2_B256", "config2_B8192",
          "config5", "config5_B16384", "config3_5000", "config3_14750"]
 names = {
     "config2": "**config 2** (headline): 1024 instances, private depth, u8 rectangles",
+    "config2_ground": "config 2 masks and depth with one ground plane per instance (`--ground`: the two-pass form; the reference's harness always passes one)",
     "config2_twopass": "config 2 with the two-pass form pinned (`LA3D_SEP=0`: round 4's default)",
     "config2_retaining": "config 2 with the retaining build pinned (`LA3D_RETAIN=1`: 128 VGPRs, two workgroups per CU; the default of rounds 2–3)",
     "config2_area_hint": "config 2, mask areas handed to the fit (`--area-hint`): no helper launch",

@@ -12,7 +12,7 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_style.json 2> $
 python bench.py > $O/bench_default.json 2>/dev/null
 modes=("config2|" "config2_rle|--rle" "config2_poly|--poly" "config2_subsample|--subsample" "config2_area_hint|--area-hint" "config2_rle_area_hint|--rle --area-hint" \
        "config5|--config5" "config5_B16384|--config5 --batch 16384" "config3_5000|--config3 5000" "config3_14750|--config3 14750" \
-       "config2_B256|--batch 256" "config2_B8192|--batch 8192")
+       "config2_B256|--batch 256" "config2_B8192|--batch 8192" "config2_ground|--ground")
 for m in "${modes[@]}"; do
   tag=${m%%|*}; args=${m#*|}
   python bench.py --no-cpu-baseline $args > $O/bench_$tag.json 2>/dev/null
@@ -45,6 +45,7 @@ python profiles/r05/exp_small_batches.py > $O/small_batches_formats.txt 2>&1
 python -m pytest tests/test_gpu_cabi.py -m gpu -q -s -k scalar_dropins 2>&1 | grep "host-pointer" > $O/host_pointer_latency.txt
 L=labelany3d_amd/lib/libla3d.so
 python profiles/r04/exp_per_image.py > $O/per_image.txt 2>&1
+python profiles/r05/exp_per_image_host.py 2>&1 | grep annotations > $O/per_image_host.txt
 # re-run the headline with the fresh traffic table in place (traffic_stale must read false)
 cp $REPO/gpurun_out/traffic_per_launch.json $REPO/profiles/traffic_per_launch.json
 python bench.py > $O/bench_default_final.json 2>/dev/null
