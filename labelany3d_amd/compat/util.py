@@ -8,7 +8,7 @@ Two ways to use it:
     does not define is fetched lazily from the reference's own ``util.py`` found further down ``sys.path``
     (module ``__getattr__``, PEP 562), so ``from util import restore_mask_from_crop, depth_to_points`` works.
 """
-from labelany3d_amd.util import *  # noqa: F401,F403
+from labelany3d_amd.util import depth_to_points  # noqa: F401   (the hot-path function only: the overlay / helpers stay the reference's own)
 from labelany3d_amd import util as _impl
 from labelany3d_amd.compat import _reference_module
 
