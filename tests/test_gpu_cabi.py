@@ -184,3 +184,78 @@ def test_scalar_dropins_run_on_host_pointers_and_are_fast(capsys):
     with capsys.disabled():
         print(f"\n[host-pointer drop-ins] estimate_bbox(500 points): {per_call:.1f} us / call; depth_to_points(480x640): {per_frame:.0f} us / frame")
     assert per_call < 150.0, per_call       # (84 us through torch tensors in round 4; the target is 30)
+
+
+@pytest.mark.gpu
+def test_host_pointer_entries_from_several_threads():
+    """The host-pointer entries keep their staging memory and stream per calling THREAD: four threads calling estimate_bbox,
+    depth_to_points and fit_annotations(to_host=True) at the same time (different inputs per thread, 40 rounds each) must get
+    exactly what a single thread gets; la3d_host_release() from a thread frees that thread's context and the next call rebuilds it."""
+    import ctypes as C
+    import threading
+
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import labelany3d_amd as la
+    from labelany3d_amd import util
+    from labelany3d_amd._lib import lib
+
+    H, W, T = 240, 320, 4
+    K = np.array([[250.0, 0, 160], [0, 250.0, 120], [0, 0, 1]])
+    work = []
+    for t in range(T):
+        rs = np.random.RandomState(100 + t)
+        pcs = [rs.randn(50 + 150 * t, 3) * [1.0, 0.4, 0.7] + [0.1 * t, 1.0, 4.0 + t] for _ in range(3)]
+        depth = rs.uniform(0.5, 10, (1, H, W)).astype(np.float32)
+        anns = []
+        for i in range(5 + t):
+            x0, y0 = rs.randint(10, W // 2), rs.randint(10, H // 2)
+            w, h = rs.randint(30, W // 3), rs.randint(30, H // 3)
+            anns.append({"iscrowd": 0, "bbox": [float(x0), float(y0), float(w), float(h)], "category_id": 1 + i,
+                         "segmentation": [[x0, y0, x0 + w, y0, x0 + w, y0 + h, x0, y0 + h]], "area": float(w * h)})
+        ground = np.array([[0.02, -0.97, 0.1, 1.0]] * len(anns)) + 0.02 * rs.randn(len(anns), 4)
+        work.append((pcs, depth, anns, ground, torch.as_tensor(depth[0], device="cuda")))
+
+    def one(t):
+        pcs, depth, anns, ground, dd = work[t]
+        out = []
+        for pc in pcs:
+            rec, aux, st = np.empty(39), np.empty(4), C.c_int32(0)
+            pcc = np.ascontiguousarray(pc)
+            assert lib.la3d_estimate_bbox_host(pcc.ctypes.data, len(pcc), None, 0, rec.ctypes.data, aux.ctypes.data, C.byref(st)) == 0
+            out.append((rec, st.value))
+        pts = util.depth_to_points(depth, K)
+        ann = la.fit_annotations(anns, (W, H), dd, K, ground=ground, to_host=True)
+        return out, pts, ann
+
+    want = [one(t) for t in range(T)]
+    errors, got = [], [None] * T
+
+    def worker(t):
+        try:
+            for r in range(40):
+                res = one(t)
+                if r == 20:
+                    lib.la3d_host_release()          # this thread's context only; rebuilt by the next call
+                for (ra, sa), (rb, sb) in zip(res[0], want[t][0]):
+                    assert sa == sb
+                    np.testing.assert_array_equal(ra, rb)
+                np.testing.assert_array_equal(res[1], want[t][1])
+                assert res[2][0] == want[t][2][0] and res[2][2] == want[t][2][2]
+                np.testing.assert_array_equal(res[2][1], want[t][2][1])
+                np.testing.assert_array_equal(res[2][3], want[t][2][3])
+                np.testing.assert_array_equal(res[2][4], want[t][2][4])
+            got[t] = True
+        except BaseException as e:   # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    assert all(got)
+    assert len(want[0][2][1]) > 0 and want[0][0][0][1] == 0
