@@ -88,6 +88,8 @@ int la3d_mask_counts(const uint8_t* mask, int B, int H, int W, int32_t* counts, 
 #define LA3D_ENGINE_INSTANCE 1        /* one workgroup per instance */
 #define LA3D_ENGINE_SPLIT 2           /* band scan + tile-range-balanced passes (falls back to the instance engine where it does not apply) */
 #define LA3D_ENGINE_BAND 3            /* two (or four) workgroups per instance, one per band of tile rows (u8 planes, tiled frames; falls back likewise) */
+#define LA3D_ENGINE_ROWS 4            /* round 5: up to sixteen workgroups per instance, one per band of rows, partial sums merged by a second short
+                                         launch (u8 planes, no ground array, at most 512 instances; falls back likewise) */
 #define LA3D_ORDER_DEFAULT 0          /* size-balanced launch order for 256 < B <= 3 resident sets; the sort keys are estimated inside the
                                          fit kernel and handed over through the workspace, so ONE workspace serves ONE call at a time, and
                                          several ORDERED calls running concurrently on different streams slow each other down (a call whose

@@ -42,13 +42,15 @@ const Config& config() {
     Config k;
     const char* e = getenv("LA3D_ENGINE");
     k.engine = (e && !strcmp(e, "instance")) ? LA3D_ENGINE_INSTANCE : (e && !strcmp(e, "split")) ? LA3D_ENGINE_SPLIT
-             : (e && !strcmp(e, "band")) ? LA3D_ENGINE_BAND : LA3D_ENGINE_DEFAULT;
+             : (e && !strcmp(e, "band")) ? LA3D_ENGINE_BAND : (e && !strcmp(e, "rows")) ? LA3D_ENGINE_ROWS : LA3D_ENGINE_DEFAULT;
     e = getenv("LA3D_BANDS");
     k.bands = (e && (atoi(e) == 4 || atoi(e) == 2)) ? atoi(e) : 0;
     e = getenv("LA3D_BAND_DEFAULT");      // 0: the band engine only when asked for (LA3D_ENGINE=band / opt_engine)
     k.band_default = !(e && e[0] == '0');
     e = getenv("LA3D_BAND_MAXB");
     k.band_maxb = (e && atoi(e) > 0) ? atoi(e) : 256;
+    e = getenv("LA3D_ROWS_MAXB");
+    k.rows_maxb = e ? atoi(e) : 192;   // largest batch the row engine takes by default (0: never); above, one workgroup per instance is as fast
     e = getenv("LA3D_BALANCE");
     k.balance = !(e && e[0] == '0');
     e = getenv("LA3D_BALANCE_ROUNDS");
@@ -509,7 +511,9 @@ __device__ __host__ inline int sep_col_words(int W) { return (2 * W + 3) & ~3; }
 // 0xffffffff / 0 before the barrier in front of this call.
 __device__ inline void sweep_sep(const FitParams& p, const float* __restrict__ dpl, const unsigned* bits,
                                  const unsigned short* list, int nactive, const double* Mg, unsigned* col, int wave, int lane,
-                                 double* acc, double* yext, unsigned* unsafe) {
+                                 double* acc, double* yext, unsigned* unsafe, int row0 = 0) {
+  // (row0: the frame row of tile row 0 - the row engine hands every workgroup a band of rows, dpl / bits / list band-local;
+  // the instance engine passes the literal 0)
   const int c = lane & 31, h4 = (lane >> 5) * 4;
   const double a00 = Mg[0], a02 = Mg[2], a11 = Mg[4], a12 = Mg[5];
   unsigned loff[4];   // byte offsets of this lane's four pixels inside a tile (uniform tile origin + 32-bit vector offset: the saddr form)
@@ -550,7 +554,7 @@ __device__ inline void sweep_sep(const FitParams& p, const float* __restrict__ d
     for (int g = 0; g < TG; ++g) {
       if (j0 + g >= nactive) continue;   // uniform
       const int tx = tcs[g] & 0xff, ty = tcs[g] >> 8;
-      double ry = fma(a11, (double)(ty * 8 + h4), a12);
+      double ry = fma(a11, (double)(ty * 8 + h4 + row0), a12);
       double c1 = 0.0, c2 = 0.0;
       unsigned cmin = 0xffffffffu, cmax = 0u;
 #pragma unroll
@@ -2379,6 +2383,305 @@ inline int retain_steps(const FitParams& p) {
   return p.B <= (c.retain_maxb >= 0 ? c.retain_maxb : RETAIN_MAXB_DEFAULT) ? RETAIN_STEPS : 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// row engine (round 5): NB workgroups per instance, one per band of tile rows, for SMALL batches of u8 planes without a ground
+// array - the separable single pass split by rows.  Everything the single pass accumulates is a sum or a min / max, so the bands
+// need no exchange and no co-residency: every band workgroup streams only ITS rows of the mask plane, builds its tile list, runs
+// sweep_sep over its rows (band-local bit image / list / depth pointer, the frame row of its first tile row handed in) and leaves a
+// partial record - five sums, the y extent, the mask count, a flag - and its per-column depth ranges in the workspace; a second,
+// short launch (merge_rows_kernel: one workgroup per instance) adds the partials in a fixed order and runs the SAME axis / extent /
+// box stages as the instance engine.  A lone workgroup needs ~27 us for one 640x480 instance (5 us to stream the plane, 12-17 us
+// in a pass that has only its own 16 loads per wave in flight); sixteen bands need a sixteenth of each.  A band that cannot take
+// the single pass (skewed K, a NaN / inf / negative depth under the mask) raises its flag and the merge workgroup fits the whole
+// instance with the generic row-linear two-pass walk (what the band engine's take-over uses): slow, rare, never a dropped box.
+// ------------------------------------------------------------------------------------------
+constexpr int ROWS_NB_MAX = 16;
+constexpr int ROWS_PART_D = 20;   // doubles per (instance, band): Sx, Sz, Sxx, Sxz, Szz | ymin, ymax | mask pixels | flag | pad | M[9] | pad
+constexpr int ROWS_MAX_B = 512;
+
+struct RowsArgs {
+  int nb;           // bands per instance (the last ones may be shorter; every band holds at least one tile row)
+  int trows;        // tile rows per band
+  int bits_bytes;   // band bit image + per-column ranges (16-aligned): LDS in front of Shared
+  double* part;     // [B][nb][ROWS_PART_D]
+  unsigned* col;    // [B][nb][2 W]: colmin | colmax of the band
+};
+
+// host: bands for a batch of B instances on an H x W frame; false = the row engine does not apply
+inline bool rows_plan(int B, int H, int W, RowsArgs* ra) {
+  if (B < 1 || B > ROWS_MAX_B || H % 8 != 0 || W % 32 != 0 || W / 32 > 255 || H / 8 < 2) return false;
+  const int nty = H / 8;
+  int nb = ROWS_NB_MAX;
+  // about 500-640 workgroups in all (profiles/r05/r05_rows_engine.txt: B = 64 / 128 / 192, us per call with at most 256 | 512 | 1024 |
+  // 2048 workgroups: 24.4 | 24.0 | 27.9 | 27.9; 32.7 | 30.0 | 33.1 | 36.8; 38.2 | 38.0 | 40.7 | 39.8)
+  while (nb > 2 && B * nb > 640) nb >>= 1;
+  int trows = (nty + nb - 1) / nb;
+  if (trows < 2) trows = 2;                          // (a band of one tile row is all fixed cost)
+  nb = (nty + trows - 1) / trows;
+  if (nb < 2 || (long long)(W / 32) * trows > 256 * NWAVE) return false;   // one-pass tile list: <= 256 tiles per wave
+  const long long bits = ((long long)trows * W + sep_col_words(W) * 4 + 15) & ~15LL;
+  if (bits + (long long)sizeof(Shared) + (long long)(W / 32) * trows * 2 + 64 > 64 * 1024) return false;
+  ra->nb = nb; ra->trows = trows; ra->bits_bytes = (int)bits;
+  return true;
+}
+inline size_t rows_workspace_bytes(int B, int H, int W) {
+  RowsArgs ra;
+  if (!rows_plan(B, H, W, &ra)) return 0;
+  return (size_t)B * ra.nb * ROWS_PART_D * 8 + (size_t)B * ra.nb * 2 * W * 4 + 256;
+}
+
+__global__ __launch_bounds__(NT, NT / 64) void fit_rows_kernel(const FitParams p, const RowsArgs ra) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned* bits = reinterpret_cast<unsigned*>(smem);
+  Shared* sh = reinterpret_cast<Shared*>(smem + ra.bits_bytes);
+  unsigned short* list = reinterpret_cast<unsigned short*>(smem + ra.bits_bytes + sizeof(Shared));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int v = (int)blockIdx.x;
+  const int inst = v / ra.nb, band = v - inst * ra.nb;
+  const int img = p.image_index ? p.image_index[inst] : inst;
+  const int row0 = band * ra.trows * 8;
+  const int trows = min(ra.trows, p.H / 8 - band * ra.trows);   // >= 1 (rows_plan)
+  const int W = p.W, ntx = W / 32;
+  const float* dpl = p.depth + (long long)img * p.depth_plane_stride + (long long)row0 * W;
+  const unsigned char* mpl = p.mask + (long long)inst * p.HW + (long long)row0 * W;
+  if (tid == NT - 1) {   // M = K^-1 (no ground array: Rg is the identity; the same expression as the instance engine's)
+    double Kinv[9], Rg[9];
+    inv3_camera(p.K + (long long)img * p.k_stride, Kinv);
+    (void)ground_rotation(nullptr, Rg);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) sh->M[i * 3 + j] = Rg[i] * Kinv[j] + Rg[3 + i] * Kinv[3 + j] + Rg[6 + i] * Kinv[6 + j];
+  }
+  // ---- the band's rows of the u8 plane -> bit image (the instance engine's optimistic 0 / 1 form, general form behind it) ----
+  unsigned short* b16 = reinterpret_cast<unsigned short*>(bits);
+  const int ngroups = trows * 8 * W / 16;
+  const u32x4* m4 = reinterpret_cast<const u32x4*>(mpl);
+  int nmask = 0;
+  {
+    unsigned seen = 0;
+#pragma unroll 4
+    for (int g = tid; g < ngroups; g += NT) {
+      const u32x4 w = __builtin_nontemporal_load(m4 + g);
+      const unsigned lo = __builtin_amdgcn_udot4(w.y, 0x80402010u, __builtin_amdgcn_udot4(w.x, 0x08040201u, 0u, false), false);
+      const unsigned hi = __builtin_amdgcn_udot4(w.w, 0x80402010u, __builtin_amdgcn_udot4(w.z, 0x08040201u, 0u, false), false);
+      const unsigned pat = lo | (hi << 8);
+      seen |= (w.x | w.y) | (w.z | w.w);
+      b16[g] = (unsigned short)pat;
+      nmask += __popc(pat);
+    }
+    const unsigned long long odd = __ballot((seen & 0xfefefefeu) != 0);
+    if (lane == 0) sh->scan[wave] = odd != 0 ? 1u : 0u;
+    __syncthreads();
+    unsigned general = 0;
+#pragma unroll
+    for (int w = 0; w < NWAVE; ++w) general |= sh->scan[w];
+    if (general) {   // uniform: some byte is neither 0 nor 1
+      nmask = 0;
+#pragma unroll 4
+      for (int g = tid; g < ngroups; g += NT) {
+        const u32x4 w = m4[g];
+        const unsigned pat = nz16(w.x, w.y, w.z, w.w);
+        b16[g] = (unsigned short)pat;
+        nmask += __popc(pat);
+      }
+    }
+  }
+  __syncthreads();
+  double Mg[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Mg[i] = uniform_f64(sh->M[i]);
+  const bool sep_cam = Mg[1] == 0.0 && Mg[3] == 0.0 && Mg[6] == 0.0 && Mg[7] == 0.0 && Mg[8] == 1.0;   // uniform
+  // ---- active tiles of the band: list + the eight row words of every active tile, compacted in place ----
+  const int ntiles = ntx * trows, per = (ntiles + NWAVE - 1) / NWAVE;
+  const int tbeg = wave * per, tend = min(tbeg + per, ntiles);
+  unsigned long long bal[4];
+  unsigned wrd[4][8];
+  int wcount = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int t = tbeg + k * 64 + lane;
+    unsigned any = 0;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) wrd[k][rr] = 0u;
+    if (t < tend) {
+      const int ty = (int)(((float)t + 0.5f) * p.rcp_ntx), tx = t - ty * ntx;
+      const unsigned* bw = bits + (ty * 8) * ntx + tx;
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const unsigned w = bw[rr * ntx];
+        any |= w;
+        wrd[k][rr] = w;
+      }
+    }
+    bal[k] = __ballot(any != 0);
+    wcount += __popcll(bal[k]);
+  }
+  if (lane == 0) sh->scan[wave] = (unsigned)wcount;
+  __syncthreads();   // (every wave has read its row words: the image region can be overwritten)
+  int base = 0, nactive = 0;
+  for (int w = 0; w < NWAVE; ++w) {
+    const int c = (int)sh->scan[w];
+    if (w < wave) base += c;
+    nactive += c;
+  }
+  {
+    int off = base;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if ((bal[k] >> lane) & 1ull) {
+        const int t = tbeg + k * 64 + lane;
+        const int ty = (int)(((float)t + 0.5f) * p.rcp_ntx), tx = t - ty * ntx;
+        const int idx = off + __popcll(bal[k] & ((1ull << lane) - 1ull));
+        list[idx] = (unsigned short)((ty << 8) | tx);
+        uint4* e = reinterpret_cast<uint4*>(bits) + 2 * idx;
+        e[0] = make_uint4(wrd[k][0], wrd[k][1], wrd[k][2], wrd[k][3]);
+        e[1] = make_uint4(wrd[k][4], wrd[k][5], wrd[k][6], wrd[k][7]);
+      }
+      off += __popcll(bal[k]);
+    }
+  }
+  unsigned* col = bits + nactive * 8;   // behind the entries: rows_plan sized the region for a band with every tile active
+  for (int u = tid; u < W; u += NT) { col[u] = 0xffffffffu; col[W + u] = 0u; }
+  __syncthreads();
+  // ---- the single pass over the band ----
+  double sacc[5] = {0, 0, 0, 0, 0}, yx[2] = {INFINITY, -INFINITY};
+  unsigned unsafe = 0u;
+  if (sep_cam) sweep_sep(p, dpl, bits, list, nactive, Mg, col, wave, lane, sacc, yx, &unsafe, row0);
+  {
+    const double r0 = wave_sum(sacc[0]), r1 = wave_sum(sacc[1]), r2 = wave_sum(sacc[2]), r3 = wave_sum(sacc[3]), r4 = wave_sum(sacc[4]);
+    const double ylo = wave_min(yx[0]), yhi = wave_max(yx[1]);
+    const int rn = wave_sum_i(nmask);
+    const bool bad = __ballot(unsafe >= 0x7f800000u) != 0ull;
+    if (lane == 0) {
+      double* pp = sh->part[wave];
+      pp[0] = r0; pp[1] = r1; pp[2] = r2; pp[3] = r3; pp[4] = r4; pp[5] = ylo; pp[6] = yhi;
+      sh->nmask[wave] = rn;
+      sh->cnt[wave] = bad ? 1 : 0;
+    }
+  }
+  __syncthreads();   // (also: every ds_min / ds_max of the pass has landed)
+  if (tid == 0) {
+    double t[7] = {0, 0, 0, 0, 0, INFINITY, -INFINITY};
+    int nm = 0, bad = sep_cam ? 0 : 1;
+    for (int w = 0; w < NWAVE; ++w) {   // fixed order: reproducible
+#pragma unroll
+      for (int k = 0; k < 5; ++k) t[k] += sh->part[w][k];
+      t[5] = fmin(t[5], sh->part[w][5]); t[6] = fmax(t[6], sh->part[w][6]);
+      nm += sh->nmask[w];
+      bad |= sh->cnt[w];
+    }
+    double* q = ra.part + (long long)v * ROWS_PART_D;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) q[k] = t[k];
+    q[7] = (double)nm; q[8] = (double)bad; q[9] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) q[10 + k] = sh->M[k];   // (the merge workgroup takes the camera from band 0: no second inversion)
+    q[19] = 0.0;
+  }
+  unsigned* gcol = ra.col + (long long)v * 2 * W;
+  for (int u = tid; u < 2 * W; u += NT) gcol[u] = col[u];
+}
+
+// one workgroup per instance: partials of its bands -> status, axis, extents, record (the instance engine's stages)
+__global__ __launch_bounds__(NT, NT / 64) void merge_rows_kernel(const FitParams p, const RowsArgs ra) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Shared* sh = reinterpret_cast<Shared*>(smem);
+  unsigned* mcol = reinterpret_cast<unsigned*>(smem + sizeof(Shared));   // [2 W]: the bands' per-column ranges merged
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int inst = (int)blockIdx.x;
+  const int img = p.image_index ? p.image_index[inst] : inst;
+  const int W = p.W;
+  const double* part = ra.part + (long long)inst * ra.nb * ROWS_PART_D;
+  const unsigned* gc = ra.col + (long long)inst * ra.nb * 2 * W;
+  // the per-column ranges first (the longest chain of loads): 2 W / 4 threads, each the min (first W words) or max (last W) of four
+  // columns over the bands - independent 16-byte loads, eight in flight
+  for (int qd = tid; qd < W / 2; qd += NT) {
+    const bool is_max = qd >= W / 4;
+    const uint4* src = reinterpret_cast<const uint4*>(gc) + qd;
+    uint4 m = is_max ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+#pragma unroll 8
+    for (int b = 0; b < ra.nb; ++b) {
+      const uint4 w = src[(long long)b * (W / 2)];
+      if (is_max) { m.x = max(m.x, w.x); m.y = max(m.y, w.y); m.z = max(m.z, w.z); m.w = max(m.w, w.w); }
+      else { m.x = min(m.x, w.x); m.y = min(m.y, w.y); m.z = min(m.z, w.z); m.w = min(m.w, w.w); }
+    }
+    reinterpret_cast<uint4*>(mcol)[qd] = m;
+  }
+  if (tid < 9) sh->M[tid] = part[10 + tid];                      // band 0's camera (every band computed the same one)
+  else if (tid < 18) sh->Rg[tid - 9] = ((tid - 9) % 4 == 0) ? 1.0 : 0.0;   // no ground array: the identity (ground_rotation(nullptr))
+  if (tid == 18) { sh->bad_ground = 0; sh->order_inst = inst; sh->sep_bad = 0; }
+  double acc[5] = {0, 0, 0, 0, 0}, ylo = INFINITY, yhi = -INFINITY;
+  int nm = 0, flag = 0;
+  if (tid < ra.nb) {   // band b in lane b of wave 0: the wave sum of stage_moments_to_axis adds them in its fixed tree
+    const double* q = part + (long long)tid * ROWS_PART_D;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) acc[k] = q[k];
+    ylo = q[5]; yhi = q[6]; nm = (int)q[7]; flag = q[8] != 0.0 ? 1 : 0;
+  }
+  const int any_flag = __syncthreads_or(flag);   // (also publishes M / Rg / mcol)
+  double Mg[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Mg[i] = uniform_f64(sh->M[i]);
+  if (!any_flag) {   // uniform
+    stage_moments_to_axis(sh, p, inst, acc, nm, nm, tid, wave, lane, true);
+    if (!sh->redo) {   // uniform
+      if (sh->st != LA3D_BOX_OK) return;
+      double N0[3], N2[3], ext[6];
+      yaw_rows(sh, Mg, N0, N2);
+      sep_col_extents(mcol, W, N0, N2, tid, ext);
+      ext[2] = ylo; ext[3] = yhi;
+      stage_extents_to_box(sh, p, inst, ext, tid, wave, lane);
+      stage_status_aux(sh, p, inst, tid);
+      return;
+    }
+    __syncthreads();
+  }
+  // a band could not take the single pass: the whole instance by this workgroup, generic row-linear two-pass walk over the plane
+  const float* dpl = p.depth + (long long)img * p.depth_plane_stride;
+  const unsigned char* mpl = p.mask + (long long)inst * p.HW;
+  double gacc[5] = {0, 0, 0, 0, 0};
+  int cnt = 0, nmask = 0;
+  sweep<true, false, 0>(p, dpl, mpl, nullptr, Mg, Mg + 3, Mg + 6, wave, lane, gacc, &cnt, &nmask);
+  stage_moments_to_axis(sh, p, inst, gacc, cnt, nmask, tid, wave, lane, false);
+  if (sh->st != LA3D_BOX_OK) return;
+  double ext[6] = {INFINITY, -INFINITY, INFINITY, -INFINITY, INFINITY, -INFINITY};
+  double N0[3], N2[3];
+  yaw_rows(sh, Mg, N0, N2);
+  int d0 = 0, d1 = 0;
+  sweep<true, false, 1>(p, dpl, mpl, nullptr, N0, Mg + 3, N2, wave, lane, ext, &d0, &d1);
+  stage_extents_to_box(sh, p, inst, ext, tid, wave, lane);
+  stage_status_aux(sh, p, inst, tid);
+}
+
+// u8 planes, 16-byte aligned, full-mask mode, no ground array, B <= ROWS_MAX_B: LA3D_ENGINE=rows / opt_engine pins it, by default
+// it takes the batches up to config().rows_maxb
+inline bool rows_eligible(const FitParams& p, bool vec, bool sample, RowsArgs* ra) {
+  const int e = p.opt_engine != LA3D_ENGINE_DEFAULT ? p.opt_engine : config().engine;
+  if (e != LA3D_ENGINE_DEFAULT && e != LA3D_ENGINE_ROWS) return false;
+  if (!vec || sample || p.mask == nullptr || p.ground != nullptr || p.sep_off || p.filter_boundary >= 0) return false;
+  if ((p.opt_build != LA3D_BUILD_DEFAULT ? p.opt_build : config().retain) == LA3D_BUILD_RETAINING) return false;
+  if (!rows_plan(p.B, p.H, p.W, ra)) return false;
+  return e == LA3D_ENGINE_ROWS || p.B <= config().rows_maxb;
+}
+
+int launch_fit_rows(const FitParams& p_in, RowsArgs ra, hipStream_t s, void* workspace) {
+  FitParams p = p_in;
+  p.ntx = p.W / 32; p.nty = p.H / 8;
+  p.rcp_ntx = 1.0f / (float)p.ntx;
+  ra.part = static_cast<double*>(workspace);
+  ra.col = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(workspace) + (((size_t)p.B * ra.nb * ROWS_PART_D * 8 + 255) & ~(size_t)255));
+  const size_t lds = (size_t)ra.bits_bytes + sizeof(Shared) + (size_t)p.ntx * ra.trows * 2 + 16;
+  allow_big_lds(reinterpret_cast<const void*>(fit_rows_kernel));
+  hipLaunchKernelGGL(fit_rows_kernel, dim3(p.B * ra.nb), dim3(NT), lds, s, p, ra);
+  const int rc = check_launch("fit_rows_kernel");
+  if (rc != LA3D_SUCCESS) return rc;
+  hipLaunchKernelGGL(merge_rows_kernel, dim3(p.B), dim3(NT), sizeof(Shared) + (size_t)2 * p.W * 4, s, p, ra);
+  return check_launch("merge_rows_kernel");
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -2397,13 +2700,16 @@ double la3d_f16_round_host(double x) { return f16_round(x); }
 //   instance engine: [B] u32 sort keys of the size-balanced launch order (4*B bytes)
 //   band engine:     [B] u32 sort keys | [B][4] i32 arrival counters | [B][88] f64 exchange records (band_workspace_bytes)
 //   split engine:    [B][GEO_D] f64 geometry, then bit images, tile lists and partial-sum slots (split_workspace_bytes)
+//   row engine:      [B][nb][10] f64 partial records | [B][nb][2 W] u32 per-column depth ranges (rows_workspace_bytes)
 size_t la3d_workspace_bytes(int B, int H, int W) {
   if (B <= 0) return 0;
   const size_t inst = (size_t)B * GEO_D * sizeof(double);  // kept as the minimum (older callers size by it)
   const size_t split = split_workspace_bytes(B, H, W);     // split engine: + bit image, tile lists, partial slots
   const size_t band = band_frame_ok(H, W, 2) ? band_workspace_bytes(B) : 0;   // band engine: keys, arrival counters, exchange records
-  const size_t m = split > inst ? split : inst;
-  return band > m ? band : m;
+  const size_t rows = rows_workspace_bytes(B, H, W);         // row engine: partial records and per-column ranges of every band
+  size_t m = split > inst ? split : inst;
+  if (band > m) m = band;
+  return rows > m ? rows : m;
 }
 
 struct PolyArgs { const int32_t* xy; const int64_t* ring_off; const int64_t* inst_rings; };
@@ -2485,10 +2791,18 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   // (profiles/r05/r05_small_batches.txt: B = 1 / 16 / 64 / 256, u8 planes: 27.7 / 32.1 / 36.8 / 45.1 us vs 31.7 / 34.8 / 37.9 / 59.8;
   // run lengths 31.2 / 35.6 / 36.4 / 40.0 vs 34.3 / 37.9 / 43.3 / 57.4).  A skewed K (not separable) still takes this route - the
   // kernel then runs its two passes -; a call WITH a ground array keeps the old choice below (two passes either way).
+  // Small batches of u8 planes (up to 192 instances by default) go one step further: the same single pass split over up to sixteen
+  // workgroups per instance, one per band of rows, and a short merge launch (row engine: B = 1 / 16 / 64 / 128 18.2 / 19.3 / 24.0 /
+  // 30.0 us per call, profiles/r05/r05_rows_engine.txt).
+  const int eng = p.opt_engine != LA3D_ENGINE_DEFAULT ? p.opt_engine : config().engine;
   const bool single_pass_call = ground == nullptr && !sample && !p.sep_off && ldsmask && vec && W % 32 == 0 && W / 32 <= 255 &&
                                 (H + 7) / 8 <= 255 && ((W / 32) * ((H + 7) / 8) + NWAVE - 1) / NWAVE <= 256 &&
-                                (p.opt_engine != LA3D_ENGINE_DEFAULT ? p.opt_engine : config().engine) == LA3D_ENGINE_DEFAULT &&
+                                (eng == LA3D_ENGINE_DEFAULT || eng == LA3D_ENGINE_ROWS) &&   // (rows pinned but not applicable: as by default)
                                 (p.opt_build != LA3D_BUILD_DEFAULT ? p.opt_build : config().retain) != LA3D_BUILD_RETAINING;
+  {
+    RowsArgs ra;
+    if (rows_eligible(p, vec, sample, &ra)) return launch_fit_rows(p, ra, s, workspace);
+  }
   if (!single_pass_call && band_eligible(p, vec, sample)) {   // u8 planes, 16 <= B <= 256 (or pinned): two / four workgroups per instance, ONE launch
     return band_count(p) == 4 ? launch_fit_bands<4>(p, s, workspace) : launch_fit_bands<2>(p, s, workspace);
   }
@@ -2671,7 +2985,7 @@ int la3d_fit_instances_ex(const la3d_fit_args* args) {
   const bool filter_on = a.filter_boundary >= 0 && a.filter_max_edge > 0;
   const FilterArgs fa{a.filter_boundary, a.filter_min_area, a.filter_max_edge, a.stats};
   const ProjArgs pr{a.proj, a.image_width, a.image_height};
-  if (a.opt_engine < 0 || a.opt_engine > LA3D_ENGINE_BAND || a.opt_launch_order < 0 || a.opt_launch_order > LA3D_ORDER_ON ||
+  if (a.opt_engine < 0 || a.opt_engine > LA3D_ENGINE_ROWS || a.opt_launch_order < 0 || a.opt_launch_order > LA3D_ORDER_ON ||
       a.opt_build < 0 || a.opt_build > LA3D_BUILD_RETAINING || a.opt_reserved != 0) {
     set_err("la3d_fit_instances_ex: bad opt_engine / opt_launch_order / opt_build (or opt_reserved != 0)");
     return LA3D_ERR_ARG;

@@ -37,6 +37,7 @@ struct Config {
   int bands;           // LA3D_BANDS=2|4 pins the workgroups per instance of the band engine (0: by batch size)
   int band_default;    // LA3D_BAND_DEFAULT=0: the band engine only when pinned
   int band_maxb;       // LA3D_BAND_MAXB: largest batch the band engine takes by default
+  int rows_maxb;       // LA3D_ROWS_MAXB: largest batch the row engine takes by default (u8 planes, no ground array)
   int balance;         // LA3D_BALANCE=0 -> launch order off by default
   int balance_rounds;  // LA3D_BALANCE_ROUNDS: batches up to this many resident sets are ordered (default 3)
   int retain;          // LA3D_RETAIN=0|1 -> LA3D_BUILD_PLAIN / LA3D_BUILD_RETAINING (0 = by batch size)

@@ -15,7 +15,7 @@ from labelany3d_amd._lib import FitArgs, check, lib
 
 dev = torch.device("cuda", 0)
 st = torch.cuda.current_stream()
-ENG = {"default": 0, "instance": 1, "split": 2, "band": 3}
+ENG = {"default": 0, "instance": 1, "split": 2, "band": 3, "rows": 4}
 
 
 def timed(fn, n=200):
@@ -69,8 +69,10 @@ for B in ([int(b) for b in sys.argv[1].split(',')] if len(sys.argv) > 1 else (1,
     for gname, g in (("no ground", None), ("ground", ground)):
         for fmt, kw in (("u8", dict(masks=masks)), ("rle", dict(rle=rle)), ("poly", dict(poly=poly))):
             cells = []
-            for eng in ("default", "instance", "split", "band"):
+            for eng in ("default", "instance", "split", "band", "rows"):
                 if eng == "band" and fmt != "u8":
+                    continue
+                if eng == "rows" and (fmt != "u8" or g is not None or B > 512):   # (the row engine: u8 planes without a ground array)
                     continue
                 a = block(f, depth, K, B, eng, ground=g, **kw)
                 t = timed(lambda: check(lib.la3d_fit_instances_ex(C.byref(a)), "fit"))

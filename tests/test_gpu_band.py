@@ -108,7 +108,7 @@ def test_band_engine_full_batch_is_deterministic_and_order_free(la, monkeypatch)
     ref, rst, _, _ = O.fit_instances(np_(depth[idx]), np_(masks[idx]).astype(bool), np.broadcast_to(K640, (24, 3, 3)))
     assert_records(np_(runs[0][0])[idx], ref, "band/config2", gap=np_(runs[0][2])[idx, 3])
     # the default dispatch takes the band engine for 16 <= B <= 256 u8 planes (four bands) when the call carries a ground array
-    # (round 5: a call without one takes the instance engine's single pass at every batch size): same records as the pinned call
+    # (round 5: a call without one takes the single pass - split by rows up to 192 instances, one workgroup per instance above): same records as the pinned call
     for Bs in (64, 256):
         fs = InstanceFitter(Bs, bench.H, bench.W, dev, slots=3)
         g = torch.as_tensor(np.array([[0.05, -0.97, 0.1, 1.2]] * Bs) + 0.02 * np.random.RandomState(Bs).randn(Bs, 4), device=dev)
@@ -118,8 +118,9 @@ def test_band_engine_full_batch_is_deterministic_and_order_free(la, monkeypatch)
         torch.cuda.synchronize()
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and not torch.equal(a[0], c[0])
         torch.testing.assert_close(a[0][:, :15], c[0][:, :15], rtol=1e-10, atol=1e-10)
-        u = fs.run(depth[:Bs], masks[:Bs], K, slot=0)                       # un-grounded: the default IS the instance engine
-        v = fs.run(depth[:Bs], masks[:Bs], K, slot=1, engine="instance")
+        # un-grounded: the default is the row engine up to 192 instances, the instance engine (single pass) above
+        u = fs.run(depth[:Bs], masks[:Bs], K, slot=0)
+        v = fs.run(depth[:Bs], masks[:Bs], K, slot=1, engine="rows" if Bs <= 192 else "instance")
         torch.cuda.synchronize()
         assert torch.equal(u[0], v[0]) and torch.equal(u[1], v[1])
 
