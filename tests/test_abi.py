@@ -23,6 +23,9 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib.la3d_workspace_bytes(1024, 480, 640) >= 1024 * 160  # >= per-instance geometry; + split-engine buffers
     assert _lib.lib.la3d_workspace_bytes(1024, 37, 53) == 1024 * 160  # frames the split engine does not take
     assert _lib.lib.la3d_workspace_bytes(0, 480, 640) == 0
+    # the row engine (round 5, at most 512 instances): sixteen bands of one instance leave 20 doubles and 2 W column words each
+    assert _lib.lib.la3d_workspace_bytes(1, 480, 640) >= 16 * (20 * 8 + 2 * 640 * 4)
+    assert _lib.lib.la3d_workspace_bytes(64, 480, 640) >= 64 * 8 * (20 * 8 + 2 * 640 * 4)
 
 
 def test_so_is_in_tree_and_gfx950():
@@ -331,6 +334,7 @@ def test_scheduling_options_are_thread_local_and_validated():
 
     assert options.codes() == (0, 0, 0)
     assert options.codes(engine="band", launch_order=False, build="retaining") == (3, 1, 2)
+    assert options.codes(engine="rows") == (4, 0, 0)
     seen = {}
 
     def other():
