@@ -492,8 +492,12 @@ def _fit_annotations_host(annotations, groups, W_img, H_img, depth, K, ground, i
             if ii.size and (ii.min() < 0 or ii.max() >= P):
                 raise ValueError("image_index out of range")
             a.image_index = ii.ctypes.data; keep.append(ii)
-        elif P > 1 and P != B:
-            raise ValueError("several depth planes need image_index")
+        elif P > 1:
+            # one plane per ANNOTATION (crowd / unsegmented ones included): this kind's instances pick theirs by annotation index
+            if P != len(annotations):
+                raise ValueError("several depth planes need image_index (or one plane per annotation)")
+            ii = sel.astype(np.int32)
+            a.image_index = ii.ctypes.data; keep.append(ii)
         a.K, a.k_stride = Kh.ctypes.data, (9 if Kh.shape[0] > 1 else 0)
         if ground is not None:
             g = np.ascontiguousarray(np.asarray(ground, dtype=np.float64).reshape(-1, 4)[sel])

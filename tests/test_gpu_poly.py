@@ -419,6 +419,13 @@ def test_fit_annotations_host_entry_equals_the_device_route(la):
         np.testing.assert_array_equal(got[4], want[4])
         np.testing.assert_array_equal(got[3], want[3])
         assert isinstance(got[3], np.ndarray) and got[3].dtype == np.float64 and got[4].dtype == np.int32
+    # one depth plane per annotation, no image_index: every kind's instances pick their own plane
+    dn = rs.uniform(0.5, 10, (len(anns), H, W)).astype(np.float32)
+    g3 = la.fit_annotations(anns, (W, H), torch.as_tensor(dn, device="cuda"), K, to_host=True)
+    w3 = la.fit_annotations(anns, (W, H), dn, K, to_host=True, image_index=np.arange(len(anns), dtype=np.int32))
+    np.testing.assert_array_equal(g3[1], w3[1]); np.testing.assert_array_equal(g3[3], w3[3])
+    with pytest.raises(ValueError, match="image_index"):
+        la.fit_annotations(anns, (W, H), depth_d[:2], K, to_host=True)
     # other thresholds travel
     w2 = la.fit_annotations(anns, (W, H), depth[0], K, to_host=True, boundary_threshold=30, scale_threshold=2000)
     g2 = la.fit_annotations(anns, (W, H), depth_d[0], K, to_host=True, boundary_threshold=30, scale_threshold=2000)
