@@ -251,7 +251,7 @@ def test_self_estimating_launch_alternating_batches(la, monkeypatch, B):
     assert int(f.workspace[0][off:off + 8].view(torch.int64)[0]) == 0
 
 
-@pytest.mark.parametrize("engine,B", [("instance", 1024), ("band", 64)])
+@pytest.mark.parametrize("engine,B", [("instance", 1024), ("band", 64), ("rows", 24)])
 def test_graph_replay_with_new_masks_in_the_same_buffers(la, monkeypatch, engine, B):
     """An ordered call captured into a HIP graph and replayed over NEW masks in the same buffers: the captured call must not carry the
     self-estimating launch's per-call nonce (a replay would find the previous replay's records complete): it keeps the helper kernel.
@@ -260,7 +260,8 @@ def test_graph_replay_with_new_masks_in_the_same_buffers(la, monkeypatch, engine
 
     from labelany3d_amd import InstanceFitter
 
-    # (the band engine's arrival words carry a per-call tag too: a captured call clears them with a memset node instead)
+    # (the band engine's arrival words carry a per-call tag too: a captured call clears them with a memset node instead; the row
+    # engine's two launches carry nothing per call)
     monkeypatch.setattr(SCHED(), "engine", engine)
     dev = torch.device("cuda", 0)
     H, W = 96, 128
