@@ -4,7 +4,6 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import labelany3d_amd as la
-from oracle import la3d_oracle as O
 
 dev = torch.device("cuda", 0)
 H, W = 480, 640
