@@ -125,3 +125,25 @@ def test_row_engine_shared_planes_2d_boxes_and_default_dispatch(la, monkeypatch)
     torch.cuda.synchronize()
     np.testing.assert_array_equal(np_(f1.boxes[0]), rows[0])
     np.testing.assert_array_equal(np_(f2.boxes[0]), rows[0])
+
+
+def test_row_engine_odd_band_splits(la, monkeypatch):
+    """Frames whose tile rows do not divide evenly among the bands (a shorter last band, bands of two tile rows, one tile column):
+    the row engine against the instance engine (to rounding) on every shape, against the oracle on the first instances of each."""
+    rs = np.random.RandomState(77)
+    for ty, tx, B in ((3, 1, 5), (5, 2, 9), (7, 3, 33), (9, 5, 3), (11, 8, 2), (13, 2, 70), (17, 1, 12), (23, 3, 4), (31, 2, 1), (60, 20, 2)):
+        H, W = ty * 8, tx * 32
+        depth = rs.uniform(0.5, 10, (B, H, W)).astype(np.float32)
+        masks = rs.rand(B, H, W) < rs.uniform(0.02, 0.9, (B, 1, 1))
+        for i in range(0, B, 3):                                   # every third: a rectangle that may straddle the band boundaries
+            h, w = rs.randint(1, H + 1), rs.randint(1, W + 1)
+            r0, c0 = rs.randint(0, H - h + 1), rs.randint(0, W - w + 1)
+            masks[i] = False; masks[i, r0:r0 + h, c0:c0 + w] = True
+        K = np.array([[0.9 * W, 0, 0.5 * W + 1.5], [0, 0.8 * W, 0.45 * H], [0, 0, 1]])
+        rows, inst = _engines(la, monkeypatch, depth, masks, K)
+        _close(rows, inst, f"{H}x{W} B={B}")
+        n = min(B, 6)
+        ref, rst, _, nval = O.fit_instances(depth[:n], masks[:n], np.broadcast_to(K, (n, 3, 3)))
+        assert rows[1][:n].tolist() == list(rst)
+        ok = (rows[1][:n] == 0) & (rows[2][:n, 3] > 1e-6)
+        assert_records(rows[0][:n][ok], ref[ok], f"row engine {H}x{W}", gap=rows[2][:n][ok, 3])
