@@ -224,7 +224,13 @@ typedef struct la3d_fit_args {
   int32_t opt_engine;         /* LA3D_ENGINE_* */
   int32_t opt_launch_order;   /* LA3D_ORDER_* */
   int32_t opt_build;          /* LA3D_BUILD_* */
-  int32_t opt_reserved;       /* must be 0 */
+  int32_t frame_width;        /* round 5 (this field was `opt_reserved, must be 0`): 0 = W.  0 < frame_width < W: the planes are W pixels wide
+                                 IN MEMORY, but only the first frame_width columns are image - rows padded on the right, e.g. to a
+                                 multiple of 32, which is what the tiled / single-pass forms need (a 640 x 427 frame runs 4-5 x
+                                 faster as H = 640, W = 448, frame_width = 427).  Run-length / polygon masks only: polygon sides are
+                                 clipped to frame_width (cv2.fillPoly on the unpadded frame), run lengths are column-major and need
+                                 nothing, the fused filter takes its right border from frame_width; K and the pixel coordinates are
+                                 those of the unpadded frame.  With u8 planes the caller pads the planes with zeros and leaves 0. */
 } la3d_fit_args;
 int la3d_fit_instances_ex(const la3d_fit_args* args);
 

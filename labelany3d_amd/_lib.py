@@ -28,7 +28,7 @@ class FitArgs(C.Structure):
                 ("out", C.c_void_p), ("status", C.c_void_p), ("aux", C.c_void_p),
                 ("workspace", C.c_void_p), ("stream", C.c_void_p),
                 ("area_hint", C.c_void_p),
-                ("opt_engine", C.c_int32), ("opt_launch_order", C.c_int32), ("opt_build", C.c_int32), ("opt_reserved", C.c_int32)]
+                ("opt_engine", C.c_int32), ("opt_launch_order", C.c_int32), ("opt_build", C.c_int32), ("frame_width", C.c_int32)]
 
 
 _SIGS = {

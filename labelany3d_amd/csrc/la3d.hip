@@ -540,11 +540,19 @@ __device__ inline void sweep_sep(const FitParams& p, const float* __restrict__ d
         const uint4 w = *reinterpret_cast<const uint4*>(bits + e * 8 + h4);
         const unsigned nib = ((w.x >> c) & 1u) | (((w.y >> c) & 1u) << 1) | (((w.z >> c) & 1u) << 2) | (((w.w >> c) & 1u) << 3);
         pk |= nib << (4 * g);
-        if (nib) {
-          // uniform tile origin in scalar registers + the lane's constant byte offsets
-          const unsigned char* tp = reinterpret_cast<const unsigned char*>(dpl + ((long long)((t >> 8) * 8u) * p.W + (t & 0xffu) * 32u));
+        // uniform tile origin in scalar registers + the lane's constant byte offsets
+        const unsigned char* tp = reinterpret_cast<const unsigned char*>(dpl + ((long long)((t >> 8) * 8u) * p.W + (t & 0xffu) * 32u));
+        if ((t >> 8) * 8u + 8u <= (unsigned)p.H) {   // uniform: every row of the tile lies inside the frame
+          if (nib) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) dq[g][k] = *reinterpret_cast<const unsigned*>(tp + loff[k]);
+            for (int k = 0; k < 4; ++k) dq[g][k] = *reinterpret_cast<const unsigned*>(tp + loff[k]);
+          }
+        } else {
+          // the last tile row of a frame whose height is not a multiple of 8: a lane loads only the rows it holds a mask bit for
+          // (rows past the frame carry none) - the block load above would read up to seven rows past the end of the depth plane
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if ((nib >> k) & 1u) dq[g][k] = *reinterpret_cast<const unsigned*>(tp + loff[k]);
         }
       }
     }
@@ -1249,13 +1257,13 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : NT / 64) void fit_instance
     const long long o0 = p.rle_offsets[inst];
     // (the block totals of the column scan borrow the LDS of the tile list, which is built afterwards)
     nmask = rle_to_bits<NT>(p.rle_counts + o0, (int)(p.rle_offsets[inst + 1] - o0), bits, p.nwords, p.H, p.W, sh->scan, tid,
-                            reinterpret_cast<unsigned*>(smem + p.mask_lds_bytes + sizeof(Shared)), TILED ? p.list_cap / 2 : 0);
+                            reinterpret_cast<unsigned*>(smem + p.mask_lds_bytes + sizeof(Shared)), TILED ? p.list_cap / 2 : 0, p.frame_w);
   } else if (LDSMASK && SRC == 2) {
     // masks arrive as polygon parts (the reference's create_boolean_mask_from_polygon, src/util.py:386-400): rasterised with
     // cv2.fillPoly's rule straight into the LDS bit image; the side stage borrows the space of the tile list
     nmask = poly_to_bits<NT>(p.poly_xy, p.poly_ring_off, p.poly_inst_rings[inst], p.poly_inst_rings[inst + 1],
                              reinterpret_cast<PolySide*>(smem + p.mask_lds_bytes + sizeof(Shared)), sh->scan, bits, p.nwords, p.H,
-                             p.W, tid);
+                             p.W, tid, p.frame_w);
   } else if (LDSMASK) {
     unsigned short* b16 = reinterpret_cast<unsigned short*>(bits);
     const int ngroups = (HW + 15) >> 4;
@@ -1319,7 +1327,7 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : NT / 64) void fit_instance
   if (SRC != 0 && LDSMASK && p.filter_boundary >= 0) {   // uniform
     // the reference's instance filter (src/util.py:375) on the bit image just built: a dropped instance costs no passes
     int st4[4];
-    bits_filter_stats<NT>(bits, p.H, p.W, p.filter_boundary, reinterpret_cast<int*>(sh->part), tid, st4);
+    bits_filter_stats<NT>(bits, p.H, p.frame_w, p.filter_boundary, reinterpret_cast<int*>(sh->part), tid, st4, p.W);   // (frame_w == W unless the rows are padded)
     if (p.filter_stats && tid < 4) (p.filter_stats + (long long)inst_p * 4)[tid] = st4[tid];   // (uniform base: scalar address arithmetic)
     const int height = SRC == 1 ? st4[1] : st4[2];   // run lengths: rows holding a pixel (:368-369); polygons: last - first + 1 (:328-335)
     const bool keep = 16 * height > p.H && st4[3] < p.filter_max_edge && st4[0] >= p.filter_min_area;   // height / H > 0.0625
@@ -2715,7 +2723,7 @@ size_t la3d_workspace_bytes(int B, int H, int W) {
 struct PolyArgs { const int32_t* xy; const int64_t* ring_off; const int64_t* inst_rings; };
 struct FilterArgs { int boundary, min_area, max_edge; int32_t* stats; };
 struct ProjArgs { double* out; double width, height; };
-struct CallOpts { int engine, order, build; };
+struct CallOpts { int engine, order, build, frame_w; };
 
 static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const int32_t* image_index, const uint8_t* mask,
                         const int32_t* rle_counts, const int64_t* rle_offsets, const double* K, int32_t k_stride,
@@ -2762,6 +2770,15 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   p.proj = proj ? proj->out : nullptr; p.proj_w = proj ? proj->width : 0; p.proj_h = proj ? proj->height : 0;
   p.area_hint = area_hint;
   p.opt_engine = opts ? opts->engine : 0; p.opt_order = opts ? opts->order : 0; p.opt_build = opts ? opts->build : 0;
+  p.frame_w = W;
+  if (opts && opts->frame_w != 0 && opts->frame_w != W) {
+    // rows padded on the right (la3d_fit_args::frame_width): run-length / polygon masks, word-aligned rows
+    if (opts->frame_w < 0 || opts->frame_w > W || mask != nullptr || W % 32 != 0) {
+      snprintf(g_err, sizeof(g_err), "%s: frame_width must be 0 or in (0, W], with run-length / polygon masks and W %% 32 == 0", who);
+      return LA3D_ERR_ARG;
+    }
+    p.frame_w = opts->frame_w;
+  }
   if (filter) {
     if (!rle || filter->boundary < 0) {
       snprintf(g_err, sizeof(g_err), "%s: the fused filter needs run-length or polygon masks and boundary >= 0", who);
@@ -2806,7 +2823,7 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   if (!single_pass_call && band_eligible(p, vec, sample)) {   // u8 planes, 16 <= B <= 256 (or pinned): two / four workgroups per instance, ONE launch
     return band_count(p) == 4 ? launch_fit_bands<4>(p, s, workspace) : launch_fit_bands<2>(p, s, workspace);
   }
-  if (!single_pass_call && !sample && split_eligible(p, vec, ldsmask)) {
+  if (!single_pass_call && !sample && p.frame_w == W && split_eligible(p, vec, ldsmask)) {   // (the split engine's decoders know no padded rows)
     const int rc = split_fit(p, workspace, s);   // (the split engine's final kernel does not project: one small follow-up launch)
     if (rc != LA3D_SUCCESS || !p.proj) return rc;
     return la3d_project_boxes(out, K, k_stride, image_index, B, p.proj_w, p.proj_h, p.proj, stream);   // (la3d_aux.hip)
@@ -2986,11 +3003,11 @@ int la3d_fit_instances_ex(const la3d_fit_args* args) {
   const FilterArgs fa{a.filter_boundary, a.filter_min_area, a.filter_max_edge, a.stats};
   const ProjArgs pr{a.proj, a.image_width, a.image_height};
   if (a.opt_engine < 0 || a.opt_engine > LA3D_ENGINE_ROWS || a.opt_launch_order < 0 || a.opt_launch_order > LA3D_ORDER_ON ||
-      a.opt_build < 0 || a.opt_build > LA3D_BUILD_RETAINING || a.opt_reserved != 0) {
-    set_err("la3d_fit_instances_ex: bad opt_engine / opt_launch_order / opt_build (or opt_reserved != 0)");
+      a.opt_build < 0 || a.opt_build > LA3D_BUILD_RETAINING) {
+    set_err("la3d_fit_instances_ex: bad opt_engine / opt_launch_order / opt_build");
     return LA3D_ERR_ARG;
   }
-  const CallOpts co{a.opt_engine, a.opt_launch_order, a.opt_build};
+  const CallOpts co{a.opt_engine, a.opt_launch_order, a.opt_build, a.frame_width};
   return fit_dispatch(a.depth, a.depth_plane_stride, a.image_index, a.mask, a.rle_counts, a.rle_offsets, a.K, a.k_stride, a.ground,
                       a.sample_idx, a.B, a.H, a.W, a.out, a.status, a.aux, a.workspace, a.stream, "la3d_fit_instances_ex",
                       a.poly_xy ? &pa : nullptr, filter_on ? &fa : nullptr, a.proj ? &pr : nullptr, a.area_hint, &co);

@@ -381,14 +381,15 @@ __device__ inline int wave_max_i(int v) {
 // last - first + 1, pixels inside the `boundary`-px border strips (a pixel in a corner counts twice, as the reference's
 // four slice sums do).  red: LDS, 5 * NTH/64 ints.  The result is valid in every thread; ends with a barrier.
 template <int NTH>
-__device__ inline void bits_filter_stats(const unsigned* bits, int H, int W, int boundary, int* red, int tid, int* out4) {
+__device__ inline void bits_filter_stats(const unsigned* bits, int H, int W, int boundary, int* red, int tid, int* out4, int row_bits = 0) {
+  // (row_bits: bits per row of the image in memory when the rows are padded - la3d_fit_args::frame_width -, 0 = W)
   const int lane = tid & 63, wave = tid >> 6;
   constexpr int NW = NTH / 64;
   const int bc = min(boundary, W), br = min(boundary, H);
   int area = 0, edge = 0, rows = 0, first = H, last = -1;
   for (int r = tid; r < H; r += NTH) {
     int cnt = 0, e = 0;
-    const unsigned base = (unsigned)r * (unsigned)W;
+    const unsigned base = (unsigned)r * (unsigned)(row_bits > 0 ? row_bits : W);
     for (int c0 = 0; c0 < W; c0 += 32) {       // 32 columns at a time (unaligned rows: the word is assembled from two)
       const unsigned i = base + c0, wi = i >> 5, sh = i & 31;
       unsigned w = bits[wi] >> sh;
@@ -522,6 +523,7 @@ struct FitParams {
   double* out;
   int* status;
   double* aux;
+  int frame_w;         // la3d_fit_args::frame_width (run-length / polygon input): image columns of the W-wide planes; == W when not given
 };
 
 // per-instance geometry in the workspace (20 doubles = 160 B), written by the split engine's plan_kernel (geo_one)
@@ -691,10 +693,12 @@ __device__ inline void column_xor_scan(unsigned* bits, int H, int ntx, unsigned*
 // the runs are painted directly instead (the slower route, also taken when W % 32 != 0).
 template <int NTH>
 __device__ inline int rle_to_bits(const int* __restrict__ counts, int nr, unsigned* bits, int nwords, int H, int W,
-                                  unsigned* wtot, int tid, unsigned* scratch = nullptr, int scratch_words = 0) {
+                                  unsigned* wtot, int tid, unsigned* scratch = nullptr, int scratch_words = 0, int frame_w = 0) {
+  // (frame_w: la3d_fit_args::frame_width - the image is frame_w columns wide, its rows are stored W bits apart; the runs are
+  // column-major, so the image ends at pixel H * frame_w of their order and nothing else changes)
   const int lane = tid & 63, wave = tid >> 6;
   constexpr int NW = NTH / 64;
-  const int HW = H * W;
+  const int HW = H * (frame_w > 0 && frame_w < W ? frame_w : W);
   const float rcpH = 1.0f / (float)H;
   for (int i = tid; i < nwords; i += NTH) bits[i] = 0;
   unsigned carry = 0;

@@ -177,7 +177,7 @@ __device__ inline void poly_fill_span(unsigned* bits, int W, int y, int x1, int 
 // ranges, each with even parity, so the parity fill of all crossings together is the union of the parts' fills.
 template <int NTH>
 __device__ __forceinline__ void poly_ring_fast(const int* __restrict__ xy, long long p0, int n, const int* rb, int nrb, PolySide* stage,
-                                      int* box, unsigned* bits, int H, int W, int tid) {
+                                      int* box, unsigned* bits, int H, int W, int tid, int clipW) {
   const int lane = tid & 63, wave = tid >> 6;
   constexpr int NW = NTH / 64;
   const int ntxw = W >> 5;
@@ -193,7 +193,7 @@ __device__ __forceinline__ void poly_ring_fast(const int* __restrict__ xy, long 
           for (int j = 0; j < nrb; ++j)
             if (i >= rb[j] && i < rb[j + 1]) { lo = rb[j]; hi = rb[j + 1]; }
           const int ip = (i == lo) ? hi - 1 : i - 1;
-          const PolySide sd = poly_side(xy[2 * (p0 + ip)], xy[2 * (p0 + ip) + 1], xy[2 * (p0 + i)], xy[2 * (p0 + i) + 1], W, H);
+          const PolySide sd = poly_side(xy[2 * (p0 + ip)], xy[2 * (p0 + ip) + 1], xy[2 * (p0 + i)], xy[2 * (p0 + i) + 1], clipW, H);
           stage[tid] = sd;
           if (pass == 0 && sd.e.y0 < sd.e.y1) {                   // bounding rows / words of the toggles of this side
             const int ya = max(sd.e.y0, 0), yb = min(sd.e.y1, H);
@@ -252,7 +252,7 @@ __device__ __forceinline__ void poly_ring_fast(const int* __restrict__ xy, long 
 // takes further sweeps over the ring until all are consumed.
 template <int NTH>
 __device__ __forceinline__ void poly_ring_general(const int* __restrict__ xy, long long p0, int n, PolySide* stage, unsigned* flags,
-                                         unsigned* bits, int H, int W, int tid) {
+                                         unsigned* bits, int H, int W, int tid, int clipW) {
   const int lane = tid & 63, wave = tid >> 6;
   constexpr int NW = NTH / 64;
   constexpr long long XINF = 0x7fffffffffffffffLL;
@@ -273,7 +273,7 @@ __device__ __forceinline__ void poly_ring_general(const int* __restrict__ xy, lo
         __syncthreads();                                          // the stage is free (and the zeroed image is published)
         if (tid < m) {
           const int i = c0 + tid, ip = (i == 0) ? n - 1 : i - 1;
-          stage[tid] = poly_side(xy[2 * (p0 + ip)], xy[2 * (p0 + ip) + 1], xy[2 * (p0 + i)], xy[2 * (p0 + i) + 1], W, H);
+          stage[tid] = poly_side(xy[2 * (p0 + ip)], xy[2 * (p0 + ip) + 1], xy[2 * (p0 + i)], xy[2 * (p0 + i) + 1], clipW, H);
         }
         __syncthreads();
         if (first)
@@ -336,7 +336,12 @@ __device__ inline long long poly_uniform(long long v) {
 
 template <int NTH>
 __device__ __forceinline__ int poly_to_bits(const int* __restrict__ xy, const long long* __restrict__ ring_off, long long r0, long long r1,
-                                   PolySide* stage, unsigned* flags, unsigned* bits, int nwords, int H, int W, int tid) {
+                                   PolySide* stage, unsigned* flags, unsigned* bits, int nwords, int H, int W, int tid, int clipW = 0) {
+  // clipW (la3d_fit_args::frame_width): 0 < clipW < W, W % 32 == 0 - the image is clipW columns wide, its rows are stored W bits
+  // apart.  The polygon sides are clipped to the IMAGE (clipLine changes the geometry of a side that leaves the frame); everything
+  // else works on the padded rows - a span or a parity run may reach into the columns [clipW, W) - and those columns are cleared
+  // before the count.
+  if (clipW <= 0 || clipW > W) clipW = W;
   r0 = poly_uniform(r0); r1 = poly_uniform(r1);
   for (int i = tid; i < nwords; i += NTH) bits[i] = 0;
   int* meta = reinterpret_cast<int*>(stage + POLY_CHUNK);   // [0..8] part bounds, [9 + 4 j ..] bounding box of part j, [41] verdict
@@ -385,15 +390,25 @@ __device__ __forceinline__ int poly_to_bits(const int* __restrict__ xy, const lo
     // (cost of the fast form: independent of the number of crossings, no per-scanline state: measured on 1024 instances of
     // 640x480 with 60 / 120-vertex non-convex parts 142 / 273 us -> 95 / 119 us per launch; convex parts of 4..31 vertices 3-6 us
     // slower than the general form)
-    poly_ring_fast<NTH>(xy, p0, n, meta, joint, stage, reinterpret_cast<int*>(flags), bits, H, W, tid);
+    poly_ring_fast<NTH>(xy, p0, n, meta, joint, stage, reinterpret_cast<int*>(flags), bits, H, W, tid, clipW);
     r = r0 + joint;
   }
   for (; r < r1; ++r) {   // whatever is left is OR-ed in by the general form
     const long long p0 = poly_uniform(ring_off[r]);
     const int n = __builtin_amdgcn_readfirstlane((int)(ring_off[r + 1] - p0));
-    poly_ring_general<NTH>(xy, p0, n, stage, flags, bits, H, W, tid);
+    poly_ring_general<NTH>(xy, p0, n, stage, flags, bits, H, W, tid, clipW);
   }
   __syncthreads();
+  if (clipW < W) {   // uniform: clear the padding columns of every row (word-aligned rows)
+    const int ntxw = W >> 5, wq = clipW >> 5, per = ntxw - wq;
+    const unsigned keep = (1u << (clipW & 31)) - 1u;   // bits of word wq that belong to the image (0: none)
+    for (int i = tid; i < H * per; i += NTH) {
+      const int row = i / per, k = i - row * per;
+      unsigned* w = bits + row * ntxw + wq + k;
+      *w = k == 0 ? (*w & keep) : 0u;
+    }
+    __syncthreads();
+  }
   int nm = 0;
   for (int i = tid; i < nwords; i += NTH) nm += __popc(bits[i]);
   return nm;

@@ -224,15 +224,35 @@ def filter_annotations(annotations, image_size, boundary_threshold: int = 10, sc
             [annotations[i]["category_id"] for i in kept])
 
 
+def padded_width(W: int) -> int:
+    """The row length the tiled / single-pass forms of the fit want: the next multiple of 32."""
+    return (int(W) + 31) // 32 * 32
+
+
+def pad_depth_rows(depth, device=None):
+    """Depth plane(s) (..., H, W) -> ((..., H, padded_width(W)) float32 on the device, W): rows padded on the right with zeros.
+    COCO frames come in widths like 427, 500, 375, 333; with run-length / polygon masks such a frame is fitted as a frame of the
+    padded width whose first W columns are image (C-ABI ``la3d_fit_args::frame_width``): 4-5 x faster than the row-linear form
+    that odd widths otherwise take (profiles/r05/r05_frame_sizes.txt).  ``fit_instances_ex`` / ``fit_instances_rle`` /
+    ``fit_instances_poly`` / ``fit_annotations*`` do this themselves; a caller that fits the same planes many times pads once and
+    passes ``frame_width=W``."""
+    d = _as_dev(depth, torch.float32, _dev(device))
+    W = int(d.shape[-1])
+    Wp = padded_width(W)
+    return (d if Wp == W else torch.nn.functional.pad(d, (0, Wp - W))), W
+
+
 def fit_instances_ex(depth, K, masks=None, rles=None, polys=None, ground=None, sample_idx=None, image_index=None, filter=None,
-                     image_size=None, area_hint=None, stream=None, device=None, _fitter=None, _stats=None):
+                     image_size=None, area_hint=None, stream=None, device=None, frame_width=None, _fitter=None, _stats=None):
     """Every option of the fit in one call (C-ABI ``la3d_fit_instances_ex``): exactly one of ``masks`` (B,H,W) u8 / bool,
     ``rles`` (COCO RLE list or ``pack_rle`` tuple), ``polys`` (``pack_polygons`` tuple) gives the masks; ``filter`` as in
     ``fit_instances_poly`` (run-length / polygon masks only); ``image_size=(width, height)`` adds the 2-D boxes the reference's
     Omni3D writer derives from every record - ``bbox2D_proj | bbox2D_trunc`` (B,8), src/tools/combine_results.py:105-108, :238-252 -
     written by the same kernel epilogue that writes the record.  ``area_hint`` (B,) int: mask areas the caller already knows (the
     annotation's ``area``, a preceding filter's statistics) - the size-balanced launch order then skips its estimate pass over the
-    masks; a hint only orders the work.  Returns a dict: boxes, status, aux, and stats / boxes2d when asked."""
+    masks; a hint only orders the work.  ``frame_width`` (run-length / polygon masks): None - a frame whose width is not a multiple
+    of 32 has its depth rows padded here (``pad_depth_rows``); an int - ``depth`` already IS padded (its last dimension is the padded
+    width) and the masks' frame is ``frame_width`` columns wide.  Returns a dict: boxes, status, aux, and stats / boxes2d when asked."""
     import ctypes as C
 
     from ._lib import FitArgs
@@ -267,6 +287,21 @@ def fit_instances_ex(depth, K, masks=None, rles=None, polys=None, ground=None, s
         what = "polygon"
     if filter and masks is not None:
         raise ValueError("the fused filter needs run-length or polygon masks")
+    fw = 0
+    if masks is None:
+        if frame_width is None:
+            if W % 32 != 0:
+                with torch.cuda.device(dev):
+                    depth, fw = pad_depth_rows(depth, dev)
+                W = padded_width(W)
+        else:
+            if int(frame_width) != W:
+                raise ValueError(f"frame_width {frame_width} does not match the {what} frame width {W}")
+            Wd = int(depth.shape[-1])
+            if Wd != W:
+                if Wd < W or Wd % 32 != 0:
+                    raise ValueError("padded depth rows must be a multiple of 32 wide and at least frame_width")
+                fw, W = W, Wd
     d, k, P, ii, g, si = _fit_common(depth, K, H, W, B, ground, sample_idx, image_index, dev, what)
     out = {}
     with torch.cuda.device(dev):
@@ -299,6 +334,7 @@ def fit_instances_ex(depth, K, masks=None, rles=None, polys=None, ground=None, s
         a.out, a.status, a.aux = _ptr(f.boxes[0]), _ptr(f.status[0]), _ptr(f.aux[0])
         a.workspace, a.stream = _ptr(f.workspace[0]), _stream(stream)
         a.opt_engine, a.opt_launch_order, a.opt_build = options.codes()
+        a.frame_width = fw
         check(lib.la3d_fit_instances_ex(C.byref(a)), "la3d_fit_instances_ex")
     _record(stream, d, k, ii, g, si, *keep, f.workspace, *out.values())
     return out
@@ -347,6 +383,10 @@ def fit_annotations(annotations, image_size, depth, K, ground=None, boundary_thr
     if (to_host and isinstance(depth, torch.Tensor) and depth.is_cuda and depth.dtype == torch.float32 and depth.is_contiguous()
             and not isinstance(K, torch.Tensor) and not isinstance(ground, torch.Tensor) and not isinstance(image_index, torch.Tensor)):
         return _fit_annotations_host(annotations, groups, W_img, H_img, depth, K, ground, image_index, flt)
+    Wp = padded_width(W_img)
+    if Wp != W_img and any(idx for idx, _ in groups.values()):   # a frame of odd width: rows padded once for both segmentation kinds
+        with torch.cuda.device(dev):
+            depth, _ = pad_depth_rows(depth, dev)
     sels, box_all, st_all, pins = [], [], [], []
     for kind, (idx, segs) in groups.items():
         if not idx:
@@ -375,9 +415,9 @@ def fit_annotations(annotations, image_size, depth, K, ground=None, boundary_thr
         g_d = up[-4] if up[-4] is not None else g
         ii_d = up[-3] if up[-3] is not None else ii
         K_d = up[-1] if up[-1] is not None else K
-        fitter, stats_buf, pin = _ann_buffers(len(idx), Hh, Ww, dev, kind)
+        fitter, stats_buf, pin = _ann_buffers(len(idx), Hh, padded_width(Ww), dev, kind)
         res = fit_instances_ex(depth, K_d, ground=g_d, image_index=ii_d, device=dev, filter=flt, area_hint=up[-2], _fitter=fitter,
-                               _stats=stats_buf, **kw)
+                               _stats=stats_buf, frame_width=Ww, **kw)
         head = fitter._arena[:pin.numel()]
         pin.copy_(head, non_blocking=True)      # records | aux | status of this group: one copy, read after the one synchronisation
         sels.append(sel); box_all.append(res["boxes"]); st_all.append(res["status"]); pins.append((pin, len(idx)))
@@ -463,6 +503,9 @@ def _fit_annotations_host(annotations, groups, W_img, H_img, depth, K, ground, i
     from ._lib import FitArgs
 
     P = depth.shape[0] if depth.dim() == 3 else 1
+    Wp = padded_width(W_img)
+    if Wp != W_img:   # a frame of odd width: rows padded to the next multiple of 32, frame_width says where the image ends
+        depth = torch.nn.functional.pad(depth, (0, Wp - W_img))
     Kh = np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(-1, 9))
     if Kh.shape[0] not in (1, P):
         raise ValueError("K must be (3,3) or (P,3,3)")
@@ -483,10 +526,11 @@ def _fit_annotations_host(annotations, groups, W_img, H_img, depth, K, ground, i
             xy, ro, ir, Hh, Ww = pack_polygons(segs, H_img, W_img)
             a.poly_xy, a.ring_offsets, a.inst_rings = xy.ctypes.data, ro.ctypes.data, ir.ctypes.data
             keep += [xy, ro, ir]
-        if depth.shape[-2:] != (Hh, Ww):
-            raise ValueError(f"depth {tuple(depth.shape[-2:])} does not match the mask size {(Hh, Ww)}")
-        a.B, a.H, a.W = B, Hh, Ww
-        a.depth, a.depth_plane_stride = depth.data_ptr(), (Hh * Ww if P > 1 else 0)
+        if (Hh, Ww) != (H_img, W_img) or depth.shape[-2:] != (Hh, Wp):
+            raise ValueError(f"depth {tuple(depth.shape[-2:])} / image size {(H_img, W_img)} do not match the mask size {(Hh, Ww)}")
+        a.B, a.H, a.W = B, Hh, Wp
+        a.frame_width = Ww if Wp != Ww else 0
+        a.depth, a.depth_plane_stride = depth.data_ptr(), (Hh * Wp if P > 1 else 0)
         if image_index is not None:
             ii = np.ascontiguousarray(np.asarray(image_index)[sel], np.int32)
             if ii.size and (ii.min() < 0 or ii.max() >= P):
@@ -594,6 +638,10 @@ def fit_instances_poly(depth, polys, K, ground=None, sample_idx=None, image_inde
     passes; a fourth return value holds the (B,4) statistics (area, rows, span, edge pixels) as ``mask_stats_poly`` gives them."""
     dev = _dev(device)
     pxy, pro, pir, H, W = polys
+    if W % 32 != 0:   # a frame of odd width: depth rows padded to the next multiple of 32 (fit_instances_ex: la3d_fit_args::frame_width)
+        r = fit_instances_ex(depth, K, polys=polys, ground=ground, sample_idx=sample_idx, image_index=image_index, filter=filter,
+                             stream=stream, device=dev)
+        return (r["boxes"], r["status"], r["aux"]) + ((r["stats"],) if filter else ())
     pxy, pro, pir, ground, image_index, sample_idx = _bulk(dev, (pxy, torch.int32), (pro, torch.int64), (pir, torch.int64), (ground, torch.float64),
                                                            (image_index, torch.int32), (sample_idx, torch.int32))
     xy, ro, ir, H, W = _poly_dev((pxy, pro, pir, H, W), dev)
@@ -651,6 +699,10 @@ def fit_instances_rle(depth, rles, K, ground=None, sample_idx=None, image_index=
     holding a pixel, src/util.py:368-369)."""
     counts, offsets, H, W = pack_rle(rles)
     dev = _dev(device)
+    if W % 32 != 0:   # (as in fit_instances_poly)
+        r = fit_instances_ex(depth, K, rles=(counts, offsets, H, W), ground=ground, sample_idx=sample_idx, image_index=image_index,
+                             filter=filter, stream=stream, device=dev)
+        return (r["boxes"], r["status"], r["aux"]) + ((r["stats"],) if filter else ())
     counts, offsets, ground, image_index, sample_idx = _bulk(dev, (counts, torch.int32), (offsets, torch.int64), (ground, torch.float64),
                                                              (image_index, torch.int32), (sample_idx, torch.int32))
     c, o = _as_dev(counts, torch.int32, dev), _as_dev(offsets, torch.int64, dev)

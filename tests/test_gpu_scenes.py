@@ -163,3 +163,58 @@ def test_category_names_follow_the_reference_table_unless_asked(tmp_path):
             seen_ref.add(a["category_name"]); seen_file.add(b["category_name"])
     assert "person" in seen_ref and "unknown" in seen_ref and not ({"human", "automobile", "mystery"} & seen_ref)
     assert {"human", "mystery"} <= seen_file and "person" not in seen_file
+
+
+def test_scene_pipeline_odd_frame_widths_vs_oracle():
+    """COCO frames whose width is not a multiple of 32 (427, 375, 333 ...): the pipeline pads the depth rows on the device and tells
+    the fit where the image ends (la3d_fit_args::frame_width); every record must be the oracle's on the UNPADDED frame (masks by the
+    reference's decoders), and equal to the scene fitted on its own, two-phase mode (ground vectors) included."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import poly_oracle as PO
+
+    from labelany3d_amd import fit_scenes as F
+
+    a, _ = F.synthetic_scenes(5, seed=31, H=375, W=500, rle_fraction=0.4)
+    b, _ = F.synthetic_scenes(5, seed=32, H=640, W=427, rle_fraction=0.4)
+    scenes = a + b
+    for i, sc in enumerate(scenes):
+        sc["name"] = f"o{i}"
+    scenes[2]["ground"] = [np.array([0.03, -0.97, 0.1, 1.2])] * 40        # (two-phase: the image's kept objects take a ground vector)
+    got = {sc["name"]: recs for sc, recs in F.ScenePipeline(batch_images=4, write=False).run(scenes)}
+    n = 0
+    for sc in scenes:
+        H, W = sc["height"], sc["width"]
+        K = np.asarray(sc["K"], dtype=np.float64).reshape(3, 3)
+        want = []
+        kept = 0
+        for an in sc["annotations"]:
+            if an.get("iscrowd") or "segmentation" not in an:
+                continue
+            seg = an["segmentation"]
+            if isinstance(seg, dict):
+                m = O.rle_decode(seg["counts"] if isinstance(seg["counts"], list) else O.rle_from_string(seg["counts"]), H, W)
+                st = O.mask_stats(m, 10)
+                keep = O.keep_instance(st, H, True)
+            else:
+                m = np.logical_or.reduce([PO.create_boolean_mask_from_polygon((W, H), [part])[0] for part in seg])
+                st = O.mask_stats(m, 10)
+                keep = O.keep_instance(st, H, False)
+            if not keep:
+                continue
+            g = sc["ground"][kept] if "ground" in sc and isinstance(sc["ground"], list) and kept < len(sc["ground"]) else None
+            rec, status = O.fit_instance(sc["depth"], m, K, g)[:2]
+            if status == 0:
+                want.append((str(kept), rec))
+            kept += 1
+        recs = list(got[sc["name"]])
+        assert [r["obj_id"] for r in recs] == [w[0] for w in want], sc["name"]
+        for r, (_, rec) in zip(recs, want):
+            np.testing.assert_allclose(r["center_cam"], rec[:3], rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(r["dimensions"], rec[3:6], rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(np.ravel(r["R_cam"]), rec[6:15], rtol=0, atol=1e-8)
+            np.testing.assert_allclose(np.ravel(r["bbox3D_cam"]), rec[15:], rtol=0, atol=2e-2)
+            n += 1
+    assert n >= 25
