@@ -509,6 +509,9 @@ __device__ __host__ inline int sep_col_words(int W) { return (2 * W + 3) & ~3; }
 // acc[0..4] += Sx, Sz, Sxx, Sxz, Szz of this wave's tiles; yext = [ymin, ymax]; *unsafe = max over the valid depth bit patterns
 // (>= 0x7f800000: a NaN, an infinity or a negative depth under the mask).  col = colmin (colmax = col + W), initialised to
 // 0xffffffff / 0 before the barrier in front of this call.
+// EDGE: the frame's height is not a multiple of 8 - the last tile row sticks out of the frame (its own copy of the walk: frames of
+// the common heights pay nothing for the test)
+template <bool EDGE = false>
 __device__ inline void sweep_sep(const FitParams& p, const float* __restrict__ dpl, const unsigned* bits,
                                  const unsigned short* list, int nactive, const double* Mg, unsigned* col, int wave, int lane,
                                  double* acc, double* yext, unsigned* unsafe, int row0 = 0) {
@@ -542,7 +545,7 @@ __device__ inline void sweep_sep(const FitParams& p, const float* __restrict__ d
         pk |= nib << (4 * g);
         // uniform tile origin in scalar registers + the lane's constant byte offsets
         const unsigned char* tp = reinterpret_cast<const unsigned char*>(dpl + ((long long)((t >> 8) * 8u) * p.W + (t & 0xffu) * 32u));
-        if ((t >> 8) * 8u + 8u <= (unsigned)p.H) {   // uniform: every row of the tile lies inside the frame
+        if (!EDGE || (t >> 8) * 8u + 8u <= (unsigned)p.H) {   // uniform: every row of the tile lies inside the frame
           if (nib) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) dq[g][k] = *reinterpret_cast<const unsigned*>(tp + loff[k]);
@@ -1502,7 +1505,8 @@ __global__ __launch_bounds__(NT, RET > 0 ? NT / 128 : NT / 64) void fit_instance
       unsigned* col = bits + nactive * 8;
       double sacc[5] = {0, 0, 0, 0, 0}, yx[2] = {INFINITY, -INFINITY};
       unsigned unsafe = 0u;
-      sweep_sep(p, dpl, bits, list, nactive, Mg, col, wave, lane, sacc, yx, &unsafe);
+      if (p.H & 7) sweep_sep<true>(p, dpl, bits, list, nactive, Mg, col, wave, lane, sacc, yx, &unsafe);   // uniform
+      else sweep_sep<false>(p, dpl, bits, list, nactive, Mg, col, wave, lane, sacc, yx, &unsafe);
       if (__ballot(unsafe >= 0x7f800000u) != 0ull && lane == 0) sh->sep_bad = 1;   // NaN / inf / negative depth under the mask
       // (the wave's y extent waits in scalar registers while the axis is computed: four vector registers fewer across that stage)
       const double ylo_w = uniform_f64(wave_min(yx[0])), yhi_w = uniform_f64(wave_max(yx[1]));
@@ -2556,7 +2560,7 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_rows_kernel(const FitParams p
   // ---- the single pass over the band ----
   double sacc[5] = {0, 0, 0, 0, 0}, yx[2] = {INFINITY, -INFINITY};
   unsigned unsafe = 0u;
-  if (sep_cam) sweep_sep(p, dpl, bits, list, nactive, Mg, col, wave, lane, sacc, yx, &unsafe, row0);
+  if (sep_cam) sweep_sep<false>(p, dpl, bits, list, nactive, Mg, col, wave, lane, sacc, yx, &unsafe, row0);   // (H % 8 == 0: rows_plan)
   {
     const double r0 = wave_sum(sacc[0]), r1 = wave_sum(sacc[1]), r2 = wave_sum(sacc[2]), r3 = wave_sum(sacc[3]), r4 = wave_sum(sacc[4]);
     const double ylo = wave_min(yx[0]), yhi = wave_max(yx[1]);
