@@ -481,7 +481,11 @@ def fit_annotations_all(annotations, image_size, depth, K, ground=None, image_in
     flt = None
     if filter:
         flt = {"boundary_threshold": 10, "scale_threshold": 100} if filter is True else dict(filter)
-    for kind, (idx, segs) in split_annotations(annotations).items():
+    groups = split_annotations(annotations)
+    if W_img % 32 != 0 and any(idx for idx, _ in groups.values()):   # a frame of odd width: rows padded once for both kinds
+        with torch.cuda.device(dev):
+            depth, _ = pad_depth_rows(depth, dev)
+    for kind, (idx, segs) in groups.items():
         if not idx:
             continue
         sel = np.asarray(idx, np.int64)
@@ -490,7 +494,8 @@ def fit_annotations_all(annotations, image_size, depth, K, ground=None, image_in
         ar = [annotations[i].get("area") for i in idx]
         hint = None if any(v is None for v in ar) else np.clip(np.asarray(ar, dtype=np.float64), 0, 2**31 - 1).astype(np.int32)
         kw = dict(rles=segs) if kind == "rle" else dict(polys=pack_polygons(segs, H_img, W_img))
-        res = fit_instances_ex(depth, K, ground=take(ground), image_index=take(image_index), device=dev, filter=flt, area_hint=hint, **kw)
+        res = fit_instances_ex(depth, K, ground=take(ground), image_index=take(image_index), device=dev, filter=flt, area_hint=hint,
+                               frame_width=W_img, **kw)
         boxes.index_copy_(0, sel_t, res["boxes"])
         status.index_copy_(0, sel_t, res["status"])
     return boxes, status

@@ -112,6 +112,9 @@ def test_prepadded_depth_and_fit_annotations(la):
     h = la.fit_annotations(anns, (W, H), torch.as_tensor(depth, device="cuda"), K, ground=ground, to_host=True)    # host-pointer route
     assert t[0] == h[0] and t[2] == h[2] and len(t[1]) >= 3
     np.testing.assert_array_equal(t[1], h[1]); np.testing.assert_array_equal(t[3], h[3]); np.testing.assert_array_equal(t[4], h[4])
+    ball, sall = (np_(x) for x in la.fit_annotations_all(anns, (W, H), depth, K, ground=ground, filter=True))   # (the sharded path's local step)
+    np.testing.assert_array_equal(np.nonzero(sall != 6)[0], t[1])
+    np.testing.assert_array_equal(ball[t[1]], t[3]); np.testing.assert_array_equal(sall[t[1]], t[4])
     bb0, segs0, kept0, cats0 = la.filter_annotations(anns, (W, H))
     np.testing.assert_array_equal(t[1], kept0)
     masks = np_(la.segmentations_to_masks(segs0, H, W)).astype(bool)
