@@ -132,18 +132,23 @@ def _load_scene(scene: dict, depth_out: np.ndarray, k_out: np.ndarray) -> None:
 
 
 # Pinned host buffers outlive a pipeline object (pinning costs far more than the copy it serves; a tool run creates one pipeline,
-# bench.py several).  Two kinds: the (P, H, W) depth / K staging buffers, keyed by shape and ring slot and NEVER evicted, and the
-# record read-back buffers, keyed by kind and ring slot and sized by CAPACITY (grown to the next power of two, sliced per batch:
-# the number of annotations changes with every batch).  One lock: the producer thread and the caller's thread both come here.
+# bench.py several).  All of them are keyed by PURPOSE and ring slot and sized by CAPACITY - grown to the next power of two when a
+# batch needs more, viewed / sliced per batch: a COCO run meets hundreds of frame sizes and a different number of annotations in
+# every batch, and a buffer per exact shape would pin (and never release) memory without bound.  So the pinned total is three ring
+# slots x the largest batch.  One lock: the producer thread and the caller's thread both come here.
 _PINNED: Dict[tuple, torch.Tensor] = {}
 _PINNED_LOCK = threading.Lock()
 
 
-def _pinned(key, shape, dtype):
+def _pinned_bytes(key, nbytes):
+    """at least ``nbytes`` bytes of pinned memory under ``key`` (uint8, grown by doubling; the contents are not preserved)"""
     with _PINNED_LOCK:
         t = _PINNED.get(key)
-        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
-            t = torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
+        if t is None or t.numel() < nbytes:
+            cap = 1 << 20
+            while cap < nbytes:
+                cap *= 2
+            t = torch.empty((cap,), dtype=torch.uint8, pin_memory=True)
             _PINNED[key] = t
         return t
 
@@ -183,15 +188,16 @@ class ScenePipeline:
         self.t = timings if timings is not None else {}
         for k in ("load_s", "pack_s", "h2d_bytes", "h2d_s", "fit_s", "d2h_s", "write_s", "images", "instances", "boxes", "batches"):
             self.t.setdefault(k, 0.0)
-        self._busy: Dict[tuple, torch.cuda.Event] = {}
+        self._busy: Dict[int, torch.cuda.Event] = {}   # ring slot -> the event behind its last upload
         self._fitters: Dict[tuple, object] = {}
 
     # ---- stage 1 (background thread): load, pack, start the uploads ------------------------------------------------------------
     def _pinned_depth(self, P, H, W, parity):
-        ev = self._busy.get((P, H, W, parity))
+        ev = self._busy.get(parity)
         if ev is not None:
-            ev.synchronize()   # the upload that last read these buffers (three batches ago) has long finished; make it certain
-        return _pinned(("depth", P, H, W, parity), (P, H, W), torch.float32), _pinned(("K", P, parity), (P, 9), torch.float64)
+            ev.synchronize()   # the upload that last read this ring slot's buffers (three batches ago) has long finished; make it certain
+        flat = _pinned_bytes(("depth", parity), P * H * W * 4)
+        return flat[:P * H * W * 4].view(torch.float32).view(P, H, W), _pinned_rows(("K", parity), P, (9,), torch.float64)
 
     def _prepare(self, scenes: List[dict], parity: int) -> _Prepared:
         H, W = scenes[0]["height"], scenes[0]["width"]
@@ -273,7 +279,7 @@ class ScenePipeline:
                 pr.groups[kind] = (up, g)
             pr.ready = torch.cuda.Event(enable_timing=True)
             pr.ready.record(self.copy_stream)
-        self._busy[(P, H, W, parity)] = pr.ready
+        self._busy[parity] = pr.ready
         pr.parity = parity
         return pr
 
@@ -282,12 +288,15 @@ class ScenePipeline:
         annotations changes with every batch; a fresh InstanceFitter per call cost ~1 ms of allocations)"""
         from .batched import InstanceFitter
         key = (kind, parity, H, W)
-        f = self._fitters.get(key)
+        f = self._fitters.pop(key, None)
         if f is None or f.B < B:
             cap = 256
             while cap < B:
                 cap *= 2
-            f = self._fitters[key] = InstanceFitter(cap, H, W, self.dev)
+            f = InstanceFitter(cap, H, W, self.dev)
+        self._fitters[key] = f                      # (most recently used last)
+        while len(self._fitters) > 24:              # a run over many frame sizes: the least recently used sizes give their memory back
+            self._fitters.pop(next(iter(self._fitters)))
         return f
 
     # ---- stage 2 (caller's thread): fit, download --------------------------------------------------------------------------------

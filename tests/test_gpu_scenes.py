@@ -124,6 +124,8 @@ def test_scene_pipeline_mixed_frame_sizes_and_rle_strings():
                 seg["counts"] = O.rle_to_string(seg["counts"])     # pycocotools' compressed form
     together = {sc["name"]: recs for sc, recs in F.ScenePipeline(batch_images=4, write=False).run(scenes)}
     assert set(together) == {sc["name"] for sc in scenes}
+    # staging memory is kept per ring slot and sized by capacity, not per frame size (a COCO run meets hundreds of sizes)
+    assert sum(1 for k in F._PINNED if k[0] == "depth") <= 3 and all(len(k) == 2 for k in F._PINNED if k[0] in ("depth", "K"))
     flat = lambda recs: np.array([np.concatenate([r["center_cam"], r["dimensions"], np.ravel(r["R_cam"]), np.ravel(r["bbox3D_cam"])]) for r in recs]).reshape(-1, 39)  # noqa: E731
     for sc in scenes:
         alone = [recs for _, recs in F.ScenePipeline(batch_images=1, write=False).run([sc])][0]
