@@ -78,6 +78,11 @@ int la3d_unproject_batch(const float* depth, const double* K, int32_t k_stride, 
  * counts: dev i32 [B].  The host needs it to draw np.random.randint(0, N, 500). */
 int la3d_mask_counts(const uint8_t* mask, int B, int H, int W, int32_t* counts, void* stream);
 
+/* Depth rows padded on the right with zeros: src dev f32 [rows][W] -> dst dev f32 [rows][Wp] (Wp >= W, Wp % 4 == 0, dst 16-byte
+ * aligned; rows = planes x H).  What la3d_fit_args::frame_width wants for frames whose width is not a multiple of 32 (run-length /
+ * polygon masks on COCO's 427 / 500 / 375 / 333-wide images): Wp = the next multiple of 32. */
+int la3d_pad_rows(const float* src, int64_t rows, int W, int Wp, float* dst, void* stream);
+
 /* The library keeps NO mutable process state (re-entrant, no global state).  How a call is scheduled - which
  * engine, whether the size-balanced launch order runs, which build of the instance kernel - is decided per call from its
  * arguments; the three `opt_*` fields of la3d_fit_args override the decision for one call (0 = the library's choice).  The

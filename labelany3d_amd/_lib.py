@@ -40,6 +40,7 @@ _SIGS = {
     "la3d_unproject_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_int, C.c_void_p]),
     "la3d_mask_counts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "la3d_pad_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "la3d_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "la3d_fit_instances": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

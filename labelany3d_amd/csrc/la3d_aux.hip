@@ -540,6 +540,23 @@ __global__ __launch_bounds__(256) void unproject_batch_kernel(const float* __res
                         blockIdx.x * blockDim.x + wave * 64, gridDim.x * blockDim.x, lane, vec16 != 0);
 }
 
+// Depth rows padded on the right with zeros: [rows][W] f32 -> [rows][Wp] f32, Wp % 4 == 0 (la3d_fit_args::frame_width: frames whose
+// width is not a multiple of 32).  One 16-byte store per thread and step; the loads are 4-byte (a row of odd width starts anywhere),
+// consecutive lanes read consecutive floats.
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ src, long long rows, int W, int Wp, float* __restrict__ dst) {
+  const int qpr = Wp >> 2;                                   // 16-byte groups per padded row
+  const long long total = rows * qpr;
+  for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+    const long long r = g / qpr;
+    const int c = (int)(g - r * qpr) * 4;
+    const float* s = src + r * W + c;
+    u32x4 v;   // (bit patterns: the store is a plain 16-byte move)
+    v.x = c < W ? __float_as_uint(s[0]) : 0u; v.y = c + 1 < W ? __float_as_uint(s[1]) : 0u;
+    v.z = c + 2 < W ? __float_as_uint(s[2]) : 0u; v.w = c + 3 < W ? __float_as_uint(s[3]) : 0u;
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst) + g);
+  }
+}
+
 __global__ __launch_bounds__(256) void mask_counts_kernel(const unsigned char* __restrict__ mask, int HW, int vec,
                                                           int* __restrict__ counts) {
   __shared__ int part[4];
@@ -1470,6 +1487,19 @@ int la3d_unproject_batch(const float* depth, const double* K, int32_t k_stride, 
   if (out_is_f64) hipLaunchKernelGGL(unproject_batch_kernel<double>, dim3(bx, P), dim3(256), 0, s, depth, K, k_stride, static_cast<double*>(out), p, vec16);
   else hipLaunchKernelGGL(unproject_batch_kernel<float>, dim3(bx, P), dim3(256), 0, s, depth, K, k_stride, static_cast<float*>(out), p, vec16);
   return check_launch("unproject_batch_kernel");
+}
+
+int la3d_pad_rows(const float* src, int64_t rows, int W, int Wp, float* dst, void* stream) {
+  if (rows < 0 || W <= 0 || Wp < W || Wp % 4 != 0 || (rows > 0 && (!src || !dst)) || (reinterpret_cast<uintptr_t>(dst) & 15)) {
+    set_err("la3d_pad_rows: bad argument (Wp >= W, Wp % 4 == 0, dst 16-byte aligned)");
+    return LA3D_ERR_ARG;
+  }
+  if (rows == 0) return LA3D_SUCCESS;
+  const long long total = (long long)rows * (Wp / 4);
+  const long long want = (total + 255) / 256;
+  const int blocks = (int)(want < 8192 ? want : 8192);
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src, (long long)rows, W, Wp, dst);
+  return check_launch("pad_rows_kernel");
 }
 
 int la3d_mask_counts(const uint8_t* mask, int B, int H, int W, int32_t* counts, void* stream) {

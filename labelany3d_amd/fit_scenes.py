@@ -42,7 +42,7 @@ import torch
 from ._lib import lib
 from .batched import _dev, _upload_many, draw_sample_idx
 from .jsonout import SceneRecords, format_scenes
-from .masks import fit_instances_ex, mask_stats_poly, mask_stats_rle, pack_polygons, pack_rle, padded_width
+from .masks import fit_instances_ex, mask_stats_poly, mask_stats_rle, pack_polygons, pack_rle, pad_depth_rows, padded_width
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 OUT_NAME = "3dbbox.json"
@@ -268,7 +268,7 @@ class ScenePipeline:
                 # a frame of odd width (COCO: 427, 500, 375, 333 ...): the rows are padded to the next multiple of 32 ON THE DEVICE
                 # (the upload stays W wide) and the fit is told where the image ends (frame_width): the tiled / single-pass forms
                 # instead of the row-linear one, 3-6 x faster (profiles/r05/r05_frame_sizes.txt)
-                pr.depth = torch.nn.functional.pad(pr.depth, (0, padded_width(W) - W))
+                pr.depth, _ = pad_depth_rows(pr.depth, self.dev)   # (la3d_pad_rows on the current - the copy - stream)
             pr.K = torch.empty((P, 9), dtype=torch.float64, device=self.dev)
             pr.K.copy_(kpin, non_blocking=True)
             pr.groups = {}

@@ -236,10 +236,18 @@ def pad_depth_rows(depth, device=None):
     that odd widths otherwise take (profiles/r05/r05_frame_sizes.txt).  ``fit_instances_ex`` / ``fit_instances_rle`` /
     ``fit_instances_poly`` / ``fit_annotations*`` do this themselves; a caller that fits the same planes many times pads once and
     passes ``frame_width=W``."""
-    d = _as_dev(depth, torch.float32, _dev(device))
+    dev = _dev(device)
+    d = _as_dev(depth, torch.float32, dev)
     W = int(d.shape[-1])
     Wp = padded_width(W)
-    return (d if Wp == W else torch.nn.functional.pad(d, (0, Wp - W))), W
+    if Wp == W:
+        return d, W
+    d = d.contiguous()
+    with torch.cuda.device(dev):
+        out = torch.empty(d.shape[:-1] + (Wp,), dtype=torch.float32, device=dev)
+        check(lib.la3d_pad_rows(_ptr(d), d.numel() // W, W, Wp, _ptr(out), _stream(None)), "la3d_pad_rows")
+    _record(None, d, out)
+    return out, W
 
 
 def fit_instances_ex(depth, K, masks=None, rles=None, polys=None, ground=None, sample_idx=None, image_index=None, filter=None,
@@ -510,7 +518,7 @@ def _fit_annotations_host(annotations, groups, W_img, H_img, depth, K, ground, i
     P = depth.shape[0] if depth.dim() == 3 else 1
     Wp = padded_width(W_img)
     if Wp != W_img:   # a frame of odd width: rows padded to the next multiple of 32, frame_width says where the image ends
-        depth = torch.nn.functional.pad(depth, (0, Wp - W_img))
+        depth, _ = pad_depth_rows(depth, depth.device)
     Kh = np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(-1, 9))
     if Kh.shape[0] not in (1, P):
         raise ValueError("K must be (3,3) or (P,3,3)")
