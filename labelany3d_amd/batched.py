@@ -230,6 +230,40 @@ class InstanceFitter:
         return self.boxes[slot], self.status[slot], self.aux[slot]
 
 
+_INDEX_OK: dict = {}   # (data_ptr, version, B, P) of image_index tensors already checked on the device (the check synchronises)
+
+
+def _check_image_index(given, ii, B, P):
+    """image_index must lie in [0, P): an index outside makes the kernel read another allocation.  Host arrays are checked on the
+    host; a device tensor is checked on the device ONCE per (storage, version) - a loop over the same index tensor then pays the
+    two reductions + the read-back (~40 us) only in its first call."""
+    if B == 0:
+        return
+    if not (isinstance(given, torch.Tensor) and given.is_cuda):
+        h = np.asarray(given.numpy() if isinstance(given, torch.Tensor) else given)
+        if h.min() < 0 or h.max() >= P:
+            raise ValueError("image_index out of range")
+        return
+    key = (ii.data_ptr(), ii._version, B, P)
+    if key in _INDEX_OK:
+        return
+    if int(ii.min()) < 0 or int(ii.max()) >= P:
+        raise ValueError("image_index out of range")
+    if len(_INDEX_OK) >= 64:
+        _INDEX_OK.clear()
+    _INDEX_OK[key] = True
+
+
+def pad_rows_f32(d: torch.Tensor, Wp: int) -> torch.Tensor:
+    """(..., H, W) float32 on the device -> (..., H, Wp) with zeros on the right (C-ABI ``la3d_pad_rows``, current stream)."""
+    W = int(d.shape[-1])
+    d = d.contiguous()
+    with torch.cuda.device(d.device):
+        out = torch.empty(d.shape[:-1] + (Wp,), dtype=torch.float32, device=d.device)
+        check(lib.la3d_pad_rows(_ptr(d), d.numel() // W, W, Wp, _ptr(out), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "la3d_pad_rows")
+    return out
+
+
 def fit_instances(depth, masks, K, ground=None, sample_idx=None, image_index=None, stream=None, device=None):
     """Batched composed hot path on the GPU.
 
@@ -264,8 +298,7 @@ def fit_instances(depth, masks, K, ground=None, sample_idx=None, image_index=Non
         ii = _as_dev(image_index, torch.int32, dev)
         if ii.shape != (B,):
             raise ValueError("image_index must be (B,)")
-        if B and (int(ii.min()) < 0 or int(ii.max()) >= P):
-            raise ValueError("image_index out of range")
+        _check_image_index(image_index, ii, B, P)
     elif P not in (1, B):
         raise ValueError("without image_index, depth must have 1 or B planes")
     g = None
@@ -279,6 +312,15 @@ def fit_instances(depth, masks, K, ground=None, sample_idx=None, image_index=Non
         if si.shape != (B, NSAMPLE):
             raise ValueError("sample_idx must be (B,500)")
     with torch.cuda.device(dev):
+        if W % 32 != 0 and 2 <= B <= 256 and si is None:
+            # a small batch on a frame of odd width (COCO: 427, 500, 375, 333 ...): the tiled forms - and the row engine small batches
+            # take - need word-aligned rows; padding the B mask planes and the depth rows with zeros costs less than the row-linear
+            # form they would otherwise run (profiles/r05/r05_odd_width_u8.txt: 8 / 64 / 256 masks of 640x427: 172 / 198 / 202 us ->
+            # 111 / 102 / 152 us per call).  Above 256 planes the copy costs what it saves: pad once yourself, or hand over annotations.
+            Wp = (W + 31) // 32 * 32
+            m = torch.nn.functional.pad(m, (0, Wp - W))
+            d = pad_rows_f32(d, Wp)
+            W = Wp
         f = InstanceFitter(B, H, W, dev)
         if B == 0:
             return f.boxes[0], f.status[0], f.aux[0]

@@ -30,7 +30,7 @@ import torch
 
 from . import options
 from ._lib import AUX, BOX_FILTERED, REC, check, lib
-from .batched import InstanceFitter, _as_dev, _bulk, _dev, _ptr, _record, _stream, _upload_many
+from .batched import InstanceFitter, _as_dev, _bulk, _dev, _ptr, _record, _stream, _upload_many, pad_rows_f32
 
 
 def rle_from_string(s) -> np.ndarray:
@@ -242,12 +242,7 @@ def pad_depth_rows(depth, device=None):
     Wp = padded_width(W)
     if Wp == W:
         return d, W
-    d = d.contiguous()
-    with torch.cuda.device(dev):
-        out = torch.empty(d.shape[:-1] + (Wp,), dtype=torch.float32, device=dev)
-        check(lib.la3d_pad_rows(_ptr(d), d.numel() // W, W, Wp, _ptr(out), _stream(None)), "la3d_pad_rows")
-    _record(None, d, out)
-    return out, W
+    return pad_rows_f32(d, Wp), W
 
 
 def fit_instances_ex(depth, K, masks=None, rles=None, polys=None, ground=None, sample_idx=None, image_index=None, filter=None,

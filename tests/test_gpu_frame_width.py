@@ -156,3 +156,34 @@ def test_frame_width_argument_checks(la):
     assert call(W + 1) != 0 and call(-3) != 0 and b"frame_width" in lib.la3d_last_error()
     assert call(80, use_mask=True) != 0                      # u8 planes: the caller pads the planes with zeros instead
     assert call(70, Wc=80) != 0                              # rows must be word aligned when a frame width is given
+
+
+def test_small_batches_of_u8_planes_on_odd_widths(la):
+    """fit_instances pads a SMALL batch of u8 planes on a frame of odd width by itself (mask planes and depth rows, zeros on the right):
+    the records are the oracle's; image_index is range-checked on the host for host arrays and once per tensor on the device."""
+    import torch
+
+    rs = np.random.RandomState(4)
+    H, W, B, P_ = 375, 500, 12, 3
+    depth = rs.uniform(0.5, 10, (P_, H, W)).astype(np.float32)
+    masks = _blobs(rs, B, H, W)
+    K = np.array([[420.0, 0, 251], [0, 415.0, 188], [0, 0, 1]])
+    img = rs.randint(0, P_, B).astype(np.int32)
+    b, s, a = (np_(t) for t in la.fit_instances(depth, masks, K, image_index=img))
+    ref, rst, _, nval = O.fit_instances(depth, masks, np.broadcast_to(K, (P_, 3, 3)), depth_index=img)
+    assert s.tolist() == list(rst)
+    ok = (s == 0) & (a[:, 3] > 1e-6)
+    assert_records(b[ok], ref[ok], "u8 planes 375x500", gap=a[ok, 3])
+    np.testing.assert_array_equal(a[s == 0, 1], nval[s == 0])
+    with pytest.raises(ValueError, match="out of range"):
+        la.fit_instances(depth, masks, K, image_index=np.full(B, P_, np.int32))
+    it = torch.as_tensor(img, device="cuda")
+    for _ in range(3):                                           # (the device-side check runs once for this tensor)
+        b2 = np_(la.fit_instances(depth, masks, K, image_index=it)[0])
+    np.testing.assert_array_equal(b2, b)
+    it2 = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+    with pytest.raises(ValueError, match="out of range"):
+        la.fit_instances(depth, masks, K, image_index=it2)
+    it.fill_(P_)                                                 # modified in place: a new version is checked again
+    with pytest.raises(ValueError, match="out of range"):
+        la.fit_instances(depth, masks, K, image_index=it)
