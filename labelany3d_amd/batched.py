@@ -11,6 +11,7 @@ src/util_3dbox.py:106-178.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Optional
 
 import numpy as np
@@ -230,13 +231,14 @@ class InstanceFitter:
         return self.boxes[slot], self.status[slot], self.aux[slot]
 
 
-_INDEX_OK: dict = {}   # (data_ptr, version, B, P) of image_index tensors already checked on the device (the check synchronises)
+_INDEX_OK: dict = {}   # id(image_index tensor) -> (weak reference to it, (version, B, P)): tensors already checked on the device
 
 
 def _check_image_index(given, ii, B, P):
     """image_index must lie in [0, P): an index outside makes the kernel read another allocation.  Host arrays are checked on the
-    host; a device tensor is checked on the device ONCE per (storage, version) - a loop over the same index tensor then pays the
-    two reductions + the read-back (~40 us) only in its first call."""
+    host; a device tensor is checked on the device ONCE per tensor object and version (in-place writes bump the version; another
+    tensor that later lands on the same address is another object) - a loop over the same index tensor then pays the two
+    reductions + the read-back (~40 us) only in its first call."""
     if B == 0:
         return
     if not (isinstance(given, torch.Tensor) and given.is_cuda):
@@ -244,14 +246,13 @@ def _check_image_index(given, ii, B, P):
         if h.min() < 0 or h.max() >= P:
             raise ValueError("image_index out of range")
         return
-    key = (ii.data_ptr(), ii._version, B, P)
-    if key in _INDEX_OK:
+    stamp, key = (given._version, B, P), id(given)
+    ent = _INDEX_OK.get(key)
+    if ent is not None and ent[0]() is given and ent[1] == stamp:
         return
     if int(ii.min()) < 0 or int(ii.max()) >= P:
         raise ValueError("image_index out of range")
-    if len(_INDEX_OK) >= 64:
-        _INDEX_OK.clear()
-    _INDEX_OK[key] = True
+    _INDEX_OK[key] = (weakref.ref(given, lambda _r, k=key: _INDEX_OK.pop(k, None)), stamp)   # (dropped when the tensor dies)
 
 
 def pad_rows_f32(d: torch.Tensor, Wp: int) -> torch.Tensor:
