@@ -872,7 +872,7 @@ def main():
             req_bytes = B * H * W + int(big.sum()) * 500 * 64 + tiles_small * 1024 + B * 39 * 8
         step_s = kern_ms * 1e-3
         achieved = req_bytes / step_s / 1e9
-        traffic, traffic_src, traffic_stale, traffic_kernel_ns = None, None, None, None
+        traffic, traffic_src, traffic_stale, traffic_kernel_ns, traffic_kernel_ns_long = None, None, None, None, None
         tp = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
         mode = traffic_mode_key(args, B)
         if os.path.exists(tp):
@@ -881,6 +881,7 @@ def main():
             if ent:
                 traffic, traffic_src = ent.get("hbm_bytes_per_step"), ent.get("source")
                 traffic_kernel_ns = ent.get("dominant_kernel_avg_ns")
+                traffic_kernel_ns_long = ent.get("dominant_kernel_avg_ns_default_length")
                 traffic_stale = tj.get("kernel_source_sha256") != kernel_source_sha256()
         # shader-side counters of the same profile set (profiles/make_valu_json.py): how busy the fp64 VALU - the path's second roof - is
         valu = None
@@ -978,6 +979,9 @@ def main():
                 "valu": valu,
                 "traffic_mode": mode,
                 "traffic_kernel_avg_ns_under_rocprof": traffic_kernel_ns,
+                # (the counter passes are 55-launch runs from an idle chip with the counter collection on: 2-3 % above a steady step;
+                # the same kernel in the profile of the default-length command - 1000 timed steps + the secondary loops:)
+                "kernel_avg_ns_under_rocprof_default_length": traffic_kernel_ns_long,
                 "note": "frac = frac_required = required bytes (byte_model) / avg_launch_ms / 8 TB/s; frac_traffic = PMC-measured bytes / avg_launch_ms / 8 TB/s; frac_algorithmic_model = SURVEY 8d's H*W*5+312 B/box / avg_launch_ms / 8 TB/s (above 1: not a fraction of anything physical); avg_launch_ms is avg_launch_ms is the HIP-EVENT time per step on "
                         "the launch stream (max over ranks); `value` and ms_per_step are on the WALL clock between the two barriers (a few "
                         "us per step more at K = 20). measured_stream_GBps = la3d_mask_counts (a pure 16-byte-load reader) over the same "
