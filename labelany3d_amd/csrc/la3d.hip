@@ -2421,8 +2421,8 @@ struct RowsArgs {
 
 // host: bands for a batch of B instances on an H x W frame; false = the row engine does not apply
 inline bool rows_plan(int B, int H, int W, RowsArgs* ra) {
-  if (B < 1 || B > ROWS_MAX_B || H % 8 != 0 || W % 32 != 0 || W / 32 > 255 || H / 8 < 2) return false;
-  const int nty = H / 8;
+  if (B < 1 || B > ROWS_MAX_B || W % 32 != 0 || W / 32 > 255 || H < 16) return false;
+  const int nty = (H + 7) / 8;   // (a frame height that is not a multiple of 8 - COCO's 427 - leaves the last band a partial tile row)
   int nb = ROWS_NB_MAX;
   // about 500-640 workgroups in all (profiles/r05/r05_rows_engine.txt: B = 64 / 128 / 192, us per call with at most 256 | 512 | 1024 |
   // 2048 workgroups: 24.4 | 24.0 | 27.9 | 27.9; 32.7 | 30.0 | 33.1 | 36.8; 38.2 | 38.0 | 40.7 | 39.8)
@@ -2453,7 +2453,8 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_rows_kernel(const FitParams p
   const int inst = v / ra.nb, band = v - inst * ra.nb;
   const int img = p.image_index ? p.image_index[inst] : inst;
   const int row0 = band * ra.trows * 8;
-  const int trows = min(ra.trows, p.H / 8 - band * ra.trows);   // >= 1 (rows_plan)
+  const int trows = min(ra.trows, (p.H + 7) / 8 - band * ra.trows);   // >= 1 (rows_plan)
+  const int rows = min(trows * 8, p.H - row0);                        // pixel rows of the band that lie inside the frame
   const int W = p.W, ntx = W / 32;
   const float* dpl = p.depth + (long long)img * p.depth_plane_stride + (long long)row0 * W;
   const unsigned char* mpl = p.mask + (long long)inst * p.HW + (long long)row0 * W;
@@ -2468,7 +2469,8 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_rows_kernel(const FitParams p
   }
   // ---- the band's rows of the u8 plane -> bit image (the instance engine's optimistic 0 / 1 form, general form behind it) ----
   unsigned short* b16 = reinterpret_cast<unsigned short*>(bits);
-  const int ngroups = trows * 8 * W / 16;
+  const int ngroups = rows * W / 16;
+  for (int g = ngroups + tid; g < trows * 8 * W / 16; g += NT) b16[g] = 0;   // (rows of the last tile row past the frame: no pixels)
   const u32x4* m4 = reinterpret_cast<const u32x4*>(mpl);
   int nmask = 0;
   {
@@ -2560,7 +2562,14 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_rows_kernel(const FitParams p
   // ---- the single pass over the band ----
   double sacc[5] = {0, 0, 0, 0, 0}, yx[2] = {INFINITY, -INFINITY};
   unsigned unsafe = 0u;
-  if (sep_cam) sweep_sep<false>(p, dpl, bits, list, nactive, Mg, col, wave, lane, sacc, yx, &unsafe, row0);   // (H % 8 == 0: rows_plan)
+  if (sep_cam) {
+    if (rows == trows * 8) sweep_sep<false>(p, dpl, bits, list, nactive, Mg, col, wave, lane, sacc, yx, &unsafe, row0);   // uniform
+    else {   // the frame's last, partial tile row is in this band: the walk that loads row by row there (band-local frame height)
+      FitParams pb = p;
+      pb.H = rows;
+      sweep_sep<true>(pb, dpl, bits, list, nactive, Mg, col, wave, lane, sacc, yx, &unsafe, row0);
+    }
+  }
   {
     const double r0 = wave_sum(sacc[0]), r1 = wave_sum(sacc[1]), r2 = wave_sum(sacc[2]), r3 = wave_sum(sacc[3]), r4 = wave_sum(sacc[4]);
     const double ylo = wave_min(yx[0]), yhi = wave_max(yx[1]);

@@ -37,7 +37,8 @@ def _engines(la, monkeypatch, *args, **kw):
     return rows, inst
 
 
-@pytest.mark.parametrize("H,W,B", [(480, 640, 1), (480, 640, 40), (480, 640, 300), (96, 128, 24), (720, 1280, 6), (16, 32, 7), (64, 96, 512)])
+@pytest.mark.parametrize("H,W,B", [(480, 640, 1), (480, 640, 40), (480, 640, 300), (96, 128, 24), (720, 1280, 6), (16, 32, 7), (64, 96, 512),
+                                   (427, 640, 20), (426, 640, 3), (101, 96, 9), (17, 64, 5)])   # (heights that are not a multiple of 8: a partial last tile row)
 def test_row_engine_vs_oracle_and_instance_engine(la, monkeypatch, H, W, B):
     rs = np.random.RandomState(H + W + B)
     depth = rs.uniform(0.5, 10, (B, H, W)).astype(np.float32)
