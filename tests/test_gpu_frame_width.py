@@ -187,3 +187,25 @@ def test_small_batches_of_u8_planes_on_odd_widths(la):
     it.fill_(P_)                                                 # modified in place: a new version is checked again
     with pytest.raises(ValueError, match="out of range"):
         la.fit_instances(depth, masks, K, image_index=it)
+
+
+def test_pad_rows_entry(la):
+    """la3d_pad_rows: [rows][W] f32 -> [rows][Wp] f32 with zeros on the right, for any W; argument checks."""
+    import torch
+    from labelany3d_amd._lib import lib
+
+    dev = torch.device("cuda", 0)
+    for rows, W, Wp in ((7, 427, 448), (1, 1, 4), (33, 500, 512), (5, 64, 64), (3, 333, 352), (0, 10, 32)):
+        src = torch.rand((max(rows, 1), W), device=dev)[:rows].contiguous()
+        dst = torch.full((max(rows, 1), Wp), -1.0, device=dev)[:rows]
+        rc = lib.la3d_pad_rows(src.data_ptr() if rows else None, rows, W, Wp, dst.data_ptr() if rows else None, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, lib.la3d_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(dst, torch.nn.functional.pad(src, (0, Wp - W)))
+    a = torch.zeros(64, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    assert lib.la3d_pad_rows(a.data_ptr(), 2, 8, 4, a.data_ptr(), s) != 0          # Wp < W
+    assert lib.la3d_pad_rows(a.data_ptr(), 2, 8, 10, a.data_ptr(), s) != 0         # Wp % 4 != 0
+    assert lib.la3d_pad_rows(None, 2, 8, 8, a.data_ptr(), s) != 0 and b"la3d_pad_rows" in lib.la3d_last_error()
+    d, w = la.pad_depth_rows(np.ones((2, 5, 33), np.float32))
+    assert w == 33 and d.shape == (2, 5, 64) and float(d.sum()) == 2 * 5 * 33 and la.pad_depth_rows(d)[0] is d
