@@ -154,7 +154,9 @@ def measured_stream_ceiling(masks, min_ms=30.0):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     nbytes = float(masks.numel())
-    iters = max(20, int(min_ms * 1e-3 * 5.0e12 / nbytes))      # ~min_ms at 5 TB/s
+    # ~min_ms at 5 TB/s; at most 600 launches (a small --batch would otherwise issue thousands of short launches: under a rocprofv3
+    # counter pass, which serialises every launch, that alone took 20 minutes at --batch 64)
+    iters = min(600, max(20, int(min_ms * 1e-3 * 5.0e12 / nbytes)))
     best, total_ms, reps = 0.0, 0.0, 0
     while total_ms < min_ms and reps < 8:
         torch.cuda.synchronize()
