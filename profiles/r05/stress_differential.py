@@ -11,7 +11,7 @@ from oracle import poly_oracle as P
 
 np_ = lambda t: t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
 ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 150
-rs = np.random.RandomState(2027)
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 2027)
 worst = 0.0
 for case in range(ncase):
     W = int(rs.choice([32 * rs.randint(1, 22), rs.randint(20, 700), rs.choice([427, 500, 375, 333, 612, 426])]))
