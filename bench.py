@@ -539,7 +539,7 @@ def run_config4(args, dist, rank, world, device, red_dev):
         gat = [float(v[1]) for v in allv]
         job = max(float(v[2]) for v in allv)
         print(json.dumps({
-            "metric": "fitted 3D boxes/sec @640x480", "value": B / job, "unit": "boxes/s", "n_gpus": world, "steps": args.jobs,
+            "metric": "fitted 3D boxes/sec @640x480", "value": B / job, "unit": "boxes/s", "n_gpus": world, "ranks": getattr(args, "ranks", None), "steps": args.jobs,
             "warmup": args.warmup_jobs, "ms_per_step": job * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BASELINE config 4 partitioning: {P} images with a shared 480x640 depth plane each, {B} instances "
@@ -622,6 +622,47 @@ def run_end_to_end(args, device):
     }), flush=True)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks of one node under torch.distributed.run
+    (one process per GPU, LOCAL_RANK = the rank's device; the rendezvous on 127.0.0.1 and a free port) and return its exit code.
+    The per-process index ranges of the reference (`src/batch_scripts/whole.py:25-27,42`) are what the ranks stand for.  Fails
+    loudly - no silent one-GPU measurement - when the node has fewer than N GPUs for the RCCL backend."""
+    import socket
+    import subprocess
+
+    backend = os.environ.get("LA3D_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < n:
+        print(f"bench.py: --gpus {n} needs {n} GPUs for its {n} RCCL ranks, this node shows {have}; nothing was measured "
+              "(LA3D_BENCH_BACKEND=gloo is the functional dry run of several ranks on one GPU)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LA3D_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rank_identity(dist, rank, local, device):
+    """What proves which ranks and devices a line was measured on: per rank its device index, name, PCI bus id and uuid
+    (gathered once, before the timed region)."""
+    p = torch.cuda.get_device_properties(device)
+    bus = None
+    if hasattr(p, "pci_bus_id"):
+        bus = "%04x:%02x:%02x" % (int(getattr(p, "pci_domain_id", 0)), int(p.pci_bus_id), int(getattr(p, "pci_device_id", 0)))
+    me = {"rank": rank, "local_rank": local, "device": device.index, "name": p.name, "pci_bus_id": bus,
+          "uuid": str(getattr(p, "uuid", "")) or None, "pid": os.getpid()}
+    if dist is None:
+        return [me]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, me)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -668,9 +709,19 @@ def main():
                     help="HIP streams the independent steps are issued on round-robin (1 = strictly serial steps)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N` (the shape of the driver's N = 1 command): become the launcher of N ranks
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        # a torchrun line whose --nproc-per-node disagrees with --gpus would record an n_gpus nobody asked for
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         f"(or plain `python bench.py --gpus {args.gpus}`, which spawns its own ranks)")
+    if world > 1 and os.environ.get("LA3D_BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} RCCL ranks need {world} GPUs, this node shows {torch.cuda.device_count()} "
+                         "(LA3D_BENCH_BACKEND=gloo is the functional dry run of several ranks on one GPU)")
     # LA3D_BENCH_FORCE_DIST=1: initialise torch.distributed even for one rank, so that the RCCL branch (device-tensor gather,
     # timing all-reduces) can be executed on a single-GPU box (tests/test_gpu_shard.py)
     if world > 1 or os.environ.get("LA3D_BENCH_FORCE_DIST") == "1":
@@ -689,11 +740,12 @@ def main():
     else:
         dist = None
         torch.cuda.set_device(0)
-    if args.gpus != world:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     device = torch.device("cuda", torch.cuda.current_device())
     red_dev = device if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")   # where the timing scalars are reduced
+    ranks = {"backend": (dist.get_backend() if dist is not None else None), "world_size": (dist.get_world_size() if dist is not None else 1),
+             "rccl_ranks": (dist.get_world_size() if dist is not None and dist.get_backend() == "nccl" else 0),
+             "self_launched": os.environ.get("LA3D_BENCH_SELF_LAUNCHED") == "1", "devices": rank_identity(dist, rank, local, device)}
+    args.ranks = ranks
 
     if args.config4:
         run_config4(args, dist, rank, world, device, red_dev)
@@ -925,6 +977,7 @@ def main():
             "steps": steps,
             "warmup": warmup,
             "ms_per_step": elapsed / steps * 1e3,
+            "ranks": ranks,
             "gather_ms": (gather_s * 1e3) if dist is not None else None,
             "value_fit_only": (world * steps * B / (kern_ms * 1e-3 * steps)) if dist is not None else None,
             "untimed_launches_before_timed_region": {"fit_steps": warmup, "other_kernels": ceiling_launches,

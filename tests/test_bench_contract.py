@@ -74,3 +74,58 @@ def test_required_bytes_model():
     m2 = torch.ones((1, 50, 70), dtype=torch.uint8)   # ragged frame: ceil(50/8) x ceil(70/32) tiles
     assert bench.required_bytes(m2)[1] == 7 * 3
     assert len(bench.kernel_source_sha256()) == 64
+
+
+def test_bench_refuses_to_measure_fewer_gpus_than_asked():
+    """`python bench.py --gpus N` on a node with fewer than N GPUs (this container: none; the one-GPU box: one) must fail
+    loudly instead of recording a one-GPU number under n_gpus = N - both as its own launcher and under a torchrun line whose
+    world size disagrees with --gpus."""
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this node could really run two ranks")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LA3D_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 2 and "needs 2 GPUs" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_plain_bench_command_launches_its_own_ranks():
+    """The shape of the driver's N = 1 command with --gpus 2 - no torch.distributed.run in front - must come back as a TWO-rank
+    line: bench.py re-runs itself under the launcher (here: gloo dry run, both ranks on this box's one GPU) and stamps the
+    ranks it really ran into the line."""
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["LA3D_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "512",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4
+    rk = d["ranks"]
+    assert rk["world_size"] == 2 and rk["backend"] == "gloo" and rk["rccl_ranks"] == 0 and rk["self_launched"] is True
+    assert [e["rank"] for e in rk["devices"]] == [0, 1] and len({e["pid"] for e in rk["devices"]}) == 2
+    assert all(e["name"] for e in rk["devices"])
+
+
+@pytest.mark.gpu
+def test_single_gpu_line_names_its_device():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-steady", "--no-pipelined"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    rk = d["ranks"]
+    assert d["n_gpus"] == 1 and rk["world_size"] == 1 and rk["backend"] is None and rk["self_launched"] is False
+    assert len(rk["devices"]) == 1 and rk["devices"][0]["device"] == 0
