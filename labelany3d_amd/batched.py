@@ -11,7 +11,6 @@ src/util_3dbox.py:106-178.
 from __future__ import annotations
 
 import ctypes as C
-import weakref
 from typing import Optional
 
 import numpy as np
@@ -231,14 +230,12 @@ class InstanceFitter:
         return self.boxes[slot], self.status[slot], self.aux[slot]
 
 
-_INDEX_OK: dict = {}   # id(image_index tensor) -> (weak reference to it, (version, B, P)): tensors already checked on the device
-
-
 def _check_image_index(given, ii, B, P):
-    """image_index must lie in [0, P): an index outside makes the kernel read another allocation.  Host arrays are checked on the
-    host; a device tensor is checked on the device ONCE per tensor object and version (in-place writes bump the version; another
-    tensor that later lands on the same address is another object) - a loop over the same index tensor then pays the two
-    reductions + the read-back (~40 us) only in its first call."""
+    """image_index must lie in [0, P): an index outside makes the kernel read another allocation (the C-ABI takes no plane count).
+    Host arrays are checked on the host, a device tensor on the device - on EVERY call: a tensor refilled through its data pointer
+    (this library's kernels, another C-ABI user, a DLPack alias) keeps its object identity and its version counter, so no cache
+    of "already checked" tensors is sound.  ~40 us (two reductions + the read-back) for a device tensor; `InstanceFitter.run` is
+    the entry for callers that have validated their index once and loop."""
     if B == 0:
         return
     if not (isinstance(given, torch.Tensor) and given.is_cuda):
@@ -246,13 +243,9 @@ def _check_image_index(given, ii, B, P):
         if h.min() < 0 or h.max() >= P:
             raise ValueError("image_index out of range")
         return
-    stamp, key = (given._version, B, P), id(given)
-    ent = _INDEX_OK.get(key)
-    if ent is not None and ent[0]() is given and ent[1] == stamp:
-        return
-    if int(ii.min()) < 0 or int(ii.max()) >= P:
+    lo, hi = torch.aminmax(ii)
+    if int(lo) < 0 or int(hi) >= P:
         raise ValueError("image_index out of range")
-    _INDEX_OK[key] = (weakref.ref(given, lambda _r, k=key: _INDEX_OK.pop(k, None)), stamp)   # (dropped when the tensor dies)
 
 
 def pad_rows_f32(d: torch.Tensor, Wp: int) -> torch.Tensor:
@@ -320,6 +313,14 @@ def fit_instances(depth, masks, K, ground=None, sample_idx=None, image_index=Non
             # 111 / 102 / 152 us per call).  Above 256 planes the copy costs what it saves: pad once yourself, or hand over annotations.
             Wp = (W + 31) // 32 * 32
             m = torch.nn.functional.pad(m, (0, Wp - W))
+            if ii is not None and P > B:
+                # a large resident stack of planes of which this call references at most B: pad the referenced planes only
+                # (P = 1000 planes of 640x427 would otherwise be copied - 1 GB - on every call)
+                sel = ii.long()
+                d = d.index_select(0, sel)
+                if k.shape[0] > 1:
+                    k = k.index_select(0, sel)
+                ii, P = None, B
             d = pad_rows_f32(d, Wp)
             W = Wp
         f = InstanceFitter(B, H, W, dev)

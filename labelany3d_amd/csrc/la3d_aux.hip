@@ -1781,6 +1781,7 @@ namespace {
 struct HostCtx {
   int device = -1;
   hipStream_t stream = nullptr;
+  hipEvent_t after = nullptr;        // orders the private stream behind the stream that produced the caller's device data
   unsigned char* pin = nullptr;      // pinned host block, mapped into the device's address space
   unsigned char* pin_dev = nullptr;  // ... its device address
   size_t pin_bytes = 0;
@@ -1792,6 +1793,7 @@ thread_local HostCtx t_host;
 
 void host_ctx_release(HostCtx& c) {
   if (c.stream) { (void)hipStreamSynchronize(c.stream); (void)hipStreamDestroy(c.stream); }
+  if (c.after) (void)hipEventDestroy(c.after);
   if (c.pin) (void)hipHostFree(c.pin);
   if (c.dev) (void)hipFree(c.dev);
   c = HostCtx();
@@ -1812,6 +1814,9 @@ int host_ctx(HostCtx** out, size_t pin_need, size_t dev_need, const char* who) {
     c.device = dev;
     if (hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) != hipSuccess) {
       snprintf(g_err, sizeof(g_err), "%s: hipStreamCreate failed", who); (void)hipGetLastError(); c = HostCtx(); return LA3D_ERR_HIP;
+    }
+    if (hipEventCreateWithFlags(&c.after, hipEventDisableTiming) != hipSuccess) {
+      snprintf(g_err, sizeof(g_err), "%s: hipEventCreate failed", who); (void)hipGetLastError(); (void)hipStreamDestroy(c.stream); c = HostCtx(); return LA3D_ERR_HIP;
     }
   }
   auto grow = [](size_t need) { size_t n = 64 * 1024; while (n < need) n *= 2; return n; };
@@ -1864,6 +1869,9 @@ int la3d_estimate_bbox_host(const double* points, int64_t n, const double* groun
   if (method == LA3D_METHOD_PCA) {
     if (++c->seq == 0) c->seq = 1;
     volatile unsigned* done = reinterpret_cast<volatile unsigned*>(c->pin + 416);
+    // la3d_fit_annotations_host shares this block and copies caller data over byte 416: a stale word there could equal this call's
+    // sequence number and end the poll before the kernel has run.  (Nothing is in flight on the private stream here.)
+    *done = 0;
     hipLaunchKernelGGL(fit_points_host_kernel, dim3(1), dim3(NTP), 0, c->stream, c->pin_dev, (long long)n, has_ground, c->seq);
     const int lrc = check_launch("fit_points_host_kernel");
     if (lrc != LA3D_SUCCESS) return lrc;
@@ -1982,6 +1990,12 @@ int la3d_fit_annotations_host(const la3d_fit_args* args) {
   memcpy(h + o_K, a.K, (size_t)(a.k_stride ? P * a.k_stride : 9) * 8);
   if (a.ground) memcpy(h + o_ground, a.ground, (size_t)B * 32);
   if (a.area_hint) memcpy(h + o_hint, a.area_hint, (size_t)B * 4);
+  *reinterpret_cast<volatile unsigned*>(h) = 0;   // the completion flag: la3d_estimate_bbox_host (hull) writes offsets over it
+  // The depth plane(s) were produced on the CALLER's stream (a depth model's output, an upload, la3d_pad_rows ...), the fit runs on
+  // this thread's private non-blocking stream: order the latter behind everything the former holds so far.  args->stream names the
+  // producer stream; NULL = the legacy default stream.
+  if (hipEventRecord(c->after, static_cast<hipStream_t>(a.stream)) != hipSuccess || hipStreamWaitEvent(c->stream, c->after, 0) != hipSuccess)
+    return check_launch("la3d_fit_annotations_host: ordering behind the producer stream");
   if (hipMemcpyAsync(c->dev + 64, h + 64, in_end - 64, hipMemcpyHostToDevice, c->stream) != hipSuccess) return check_launch("la3d_fit_annotations_host: upload");
   la3d_fit_args d = a;
   d.struct_size = (int32_t)sizeof(la3d_fit_args);

@@ -130,7 +130,8 @@ def pack_polygons(segmentations, H=None, W=None):
     parts = [polygon for seg in segmentations for polygon in seg]
     inst_rings = np.zeros(len(segmentations) + 1, np.int64)
     np.cumsum([len(seg) for seg in segmentations], out=inst_rings[1:])
-    plain = all(type(q) is list for q in parts)
+    # (a part given as nested pairs [[x, y], ...] is a list too: the flat fast path is for lists of scalars only)
+    plain = all(type(q) is list and not (q and isinstance(q[0], (list, tuple, np.ndarray))) for q in parts)
     lens = np.fromiter(map(len, parts), np.int64, len(parts)) if plain else None
     if plain and len(parts) and not (lens & 1).any():
         # flat Python lists (what the annotation JSON holds): ONE conversion loop over all coordinates of the batch instead of one
@@ -562,7 +563,11 @@ def _fit_annotations_host(annotations, groups, W_img, H_img, depth, K, ground, i
         out = np.empty((B, REC), np.float64)
         st = np.empty(B, np.int32)
         a.out, a.status = out.ctypes.data, st.ctypes.data
-        check(lib.la3d_fit_annotations_host(C.byref(a)), "la3d_fit_annotations_host")
+        # the C entry fits on the library's private stream of this thread, on the thread's CURRENT device: make that the depth's
+        # device and name the stream the depth (and the padding above) was produced on, which the entry orders itself behind
+        with torch.cuda.device(depth.device):
+            a.stream = torch.cuda.current_stream(depth.device).cuda_stream
+            check(lib.la3d_fit_annotations_host(C.byref(a)), "la3d_fit_annotations_host")
         sels.append(sel); recs.append(out); sts.append(st)
     if not sels:
         return [], np.zeros(0, np.int64), [], np.zeros((0, REC)), np.zeros(0, np.int32)

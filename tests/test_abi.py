@@ -351,3 +351,25 @@ def test_scheduling_options_are_thread_local_and_validated():
     assert options.codes() == (0, 0, 0) and seen["other"] == (0, 0, 0)
     with pytest.raises(ValueError):
         options.codes(build="big")
+
+
+def test_pack_polygons_accepts_every_form_the_reference_accepts():
+    """np.array(polygon).reshape(-1, 2).astype(np.int32) (reference src/util.py:398) takes flat lists, nested pairs and arrays;
+    the one-loop fast path of pack_polygons is for flat lists of scalars only and must not swallow the other forms."""
+    import numpy as np
+
+    from labelany3d_amd.masks import pack_polygons
+
+    flat = [[[1.5, 2.5, 10.2, 2.0, 9.9, 8.1]], [[0, 0, 4, 0, 4, 4, 0, 4], [2, 2, 3, 2, 3, 3]]]
+    nested = [[[[1.5, 2.5], [10.2, 2.0], [9.9, 8.1]]], [[[0, 0], [4, 0], [4, 4], [0, 4]], [[2, 2], [3, 2], [3, 3]]]]
+    arrays = [[np.array(p) for p in seg] for seg in flat]
+    mixed = [flat[0], nested[1]]
+    want = pack_polygons(flat, 16, 16)
+    for other in (nested, arrays, mixed):
+        got = pack_polygons(other, 16, 16)
+        for a, b in zip(want[:3], got[:3]):
+            np.testing.assert_array_equal(a, b)
+    assert want[0].dtype == np.int32 and want[0].tolist()[:3] == [[1, 2], [10, 2], [9, 8]]
+    import pytest
+    with pytest.raises(ValueError):
+        pack_polygons([[[1, 2, 3]]], 16, 16)     # odd count: the reference's reshape error

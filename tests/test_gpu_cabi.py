@@ -259,3 +259,80 @@ def test_host_pointer_entries_from_several_threads():
     assert not errors, errors
     assert all(got)
     assert len(want[0][2][1]) > 0 and want[0][0][0][1] == 0
+
+
+def test_host_entry_waits_for_the_stream_that_produced_the_depth():
+    """la3d_fit_annotations_host fits on the library's private non-blocking stream; the depth it reads may only be ENQUEUED on
+    the caller's stream (a depth model's output, an upload, the odd-width padding).  The entry orders itself behind that stream:
+    a depth plane written at the end of a long chain of kernels on a side stream - on a frame of odd width, so that the padding
+    kernel sits on that stream too - must be the plane the fit sees."""
+    import torch
+
+    rs = np.random.RandomState(5)
+    H, W = 240, 427
+    anns = []
+    for i in range(6):
+        x0, y0 = int(rs.randint(20, 200)), int(rs.randint(20, 100))
+        w, h = int(rs.randint(40, 180)), int(rs.randint(40, 110))
+        anns.append({"iscrowd": 0, "bbox": [x0, y0, w, h], "category_id": 1, "area": float(w * h),
+                     "segmentation": [[x0, y0, x0 + w, y0, x0 + w, y0 + h, x0, y0 + h]]})
+    K = np.array([[300.0, 0, 213], [0, 300.0, 120], [0, 0, 1]])
+    final = torch.as_tensor(rs.uniform(0.5, 10, (H, W)).astype(np.float32), device="cuda")
+    want = la.fit_annotations(anns, (W, H), final.clone(), K, to_host=True)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    big = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+    for _ in range(3):
+        depth = torch.full((H, W), 3.0, dtype=torch.float32, device="cuda")     # (stale content the fit must not see)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            for _k in range(20):          # ~ms of queued work in front of the producer
+                big.mul_(1.0001)
+            depth.copy_(final, non_blocking=True)
+            got = la.fit_annotations(anns, (W, H), depth, K, to_host=True)
+        np.testing.assert_array_equal(got[1], want[1])
+        np.testing.assert_array_equal(got[3], want[3])
+        torch.cuda.synchronize()
+
+
+def test_host_entries_share_their_pinned_block_without_stale_completion_words():
+    """la3d_estimate_bbox_host polls a completion word inside the calling thread's pinned block; la3d_fit_annotations_host copies
+    caller data (here: polygon coordinates) over the same bytes.  A stale word equal to the next call's sequence number must not
+    end the poll before the kernel has run: in a fresh thread (sequence numbers start at 1) the polygon coordinates are all the
+    number the following estimate_bbox call will carry."""
+    import threading
+
+    import torch
+
+    import labelany3d_amd as la
+    from labelany3d_amd import util_3dbox as U
+    from oracle import la3d_oracle as O
+
+    H, W = 64, 256
+    K = np.array([[100.0, 0, 128], [0, 100.0, 32], [0, 0, 1]])
+    depth = torch.full((H, W), 2.0, dtype=torch.float32, device="cuda")
+    rs = np.random.RandomState(3)
+    clouds = [rs.randn(200, 3) * np.array([2.0, 0.5, 1.0]) + 5 for _ in range(6)]
+    errs = []
+
+    def body():
+        try:
+            torch.cuda.set_device(0)
+            for trial in range(5):
+                seq_next = 2 * trial + 2         # calls so far in this thread: 2 per trial
+                v = float(seq_next)
+                # > 90 vertex pairs of the value (byte 416 of the block is the 88th int32 of the coordinates): a degenerate polygon
+                anns = [{"iscrowd": 0, "bbox": [0, 0, 1, 1], "category_id": 1, "segmentation": [[v, v] * 120]}]
+                la.fit_annotations(anns, (W, H), depth, K, to_host=True)
+                import contextlib, io
+                with contextlib.redirect_stdout(io.StringIO()):
+                    verts, center, dims, R = U.estimate_bbox(clouds[trial], None, None)
+                ref = O.estimate_bbox(clouds[trial], None, None)
+                np.testing.assert_allclose(center, ref[1], rtol=0, atol=1e-9)
+                np.testing.assert_allclose(np.asarray(dims, float), np.asarray(ref[2], float), rtol=0, atol=1e-9)
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    t = threading.Thread(target=body)
+    t.start(); t.join()
+    assert not errs, errs[0]
