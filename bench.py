@@ -195,6 +195,21 @@ def kernel_source_sha256():
     return h.hexdigest()
 
 
+def build_identity():
+    """Which binary produced this line: the hash of the kernel sources and of the compile command embedded in the loaded libla3d.so
+    at build time (la3d_build_info) next to the hash of the sources in the tree."""
+    try:
+        from labelany3d_amd import _build
+        from labelany3d_amd._lib import LIB, lib
+        info = lib.la3d_build_info().decode()
+        _, src, cmd = info.split(":")
+        tree = _build.source_sha256()
+        return {"lib": os.path.relpath(LIB, ROOT), "lib_sources_sha256": src, "lib_compile_cmd_sha256": cmd, "tree_sources_sha256": tree,
+                "lib_built_from_tree": src == tree, "kernel_source_sha256": kernel_source_sha256()}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
+
+
 def rect_rle(rects):
     """COCO run lengths (column-major, zeros first) of the same rectangles: the --rle input format."""
     r0, c0, hh, ww = rects
@@ -291,26 +306,91 @@ def cpu_baseline(depth, masks, budget_s=8.0, max_inst=256):
     return out
 
 
+def build_inputs(args, B, device, seed, aux_seed):
+    """One resident input batch of the workload the flags name: depth, K, the masks as u8 planes (`all_masks`: always built - the
+    byte model and the stream ceiling read them) and, per flag, the run lengths / polygon parts the fit is fed instead (`masks` is
+    then None), the drawn sample indices, the area hints, the ground planes."""
+    x = {"image_index": None, "rle": None, "poly": None, "sample_idx": None, "area_hint": None, "ground": None}
+    if args.config3:
+        depth, masks, K, n_masked, x["image_index"] = make_config3(args.config3, device, seed)
+        rects = None
+    elif args.config5:
+        depth, masks, K, n_masked, rects = make_config5(B, device, seed)
+    else:
+        depth, masks, K, n_masked, rects = make_inputs(B, device, seed)
+    B = masks.shape[0]
+    x.update(depth=depth, K=K, all_masks=masks, masks=masks, n_masked=n_masked)
+    if args.subsample:
+        from labelany3d_amd import draw_sample_idx
+        counts = masks.reshape(B, -1).sum(1, dtype=torch.int64)
+        x["sample_idx"] = torch.as_tensor(draw_sample_idx(counts, np.random.RandomState(99 + aux_seed)), device=device)
+    if args.rle:
+        if rects is None:
+            raise SystemExit("--rle needs the rectangle masks of the default workload (not --config3)")
+        rc_np, ro_np = rect_rle(rects)
+        x["rle"] = (torch.as_tensor(rc_np, device=device), torch.as_tensor(ro_np, device=device))
+        x["masks"] = None
+    if args.poly:
+        if rects is None:
+            raise SystemExit("--poly needs the rectangle masks of the default workload (not --config3 / --config5)")
+        from labelany3d_amd import pack_polygons
+        r0_, c0_, hh_, ww_ = rects
+        segs = [[[int(b), int(a), int(b + w - 1), int(a), int(b + w - 1), int(a + h - 1), int(b), int(a + h - 1)]]
+                for a, b, h, w in zip(r0_, c0_, hh_, ww_)]
+        pxy, pro, pir, _, _ = pack_polygons(segs, H, W)
+        x["poly"] = tuple(torch.as_tensor(t, device=device) for t in (pxy, pro, pir))
+        x["masks"] = None
+    if args.area_hint:
+        if args.config3 or args.subsample:
+            raise SystemExit("--area-hint: private depth planes, full-mask mode only")
+        x["area_hint"] = masks.reshape(B, -1).sum(1, dtype=torch.int32)     # what the annotation's "area" field holds
+    if args.ground:     # near-level cameras: the plane normal within a few degrees of -y, as the reference's canonical upright vectors are
+        gr = np.random.RandomState(77 + aux_seed)
+        x["ground"] = torch.as_tensor(np.array([[0.02, -0.97, 0.1, 1.2]] * B) + 0.03 * gr.randn(B, 4), device=device)
+    return x
+
+
+def batch_required_bytes(args, x):
+    """(required bytes, active tiles) of one input batch: bytes this input cannot be fitted without - every mask plane once + the
+    128-B depth lines of the 32x8 tiles that hold a mask pixel once + the records (computed from the masks; with run-length /
+    polygon input the mask term is their arrays; reference-subsample mode: one 64-B sector per drawn point)."""
+    masks = x["all_masks"]
+    B = masks.shape[0]
+    req, tiles = required_bytes(masks, x.get("image_index"), args.config3)
+    if x.get("rle") is not None:
+        req += int(x["rle"][0].numel()) * 4 - B * H * W
+    if x.get("poly") is not None:
+        pxy, pro, pir = x["poly"]
+        req += int(pxy.numel()) * 4 + int(pro.numel() + pir.numel()) * 8 - B * H * W
+    if args.subsample:   # mask planes + one 64-B sector per drawn point (masks of <= 500 px: their tiles, as above) + records
+        cnt = masks.reshape(B, -1).sum(1, dtype=torch.int64)
+        big = cnt > 500
+        tiles_small = required_bytes(masks[~big], None, 0)[1] if int((~big).sum()) else 0
+        req = B * H * W + int(big.sum()) * 500 * 64 + tiles_small * 1024 + B * 39 * 8
+    return req, tiles
+
+
 class StepRunner:
     """One step = ONE la3d_fit_instances_ex call on a pre-built argument block (the steady-state call is a pure enqueue: no
-    allocation, no Python work beyond the ctypes call).  Exactly one of masks / rle / poly gives the masks; the scheduling of a
-    call travels in the block (opt_launch_order), never in process state."""
+    allocation, no Python work beyond the ctypes call).  `inputs` is a list of resident input batches (dicts: depth, K and exactly
+    one of masks / rle / poly, optional image_index / sample_idx / area_hint / ground); step k reads batch k % len(inputs) - with
+    more than one batch no two consecutive steps read the same bytes (--rotate).  The scheduling of a call travels in the block
+    (opt_launch_order), never in process state."""
 
-    def __init__(self, fitter, depth, K, masks=None, rle=None, poly=None, image_index=None, sample_idx=None, area_hint=None,
-                 one_slot=False, ground=None):
-        self.f, self.depth, self.K, self.masks, self.rle, self.poly = fitter, depth, K, masks, rle, poly
-        self.ground = ground
-        self.image_index, self.sample_idx, self.area_hint, self.one_slot = image_index, sample_idx, area_hint, one_slot
+    def __init__(self, fitter, inputs, one_slot=False):
+        self.f, self.inputs, self.one_slot = fitter, list(inputs), one_slot
         self.blocks = {}
         import ctypes as C
 
         from labelany3d_amd._lib import check, lib
         self._fit, self._byref, self._check = lib.la3d_fit_instances_ex, C.byref, check
 
-    def __call__(self, slot=0, stream=None, ws_slot=0, launch_order=None):
+    def __call__(self, slot=0, stream=None, ws_slot=0, launch_order=None, batch=None):
         if self.one_slot:
             slot = 0
-        key = (slot, ws_slot, stream.cuda_stream, launch_order)
+        if batch is None:
+            batch = slot % len(self.inputs)
+        key = (slot, ws_slot, stream.cuda_stream, launch_order, batch)
         a = self.blocks.get(key)
         if a is not None and not self.dry:      # the steady-state call: one dictionary lookup, one foreign call
             rc = self._fit(self._byref(a))
@@ -322,23 +402,25 @@ class StepRunner:
         from labelany3d_amd import options
         from labelany3d_amd._lib import FitArgs, check, lib
         if a is None:
-            f, d, k = self.f, self.depth, self.K
+            f, x = self.f, self.inputs[batch]
+            d, k = x["depth"], x["K"]
+            ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
             a = FitArgs()
             a.struct_size = C.sizeof(FitArgs)
             a.B, a.H, a.W = f.B, f.H, f.W
             a.depth, a.depth_plane_stride = d.data_ptr(), (f.H * f.W if (d.dim() == 3 and d.shape[0] > 1) else 0)
-            a.image_index = None if self.image_index is None else self.image_index.data_ptr()
-            if self.rle is not None:
-                a.rle_counts, a.rle_offsets = self.rle[0].data_ptr(), self.rle[1].data_ptr()
-            elif self.poly is not None:
-                a.poly_xy, a.ring_offsets, a.inst_rings = (t.data_ptr() for t in self.poly)
+            a.image_index = ptr(x.get("image_index"))
+            if x.get("rle") is not None:
+                a.rle_counts, a.rle_offsets = x["rle"][0].data_ptr(), x["rle"][1].data_ptr()
+            elif x.get("poly") is not None:
+                a.poly_xy, a.ring_offsets, a.inst_rings = (t.data_ptr() for t in x["poly"])
             else:
-                a.mask = self.masks.data_ptr()
+                a.mask = x["masks"].data_ptr()
             a.K, a.k_stride = k.data_ptr(), (9 if (k.dim() == 3 and k.shape[0] > 1) else 0)
             a.filter_boundary = -1
-            a.ground = None if self.ground is None else self.ground.data_ptr()
-            a.sample_idx = None if self.sample_idx is None else self.sample_idx.data_ptr()
-            a.area_hint = None if self.area_hint is None else self.area_hint.data_ptr()
+            a.ground = ptr(x.get("ground"))
+            a.sample_idx = ptr(x.get("sample_idx"))
+            a.area_hint = ptr(x.get("area_hint"))
             a.out, a.status, a.aux = f.boxes[slot].data_ptr(), f.status[slot].data_ptr(), f.aux[slot].data_ptr()
             a.workspace, a.stream = f.workspace[ws_slot].data_ptr(), stream.cuda_stream
             a.opt_launch_order = options.ORDER[launch_order]
@@ -705,6 +787,9 @@ def main():
                     help="host-resident scenes -> records on the host through labelany3d_amd.fit_scenes (never the headline): boxes/s with the "
                          "split pack / H2D / fit / D2H and the host-link ceiling")
     ap.add_argument("--batch-images", type=int, default=256, help="--end-to-end: images per fit launch")
+    ap.add_argument("--rotate", type=int, default=3, metavar="R",
+                    help="distinct resident input batches the timed steps rotate through (step k reads batch k %% R; default 3 = 5.6 GB at "
+                         "B = 1024; 1 = every step reads the same batch, the protocol of rounds 1-5; falls back to 1 when memory is short)")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the independent steps are issued on round-robin (1 = strictly serial steps)")
     args = ap.parse_args()
@@ -763,50 +848,22 @@ def main():
     from labelany3d_amd.shard import gather_boxes
 
     B, steps, warmup = args.batch, args.steps, args.warmup
-    image_index = None
-    if args.config3:
-        depth, masks, K, n_masked, image_index = make_config3(args.config3, device, 1234 + rank)
-        B = masks.shape[0]
-        rects = None
-    elif args.config5:
-        depth, masks, K, n_masked, rects = make_config5(B, device, 1234 + rank)
-    else:
-        depth, masks, K, n_masked, rects = make_inputs(B, device, 1234 + rank)
+    # Input batches resident in HBM before the clock starts.  Batch 0 is the batch of every earlier round (seed 1234 + rank); with
+    # --rotate R (default 3; 1 = the old protocol) R - 1 more batches of the same distribution follow and timed step k reads batch
+    # k % R: no step finds the bytes of the step before it anywhere on the chip (1.9 GB per batch against 256 MB of Infinity Cache).
+    R = 1 if args.config3 else max(1, args.rotate)
+    free_b = torch.cuda.mem_get_info(device)[0]
+    if R > 1 and R * B * H * W * 5 * 1.15 + steps * B * 400 > 0.8 * free_b:
+        R = 1
+    inputs = [build_inputs(args, B, device, 1234 + rank + 7919 * r, rank + 31 * r) for r in range(R)]
+    x0 = inputs[0]
+    depth, masks, image_index = x0["depth"], x0["all_masks"], x0.get("image_index")
+    B = masks.shape[0]
+    n_masked = sum(x["n_masked"] for x in inputs) / R
     fitter = InstanceFitter(B, H, W, device, slots=(1 if args.config3 else max(steps, 1)), ws_slots=max(args.streams, 2))
-    sample_idx = None
-    if args.subsample:
-        from labelany3d_amd import draw_sample_idx
-        counts = masks.reshape(B, -1).sum(1, dtype=torch.int64)
-        sample_idx = torch.as_tensor(draw_sample_idx(counts, np.random.RandomState(99 + rank)), device=device)
     stream = torch.cuda.current_stream()
     streams = [stream] + [torch.cuda.Stream(device=device) for _ in range(max(args.streams, 1) - 1)]
-    rle_c = rle_o = pxy = pro = pir = None
-    if args.rle:
-        if rects is None:
-            raise SystemExit("--rle needs the rectangle masks of the default workload (not --config3)")
-        rc_np, ro_np = rect_rle(rects)
-        rle_c, rle_o = torch.as_tensor(rc_np, device=device), torch.as_tensor(ro_np, device=device)
-    if args.poly:
-        if rects is None:
-            raise SystemExit("--poly needs the rectangle masks of the default workload (not --config3 / --config5)")
-        from labelany3d_amd import pack_polygons
-        r0_, c0_, hh_, ww_ = rects
-        segs = [[[int(b), int(a), int(b + w - 1), int(a), int(b + w - 1), int(a + h - 1), int(b), int(a + h - 1)]]
-                for a, b, h, w in zip(r0_, c0_, hh_, ww_)]
-        pxy, pro, pir, _, _ = pack_polygons(segs, H, W)
-        pxy, pro, pir = (torch.as_tensor(x, device=device) for x in (pxy, pro, pir))
-    areas = None
-    if args.area_hint:
-        if args.config3 or args.subsample:
-            raise SystemExit("--area-hint: private depth planes, full-mask mode only")
-        areas = masks.reshape(B, -1).sum(1, dtype=torch.int32)     # what the annotation's "area" field holds
-    ground = None
-    if args.ground:     # near-level cameras: the plane normal within a few degrees of -y, as the reference's canonical upright vectors are
-        gr = np.random.RandomState(77 + rank)
-        ground = torch.as_tensor(np.array([[0.02, -0.97, 0.1, 1.2]] * B) + 0.03 * gr.randn(B, 4), device=device)
-    run = StepRunner(fitter, depth, K, masks=None if (args.rle or args.poly) else masks, rle=(rle_c, rle_o) if args.rle else None,
-                     poly=(pxy, pro, pir) if args.poly else None, image_index=image_index, sample_idx=sample_idx, area_hint=areas,
-                     one_slot=bool(args.config3), ground=ground)
+    run = StepRunner(fitter, inputs, one_slot=bool(args.config3))
 
     def barrier():
         torch.cuda.synchronize()
@@ -818,8 +875,8 @@ def main():
     # a 20-step timed region entered from an idle chip reads ~5 % slower, profiles/r03/exp_step_ramp.py)
     stream_GBps, _, ceiling_launches = measured_stream_ceiling(masks)
     run.prepare([dict(slot=k, stream=streams[k % len(streams)], ws_slot=(k % len(streams)) if len(streams) > 1 else 0) for k in range(steps)])
-    for _ in range(warmup):
-        run(slot=0, stream=stream)
+    for w_ in range(warmup):
+        run(slot=0, stream=stream, batch=w_ % R)
     if dist is not None:  # warm the communicator outside the timed region
         gather_boxes(fitter.boxes[:1].reshape(-1, 39), fitter.status[:1].reshape(-1), dst=0, counts=[B] * world)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -855,6 +912,17 @@ def main():
     # secondary figure, AFTER the timed region (round 5; round 4 ran it before the warm-up, which conditioned the chip's clocks for
     # the timed steps - 2-4 us per step of the round-4 headline): the SAME serial step in back-to-back loops of 100 (>= 40 ms of
     # GPU time, HIP events on the launch stream) - what a caller that keeps fitting batches sees.
+    # secondary, right behind the timed region: the same K serial steps all reading batch 0 (the protocol of rounds 1-5), HIP events
+    same_batch_ms = None
+    if R > 1 and len(streams) == 1:
+        sb0, sb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        sb0.record(stream)
+        for k in range(steps):
+            run(slot=k, stream=stream, batch=0)
+        sb1.record(stream)
+        torch.cuda.synchronize()
+        same_batch_ms = sb0.elapsed_time(sb1) / steps
     steady = None
     if not args.config3 and len(streams) == 1 and not args.no_steady:
         se0, se1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -863,7 +931,7 @@ def main():
             torch.cuda.synchronize()
             se0.record(stream)
             for _k in range(100):
-                run(slot=0, stream=stream)
+                run(slot=0, stream=stream, batch=_k % R)
             se1.record(stream)
             torch.cuda.synchronize()
             ms = se0.elapsed_time(se1) / 100
@@ -881,7 +949,7 @@ def main():
         s2 = [stream, torch.cuda.Stream(device=device)]
         run.prepare([dict(slot=k, stream=s2[k % 2], ws_slot=k % 2, launch_order=False) for k in range(steps)])
         for k in range(max(4, warmup // 4)):
-            run(slot=0, stream=s2[k % 2], ws_slot=k % 2, launch_order=False)
+            run(slot=0, stream=s2[k % 2], ws_slot=k % 2, launch_order=False, batch=k % R)
         barrier()
         p0 = time.perf_counter()
         s2[1].wait_stream(stream)
@@ -914,16 +982,10 @@ def main():
             alg_bytes = args.config3 * H * W * 4 + B * (H * W + 39 * 8)
         # bytes this input cannot be fitted without: every mask plane once + the 128-B depth lines of the 32x8 tiles that hold
         # a mask pixel once + the records (computed from the masks; with run-length input the mask term is the run lengths)
-        req_bytes, active_tiles = required_bytes(masks, image_index, args.config3)
-        if args.rle:
-            req_bytes += int(rle_c.numel()) * 4 - B * H * W
-        if args.poly:
-            req_bytes += int(pxy.numel()) * 4 + int(pro.numel() + pir.numel()) * 8 - B * H * W
-        if args.subsample:   # mask planes + one 64-B sector per drawn point (masks of <= 500 px: their tiles, as above) + records
-            cnt = masks.reshape(B, -1).sum(1, dtype=torch.int64)
-            big = cnt > 500
-            tiles_small = required_bytes(masks[~big], None, 0)[1] if int((~big).sum()) else 0
-            req_bytes = B * H * W + int(big.sum()) * 500 * 64 + tiles_small * 1024 + B * 39 * 8
+        per_batch = [batch_required_bytes(args, x) for x in inputs]
+        # (the timed steps read batch k % R: the per-launch figure is their average)
+        req_bytes = sum(per_batch[k % R][0] for k in range(steps)) / steps
+        active_tiles = sum(per_batch[k % R][1] for k in range(steps)) / steps
         step_s = kern_ms * 1e-3
         achieved = req_bytes / step_s / 1e9
         traffic, traffic_src, traffic_stale, traffic_kernel_ns, traffic_kernel_ns_long = None, None, None, None, None
@@ -982,7 +1044,7 @@ def main():
             "value_fit_only": (world * steps * B / (kern_ms * 1e-3 * steps)) if dist is not None else None,
             "untimed_launches_before_timed_region": {"fit_steps": warmup, "other_kernels": ceiling_launches,
                                                      "other_kernels_what": "la3d_mask_counts (the pure-reader stream ceiling, a different kernel)"},
-            "methodology": "r05: stream-ceiling measurement, W warm-up steps, then the K timed steps between two barriers (N > 1: the one "
+            "methodology": "r06: as r05, and timed step k reads resident input batch k % R (--rotate, default 3; `rotation` holds the same-batch figure). r05: stream-ceiling measurement, W warm-up steps, then the K timed steps between two barriers (N > 1: the one "
                            "final gather inside the region, as in rounds 1-3); steady-state and pipelined loops run AFTER the timed region "
                            "(round 4 ran 100-400 steady-state steps before the warm-up)",
             "higher_is_better": True,
@@ -1002,6 +1064,7 @@ def main():
                 "mask_input": ("COCO run lengths (la3d_fit_instances_rle) — not the config-2 format" if args.rle else
                                "polygon parts (la3d_fit_instances_poly), 4-vertex rings — not the config-2 format" if args.poly else "u8 planes"),
                 "streams": len(streams),
+                "input_batches": R,
                 "default_steps": "1000 timed steps / 50 warm-up (0.11 s timed region); any --steps works",
             },
             "roofline": {
@@ -1050,6 +1113,16 @@ def main():
                         "step's VALU instructions (fp64 ~5.2 cycles per wave-instruction), from the shader-side counters of the same profile set.",
             },
         }
+        out["rotation"] = {
+            "batches": R, "resident_input_bytes": R * int(depth.numel() * 4 + masks.numel()),
+            "required_bytes_per_batch": [pb[0] for pb in per_batch],
+            "same_batch_ms_per_step": same_batch_ms,
+            "same_batch_value": (world * B / (same_batch_ms * 1e-3)) if same_batch_ms else None,
+            "note": "timed step k reads resident batch k % batches (same distribution, different seeds: batch 0 is the batch of rounds 1-5), so "
+                    "no step re-reads the bytes of its predecessor; same_batch_* = the same K serial steps all on batch 0, HIP events, run "
+                    "right after the timed region (rank 0's figure x ranks) - the two agree when no cache level helps the repeated read",
+        }
+        out["build"] = build_identity()
         if steady is not None:
             out["steady_state"] = {
                 "value": world * B / (steady[0] * 1e-3), "unit": "boxes/s", "ms_per_step": steady[0], "steps_run": steady[1],
@@ -1066,6 +1139,13 @@ def main():
             }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(depth, masks)
+            # the figure not to confuse it with: the REFERENCE's own loop amortises depth_to_points per image (one call per frame,
+            # src/batch_scripts/depth.py:154) - the port above unprojects a private plane per instance (34 ms each) as config 2 defines it
+            out["cpu_baseline"]["reference_probe"] = {
+                "value": 573.0, "unit": "boxes/s/core", "ms_per_instance": 1.75,
+                "what": "the reference's own functions (depth_to_points amortised per image + pts[mask] + estimate_bbox) on 128 config-2 "
+                        "masks, single thread, measured in the survey container (8 vCPU Xeon 2.10 GHz) - BASELINE.md section 2; "
+                        "not measured on this box: /root/reference does not travel"}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -56,6 +56,8 @@ extern "C" {
 #define LA3D_HINT_SMALL_CLOUDS 0x100
 
 int la3d_version(void);
+/* "LA3D_BUILD_INFO:<sha256 of the sources this library was compiled from>:<sha256 of the compile command>" - static storage. */
+const char* la3d_build_info(void);
 const char* la3d_last_error(void);
 
 /* Replaces depth_to_points(depth, K, R, t) — reference src/util.py:52-75 (caller

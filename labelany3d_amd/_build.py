@@ -14,21 +14,63 @@ INCLUDE = os.path.join(ROOT, "include")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
 
 
+def source_sha256() -> str:
+    """Hash of everything libla3d.so is compiled from (sources and headers, fixed order, names included)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def compile_cmd_sha256() -> str:
+    """Hash of the compile command: the flags and the compiler's own version line."""
+    import hashlib
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    try:
+        ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.splitlines()[0]
+    except Exception:  # noqa: BLE001
+        ver = "unknown"
+    return hashlib.sha256((" ".join(HIPCC_FLAGS) + "|" + ver).encode()).hexdigest()
+
+
+def embedded_info(lib_path: str = LIB):
+    """(sources hash, compile-command hash) the library at lib_path was built from - read from the file's bytes (the string
+    la3d_build_info() returns), without loading it - or None for a library that carries none."""
+    import re
+    try:
+        data = open(lib_path, "rb").read()
+    except OSError:
+        return None
+    m = re.search(rb"LA3D_BUILD_INFO:([0-9a-f]{64}):([0-9a-f]{64})", data)
+    return (m.group(1).decode(), m.group(2).decode()) if m else None
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the sources of csrc/ for gfx950 into lib/libla3d.so (in-tree, so it travels with the repo): one object per
-    translation unit, compiled side by side, then one link."""
+    translation unit, compiled side by side, then one link.  The hash of the sources and of the compile command is compiled INTO
+    the library (la3d_build_info); an existing library is reused only when the hash it carries is the hash of the tree's sources
+    (not by file time: a library that travelled with a snapshot proves what it was built from)."""
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    newest = max(os.path.getmtime(f) for f in SOURCES + HEADERS)
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest:
-        return LIB
+    src_hash = source_sha256()
+    if not force and os.path.exists(LIB):
+        have = embedded_info(LIB)
+        if have is not None and have[0] == src_hash:
+            if verbose:
+                print(f"libla3d.so is current: built from sources sha256 {src_hash[:16]}.. (compile command {have[1][:16]}..)")
+            return LIB
     import tempfile
     from concurrent.futures import ThreadPoolExecutor
 
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd_hash = compile_cmd_sha256()
     flags = [f for f in HIPCC_FLAGS if f != "-shared"]
     with tempfile.TemporaryDirectory(prefix="la3d_build_") as tmp:
         objs = [os.path.join(tmp, os.path.splitext(os.path.basename(src))[0] + ".o") for src in SOURCES]
         cmds = [[hipcc, *flags, "-I", INCLUDE, "-c", src, "-o", obj] for src, obj in zip(SOURCES, objs)]
+        # the host-only translation unit carries the identity string
+        cmds[-1][1:1] = [f'-DLA3D_BUILD_SOURCES="{src_hash}"', f'-DLA3D_BUILD_CMD="{cmd_hash}"']
         if verbose:
             for c in cmds:
                 print(" ".join(c))
@@ -40,6 +82,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(link))
         subprocess.run(link, check=True)
+    if verbose:
+        print(f"libla3d.so built from sources sha256 {src_hash[:16]}.. with compile command {cmd_hash[:16]}..")
+    assert embedded_info(LIB) == (src_hash, cmd_hash), "the library does not carry the identity it was built with"
     return LIB
 
 

@@ -80,6 +80,7 @@ _SIGS = {
     "la3d_project_boxes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int, C.c_double, C.c_double,
                                      C.c_void_p, C.c_void_p]),
     "la3d_iou_matrix": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "la3d_build_info": (C.c_char_p, []),
     "la3d_rle_from_string_host": (C.c_int, [C.c_char_p, C.c_int64, C.POINTER(C.c_int32), C.c_int]),
     "la3d_estimate_bbox_host": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
     "la3d_unproject_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),

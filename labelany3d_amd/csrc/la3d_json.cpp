@@ -151,3 +151,11 @@ int la3d_gather_planes_host(const void* const* src, int64_t n, int64_t bytes_eac
 }
 
 }  // extern "C"
+
+// Identity of this binary: "LA3D_BUILD_INFO:<sha256 of the sources and headers>:<sha256 of the compile command>", put in by the build
+// recipe (labelany3d_amd/_build.py) - what a measurement quotes to say which code produced it.
+#ifndef LA3D_BUILD_SOURCES
+#define LA3D_BUILD_SOURCES "unknown"
+#define LA3D_BUILD_CMD "unknown"
+#endif
+extern "C" const char* la3d_build_info(void) { return "LA3D_BUILD_INFO:" LA3D_BUILD_SOURCES ":" LA3D_BUILD_CMD; }

@@ -373,3 +373,19 @@ def test_pack_polygons_accepts_every_form_the_reference_accepts():
     import pytest
     with pytest.raises(ValueError):
         pack_polygons([[[1, 2, 3]]], 16, 16)     # odd count: the reference's reshape error
+
+
+def test_library_carries_the_identity_of_its_sources():
+    """la3d_build_info(): the hash of the sources the loaded library was compiled from = the hash of the tree's sources (the
+    build recipe reuses a library only then), readable from the file without loading it."""
+    import importlib.util
+
+    from labelany3d_amd import _lib
+
+    spec = importlib.util.spec_from_file_location("_la3d_build_t", os.path.join(ROOT, "labelany3d_amd", "_build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    tag, src, cmd = _lib.lib.la3d_build_info().decode().split(":")
+    assert tag == "LA3D_BUILD_INFO" and len(src) == 64 and len(cmd) == 64
+    assert b.embedded_info(_lib.LIB) == (src, cmd)
+    assert src == b.source_sha256(), "libla3d.so was not built from the sources in the tree: run __graft_entry__.build()"

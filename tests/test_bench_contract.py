@@ -58,6 +58,32 @@ def test_bench_prints_one_contract_line():
     assert v is None or (0.0 < v["frac_of_step"] < 1.0 and v["stale"] in (True, False) and v["wave_instructions_per_step"] > 1e6)
     assert abs(d["value"] - 5 * 1024 / (d["ms_per_step"] * 5e-3)) / d["value"] < 1e-6
     assert d["value"] > 2.08e6   # BASELINE target: 40 % of the HBM-read roofline
+    # round 6: the timed steps rotate through distinct resident input batches; the line says which binary produced it
+    rot = d["rotation"]
+    assert rot["batches"] == 3 and d["config"]["input_batches"] == 3 and len(rot["required_bytes_per_batch"]) == 3
+    assert len(set(rot["required_bytes_per_batch"])) == 3                    # different masks, same distribution
+    mean_req = sum(rot["required_bytes_per_batch"][k % 3] for k in range(5)) / 5
+    assert abs(r["required_bytes_per_launch"] - mean_req) < 1e-6 * mean_req
+    assert rot["same_batch_ms_per_step"] > 0 and abs(rot["same_batch_ms_per_step"] / r["avg_launch_ms"] - 1) < 0.25
+    b = d["build"]
+    assert len(b["lib_sources_sha256"]) == 64 and len(b["lib_compile_cmd_sha256"]) == 64 and b["lib_built_from_tree"] is True
+    assert b["kernel_source_sha256"] == __import__("bench").kernel_source_sha256()
+
+
+@pytest.mark.gpu
+def test_bench_rotate_1_is_the_old_protocol_and_cpu_baseline_names_the_reference_probe():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--rotate", "1", "--no-steady",
+                          "--no-pipelined", "--batch", "256"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["rotation"]["batches"] == 1 and d["rotation"]["same_batch_ms_per_step"] is None
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+    assert cb["reference_probe"]["value"] == 573.0 and cb["reference_probe"]["unit"] == "boxes/s/core"
 
 
 def test_required_bytes_model():

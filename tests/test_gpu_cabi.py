@@ -268,6 +268,8 @@ def test_host_entry_waits_for_the_stream_that_produced_the_depth():
     kernel sits on that stream too - must be the plane the fit sees."""
     import torch
 
+    import labelany3d_amd as la
+
     rs = np.random.RandomState(5)
     H, W = 240, 427
     anns = []
