@@ -95,8 +95,11 @@ int la3d_pad_rows(const float* src, int64_t rows, int W, int Wp, float* dst, voi
 #define LA3D_ENGINE_INSTANCE 1        /* one workgroup per instance */
 #define LA3D_ENGINE_SPLIT 2           /* band scan + tile-range-balanced passes (falls back to the instance engine where it does not apply) */
 #define LA3D_ENGINE_BAND 3            /* two (or four) workgroups per instance, one per band of tile rows (u8 planes, tiled frames; falls back likewise) */
-#define LA3D_ENGINE_ROWS 4            /* round 5: up to sixteen workgroups per instance, one per band of rows, partial sums merged by a second short
-                                         launch (u8 planes, no ground array, at most 512 instances; falls back likewise) */
+#define LA3D_ENGINE_ROWS 4            /* up to sixteen workgroups per instance, one per band of rows (u8 planes, no ground array, at most 512
+                                         instances; falls back likewise).  Round 6: ONE launch - the band that finishes last merges its
+                                         instance's partial sums and writes the record */
+#define LA3D_ENGINE_ROWS2 5           /* the row engine in its round-5 form: the partial sums merged by a second short launch (what a call
+                                         captured into a HIP graph takes anyway) */
 #define LA3D_ORDER_DEFAULT 0          /* size-balanced launch order for 256 < B <= 3 resident sets; the sort keys are estimated inside the
                                          fit kernel and handed over through the workspace, so ONE workspace serves ONE call at a time, and
                                          several ORDERED calls running concurrently on different streams slow each other down (a call whose

@@ -42,7 +42,8 @@ const Config& config() {
     Config k;
     const char* e = getenv("LA3D_ENGINE");
     k.engine = (e && !strcmp(e, "instance")) ? LA3D_ENGINE_INSTANCE : (e && !strcmp(e, "split")) ? LA3D_ENGINE_SPLIT
-             : (e && !strcmp(e, "band")) ? LA3D_ENGINE_BAND : (e && !strcmp(e, "rows")) ? LA3D_ENGINE_ROWS : LA3D_ENGINE_DEFAULT;
+             : (e && !strcmp(e, "band")) ? LA3D_ENGINE_BAND : (e && !strcmp(e, "rows")) ? LA3D_ENGINE_ROWS
+             : (e && !strcmp(e, "rows2")) ? LA3D_ENGINE_ROWS2 : LA3D_ENGINE_DEFAULT;
     e = getenv("LA3D_BANDS");
     k.bands = (e && (atoi(e) == 4 || atoi(e) == 2)) ? atoi(e) : 0;
     e = getenv("LA3D_BAND_DEFAULT");      // 0: the band engine only when asked for (LA3D_ENGINE=band / opt_engine)
@@ -50,7 +51,12 @@ const Config& config() {
     e = getenv("LA3D_BAND_MAXB");
     k.band_maxb = (e && atoi(e) > 0) ? atoi(e) : 256;
     e = getenv("LA3D_ROWS_MAXB");
-    k.rows_maxb = e ? atoi(e) : 192;   // largest batch the row engine takes by default (0: never); above, one workgroup per instance is as fast
+    k.rows_maxb = e ? atoi(e) : 160;   // largest batch the row engine takes by default (0: never); above, one workgroup per instance is as fast
+                                       // (round 6, us per call, instance | rows: B = 128: 37.1 | 30.3; 192: 39.8 | 41.1 - profiles/r06/r06_rows_engine.txt)
+    e = getenv("LA3D_ROWS_FUSED");        // 0: the two-launch form of the row engine (fit_rows_kernel + merge_rows_kernel)
+    k.rows_fused = !(e && e[0] == '0');
+    e = getenv("LA3D_ROWS_WGS");          // workgroups the row engine spreads a batch over, at most
+    k.rows_wgs = (e && atoi(e) > 0) ? atoi(e) : 640;
     e = getenv("LA3D_BALANCE");
     k.balance = !(e && e[0] == '0');
     e = getenv("LA3D_BALANCE_ROUNDS");
@@ -1779,12 +1785,42 @@ __device__ inline unsigned tagged_arrive(unsigned long long* w, unsigned long lo
     old = prev;
   }
 }
+// The same counter for MANY arrivals per word at about the same time (the row engine: up to sixteen bands of an instance finish
+// together; the CAS loop above then retries once per competitor - measured 20 us for sixteen): once the word carries this call's
+// tag an arrival is ONE atomic add; only the arrivals that still see a foreign tag compete for the reset.
+__device__ inline unsigned tagged_arrive_many(unsigned long long* w, unsigned long long tag) {
+  while (true) {
+    const unsigned long long old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((old >> 16) == tag) return (unsigned)(atomicAdd(w, 1ull) & 0xffffull) + 1u;   // (the tag stays for the rest of the call)
+    if (atomicCAS(w, old, (tag << 16) + 1ull) == old) return 1u;                       // this arrival opened the call's count
+  }
+}
 __device__ inline unsigned tagged_count(const unsigned long long* w, unsigned long long tag) {
   const unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return (v >> 16) == tag ? (unsigned)(v & 0xffffull) : 0u;
 }
 __device__ inline void st_agent(double* q, double v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline double ld_agent(const double* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// 16-byte write-through store (sc0 sc1): what one workgroup hands another through global memory without a release fence - scalar
+// sc1 stores are one fabric write each (a dword costs ~6 x the time per byte of a dwordx4: MI355X_MICROARCH.md, "stores of each
+// flavour"), so exchanged arrays go out in 16-byte granules.  (The s_nop keeps the data registers untouched while the store reads them.)
+__device__ inline void st16_through(void* q, uint4 v) {
+  const u32x4 w = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(q), "v"(w) : "memory");
+}
+// Four independent 16-byte loads of such data in flight at once, then one wait: the compiler puts an s_waitcnt vmcnt(0) behind EVERY
+// agent-scope atomic load (measured: the merge of sixteen bands through __hip_atomic_load took 20 us), and it cannot see into inline
+// assembly, so the wait is part of the block.  (Early-clobber outputs: no result register doubles as a later address.)
+__device__ inline void ld16x4_through(const void* p0, const void* p1, const void* p2, const void* p3, u32x4* a, u32x4* b, u32x4* c, u32x4* d) {
+  u32x4 r0, r1, r2, r3;
+  asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\t"
+               "global_load_dwordx4 %1, %5, off sc0 sc1\n\t"
+               "global_load_dwordx4 %2, %6, off sc0 sc1\n\t"
+               "global_load_dwordx4 %3, %7, off sc0 sc1\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+  *a = r0; *b = r1; *c = r2; *d = r3;
+}
 
 // Band moments -> instance moments -> status / axis, for every band of the instance alike.  Thread 0 publishes this band's
 // partial record, waits for the other bands of the instance, then sums the NB records IN BAND ORDER (its own re-read from
@@ -2408,8 +2444,9 @@ inline int retain_steps(const FitParams& p) {
 // instance with the generic row-linear two-pass walk (what the band engine's take-over uses): slow, rare, never a dropped box.
 // ------------------------------------------------------------------------------------------
 constexpr int ROWS_NB_MAX = 16;
-constexpr int ROWS_PART_D = 20;   // doubles per (instance, band): Sx, Sz, Sxx, Sxz, Szz | ymin, ymax | mask pixels | flag | pad | M[9] | pad
+constexpr int ROWS_PART_D = 20;   // doubles per (instance, band): Sx, Sz, Sxx, Sxz, Szz | ymin, ymax | mask pixels (+ ROWS_FLAG) | pad[2] | M[9] | pad
 constexpr int ROWS_MAX_B = 512;
+constexpr double ROWS_FLAG = 1099511627776.0;   // 2^40, added to a band's pixel count: "this band could not take the single pass"
 
 struct RowsArgs {
   int nb;           // bands per instance (the last ones may be shorter; every band holds at least one tile row)
@@ -2417,6 +2454,10 @@ struct RowsArgs {
   int bits_bytes;   // band bit image + per-column ranges (16-aligned): LDS in front of Shared
   double* part;     // [B][nb][ROWS_PART_D]
   unsigned* col;    // [B][nb][2 W]: colmin | colmax of the band
+  // round 6, the ONE-launch form: the band workgroup that arrives LAST at its instance's counter merges the instance (nobody ever
+  // waits); arrive = [B] tagged arrival words (tagged_arrive: never cleared), null = the two-launch form (merge_rows_kernel)
+  unsigned long long* arrive;
+  unsigned long long tag;
 };
 
 // host: bands for a batch of B instances on an H x W frame; false = the row engine does not apply
@@ -2424,9 +2465,14 @@ inline bool rows_plan(int B, int H, int W, RowsArgs* ra) {
   if (B < 1 || B > ROWS_MAX_B || W % 32 != 0 || W / 32 > 255 || H < 16) return false;
   const int nty = (H + 7) / 8;   // (a frame height that is not a multiple of 8 - COCO's 427 - leaves the last band a partial tile row)
   int nb = ROWS_NB_MAX;
-  // about 500-640 workgroups in all (profiles/r05/r05_rows_engine.txt: B = 64 / 128 / 192, us per call with at most 256 | 512 | 1024 |
-  // 2048 workgroups: 24.4 | 24.0 | 27.9 | 27.9; 32.7 | 30.0 | 33.1 | 36.8; 38.2 | 38.0 | 40.7 | 39.8)
-  while (nb > 2 && B * nb > 640) nb >>= 1;
+  // two-launch form (round 5): about 500-640 workgroups in all (profiles/r05/r05_rows_engine.txt: B = 64 / 128 / 192, us per call with
+  // at most 256 | 512 | 1024 | 2048 workgroups: 24.4 | 24.0 | 27.9 | 27.9; 32.7 | 30.0 | 33.1 | 36.8; 38.2 | 38.0 | 40.7 | 39.8).
+  // The one-launch form (round 6) keeps the plan: with a full resident round (1024 workgroups) B = 64 takes sixteen bands per instance
+  // and 39.4 us instead of 25.0, and above ~170 instances more bands per instance do not help at all - B = 256 as 2 / 4 / 8 bands:
+  // 46.2 / 47.6 / 60.7 us against 44.3 with one workgroup per instance (profiles/r06/r06_rows_engine.txt): the bands of a call stream,
+  // list, walk and merge in lockstep, so the call lasts (chain of one band) + (bytes / bandwidth) however fine the bands are.
+  const int wg_cap = config().rows_wgs;
+  while (nb > 2 && B * nb > wg_cap) nb >>= 1;
   int trows = (nty + nb - 1) / nb;
   if (trows < 2) trows = 2;                          // (a band of one tile row is all fixed cost)
   nb = (nty + trows - 1) / trows;
@@ -2439,7 +2485,123 @@ inline bool rows_plan(int B, int H, int W, RowsArgs* ra) {
 inline size_t rows_workspace_bytes(int B, int H, int W) {
   RowsArgs ra;
   if (!rows_plan(B, H, W, &ra)) return 0;
-  return (size_t)B * ra.nb * ROWS_PART_D * 8 + (size_t)B * ra.nb * 2 * W * 4 + 256;
+  return (((size_t)B * ra.nb * ROWS_PART_D * 8 + 255) & ~(size_t)255) + (((size_t)B * ra.nb * 2 * W * 4 + 255) & ~(size_t)255) + (size_t)B * 8 + 256;
+}
+
+// The plainest walk over one instance: thread t visits pixels t, t + NT, ... of the u8 plane, one at a time.  PASS 0: count and
+// moments of (x', z'); PASS 1: the six extents (A0 / A1 / A2 as in `sweep`).  Used where a path is rare and registers are scarce.
+template <int PASS>
+__device__ inline void sweep_plain(const FitParams& p, const float* __restrict__ dpl, const unsigned char* __restrict__ mpl,
+                                   const double* A0, const double* A1, const double* A2, int tid, double* acc, int* cnt, int* nmask) {
+#pragma clang loop unroll(disable) vectorize(disable)
+  for (int i = tid; i < p.HW; i += NT) {
+    if (!mpl[i]) continue;
+    if (PASS == 0) *nmask += 1;
+    const float df = dpl[i];
+    if (!finite_f32(df)) continue;
+    unsigned u, v;
+    pix_uv((unsigned)i, p.W, p.rcpW, &u, &v);
+    const double ud = (double)u, vd = (double)v, d = (double)df;
+    const double x = d * fma(A0[0], ud, fma(A0[1], vd, A0[2])), z = d * fma(A2[0], ud, fma(A2[1], vd, A2[2]));
+    if (PASS == 0) {
+      acc[0] += x; acc[1] += z;
+      acc[2] = fma(x, x, acc[2]); acc[3] = fma(x, z, acc[3]); acc[4] = fma(z, z, acc[4]);
+      *cnt += 1;
+    } else {
+      const double y = d * fma(A1[0], ud, fma(A1[1], vd, A1[2]));
+      acc[0] = dmin(acc[0], x); acc[1] = dmax(acc[1], x);
+      acc[2] = dmin(acc[2], y); acc[3] = dmax(acc[3], y);
+      acc[4] = dmin(acc[4], z); acc[5] = dmax(acc[5], z);
+    }
+  }
+}
+
+// The merge of one instance by one workgroup: the partial records of its nb bands (band b in lane b of wave 0: the fixed tree of
+// stage_moments_to_axis adds them - the same operands in the same order whichever workgroup merges) and the bands' per-column
+// depth ranges (min / max INTO mcol: LDS, 2 W words, holding either the merging band's own ranges or the identities) -> status,
+// axis, extents, record: the instance engine's stages.  Everything another workgroup wrote is read with agent-scope loads.
+template <bool XCH>
+__device__ inline void rows_merge(Shared* sh, const FitParams& p, const RowsArgs& ra, int inst, int img, unsigned* mcol, int tid,
+                                  int wave, int lane) {
+  // XCH: the data was written by other workgroups of THIS launch with 16-byte write-through stores and is loaded the same way,
+  // four granules per thread in flight (ld16x4_through); else (the merge launch) plain loads
+  const int W = p.W;
+  const double* part = ra.part + (long long)inst * ra.nb * ROWS_PART_D;
+  const unsigned* gc = ra.col + (long long)inst * ra.nb * 2 * W;
+  // the per-column ranges first (the longest chain of loads).  Work item = (16-byte granule g of [colmin W | colmax W], four bands):
+  // min / max of the four, folded into mcol with LDS atomics (a band index past the last band repeats the last one: harmless)
+  const int ngran = W / 2, nq = (ra.nb + 3) >> 2;
+  for (int it = tid; it < ngran * nq; it += NT) {
+    const int bq = it / ngran, g = it - bq * ngran;
+    const bool is_max = 2 * g >= ngran;
+    const u32x4* src = reinterpret_cast<const u32x4*>(gc) + g;
+    const long long bs = (long long)W / 2;   // granules per band
+    const int b0 = bq * 4, b1 = min(b0 + 1, ra.nb - 1), b2 = min(b0 + 2, ra.nb - 1), b3 = min(b0 + 3, ra.nb - 1);
+    u32x4 x0, x1, x2, x3;
+    if (XCH) ld16x4_through(src + b0 * bs, src + b1 * bs, src + b2 * bs, src + b3 * bs, &x0, &x1, &x2, &x3);
+    else { x0 = src[b0 * bs]; x1 = src[b1 * bs]; x2 = src[b2 * bs]; x3 = src[b3 * bs]; }
+    unsigned* dst = mcol + 4 * g;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (is_max) atomicMax(dst + k, max(max(x0[k], x1[k]), max(x2[k], x3[k])));
+      else atomicMin(dst + k, min(min(x0[k], x1[k]), min(x2[k], x3[k])));
+    }
+  }
+  if (!XCH && tid < 9) sh->M[tid] = part[10 + tid];              // band 0's camera (every band computed the same one; a band
+                                                                  // that merges keeps its own: the same expression of the same K)
+  else if (tid >= 9 && tid < 18) sh->Rg[tid - 9] = ((tid - 9) % 4 == 0) ? 1.0 : 0.0;   // no ground array: the identity (ground_rotation(nullptr))
+  if (tid == 18) { sh->bad_ground = 0; sh->order_inst = inst; sh->sep_bad = 0; }
+  double acc[5] = {0, 0, 0, 0, 0}, ylo = INFINITY, yhi = -INFINITY;
+  int nm = 0, flag = 0;
+  if (tid < ra.nb) {   // band b's record in lane b of wave 0: its first four granules
+    const u32x4* q = reinterpret_cast<const u32x4*>(part + (long long)tid * ROWS_PART_D);
+    u32x4 x0, x1, x2, x3;
+    if (XCH) ld16x4_through(q, q + 1, q + 2, q + 3, &x0, &x1, &x2, &x3);
+    else { x0 = q[0]; x1 = q[1]; x2 = q[2]; x3 = q[3]; }
+    acc[0] = __hiloint2double((int)x0[1], (int)x0[0]); acc[1] = __hiloint2double((int)x0[3], (int)x0[2]);
+    acc[2] = __hiloint2double((int)x1[1], (int)x1[0]); acc[3] = __hiloint2double((int)x1[3], (int)x1[2]);
+    acc[4] = __hiloint2double((int)x2[1], (int)x2[0]); ylo = __hiloint2double((int)x2[3], (int)x2[2]);
+    yhi = __hiloint2double((int)x3[1], (int)x3[0]);
+    double cntf = __hiloint2double((int)x3[3], (int)x3[2]);
+    if (cntf >= ROWS_FLAG) { flag = 1; cntf -= ROWS_FLAG; }
+    nm = (int)cntf;
+  }
+  bool generic = __syncthreads_or(flag) != 0;   // (also publishes M / Rg / mcol)
+  // generic: a band could not take the single pass (a NaN / inf / negative depth under the mask, a skewed K) - the whole instance
+  // by this workgroup, pixel by pixel straight from the planes (sweep_plain: rare, written for few registers, not for speed)
+  if (!generic) {   // uniform
+    stage_moments_to_axis(sh, p, inst, acc, nm, nm, tid, wave, lane, true);
+    if (sh->redo) { generic = true; __syncthreads(); }   // uniform: non-finite sums
+  }
+  const float* dpl = p.depth + (long long)img * p.depth_plane_stride;
+  const unsigned char* mpl = p.mask + (long long)inst * p.HW;
+  if (generic) {
+    double gacc[5] = {0, 0, 0, 0, 0};
+    int cnt = 0, nmask = 0;
+    sweep_plain<0>(p, dpl, mpl, sh->M, sh->M + 3, sh->M + 6, tid, gacc, &cnt, &nmask);
+    stage_moments_to_axis(sh, p, inst, gacc, cnt, nmask, tid, wave, lane, false);
+  }
+  if (sh->st != LA3D_BOX_OK) return;
+  double ext[6] = {INFINITY, -INFINITY, INFINITY, -INFINITY, INFINITY, -INFINITY};
+  if (generic) {
+    if (tid < 3) {   // rows 0 and 2 of rotate_y(yaw) @ M through LDS: this route keeps nothing wave-uniform in registers
+      sh->part[0][tid] = sh->cyaw * sh->M[tid] + sh->syaw * sh->M[6 + tid];
+      sh->part[1][tid] = -sh->syaw * sh->M[tid] + sh->cyaw * sh->M[6 + tid];
+    }
+    __syncthreads();
+    int d0 = 0, d1 = 0;
+    sweep_plain<1>(p, dpl, mpl, sh->part[0], sh->M + 3, sh->part[1], tid, ext, &d0, &d1);
+    __syncthreads();
+  } else {
+    double Mg[9], N0[3], N2[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Mg[i] = uniform_f64(sh->M[i]);
+    yaw_rows(sh, Mg, N0, N2);
+    sep_col_extents(mcol, W, N0, N2, tid, ext);
+    ext[2] = ylo; ext[3] = yhi;
+  }
+  stage_extents_to_box(sh, p, inst, ext, tid, wave, lane);
+  stage_status_aux(sh, p, inst, tid);
 }
 
 __global__ __launch_bounds__(NT, NT / 64) void fit_rows_kernel(const FitParams p, const RowsArgs ra) {
@@ -2583,6 +2745,9 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_rows_kernel(const FitParams p
     }
   }
   __syncthreads();   // (also: every ds_min / ds_max of the pass has landed)
+  // the band's partial record and per-column ranges -> workspace.  One-launch form: 16-byte write-through stores - the workgroup
+  // that merges the instance may sit on another XCD (another L2); two-launch form: plain stores (the kernel boundary publishes them)
+  const bool xch = ra.arrive != nullptr;   // uniform
   if (tid == 0) {
     double t[7] = {0, 0, 0, 0, 0, INFINITY, -INFINITY};
     int nm = 0, bad = sep_cam ? 0 : 1;
@@ -2593,16 +2758,39 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_rows_kernel(const FitParams p
       nm += sh->nmask[w];
       bad |= sh->cnt[w];
     }
-    double* q = ra.part + (long long)v * ROWS_PART_D;
+    // through LDS (sh->part is free again: every wave's partials have been read): [0..6] sums and y extent | mask pixels | flag | - |
+    // M[9] (the merge takes the camera from band 0: no second inversion) | -
+    double* z = &sh->part[0][0];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) q[k] = t[k];
-    q[7] = (double)nm; q[8] = (double)bad; q[9] = 0.0;
+    for (int k = 0; k < 7; ++k) z[k] = t[k];
+    z[7] = (double)nm + (bad ? ROWS_FLAG : 0.0); z[8] = 0.0; z[9] = 0.0;   // (mask pixels < 2^28: the sum is exact)
 #pragma unroll
-    for (int k = 0; k < 9; ++k) q[10 + k] = sh->M[k];   // (the merge workgroup takes the camera from band 0: no second inversion)
-    q[19] = 0.0;
+    for (int k = 0; k < 9; ++k) z[10 + k] = sh->M[k];
+    z[19] = 0.0;
   }
-  unsigned* gcol = ra.col + (long long)v * 2 * W;
-  for (int u = tid; u < 2 * W; u += NT) gcol[u] = col[u];
+  __syncthreads();
+  {
+    double* q = ra.part + (long long)v * ROWS_PART_D;
+    unsigned* gcol = ra.col + (long long)v * 2 * W;
+    const uint4* zq = reinterpret_cast<const uint4*>(&sh->part[0][0]);
+    const uint4* cq = reinterpret_cast<const uint4*>(col);
+    if (xch) {
+      if (tid < ROWS_PART_D / 2) st16_through(reinterpret_cast<uint4*>(q) + tid, zq[tid]);
+      for (int g = tid; g < W / 2; g += NT) st16_through(reinterpret_cast<uint4*>(gcol) + g, cq[g]);
+    } else {
+      if (tid < ROWS_PART_D / 2) reinterpret_cast<uint4*>(q)[tid] = zq[tid];
+      for (int g = tid; g < W / 2; g += NT) reinterpret_cast<uint4*>(gcol)[g] = cq[g];
+    }
+  }
+  if (ra.arrive == nullptr) return;   // uniform: the two-launch form - merge_rows_kernel follows on the stream
+  // ---- one launch: the band that arrives last merges the instance (nobody waits for anybody) ----
+  band_release();      // every thread: its own stores have been acknowledged ...
+  __syncthreads();     // ... all of them, before thread 0 announces the band
+  if (tid == 0) sh->scan[0] = tagged_arrive_many(ra.arrive + inst, ra.tag) == (unsigned)ra.nb ? 1u : 0u;
+  __syncthreads();
+  if (!sh->scan[0]) return;   // uniform
+  band_acquire();      // the other bands' data is loaded after their arrivals were seen
+  rows_merge<true>(sh, p, ra, inst, img, col, tid, wave, lane);
 }
 
 // one workgroup per instance: partials of its bands -> status, axis, extents, record (the instance engine's stages)
@@ -2614,91 +2802,51 @@ __global__ __launch_bounds__(NT, NT / 64) void merge_rows_kernel(const FitParams
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int inst = (int)blockIdx.x;
   const int img = p.image_index ? p.image_index[inst] : inst;
-  const int W = p.W;
-  const double* part = ra.part + (long long)inst * ra.nb * ROWS_PART_D;
-  const unsigned* gc = ra.col + (long long)inst * ra.nb * 2 * W;
-  // the per-column ranges first (the longest chain of loads): 2 W / 4 threads, each the min (first W words) or max (last W) of four
-  // columns over the bands - independent 16-byte loads, eight in flight
-  for (int qd = tid; qd < W / 2; qd += NT) {
-    const bool is_max = qd >= W / 4;
-    const uint4* src = reinterpret_cast<const uint4*>(gc) + qd;
-    uint4 m = is_max ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
-#pragma unroll 8
-    for (int b = 0; b < ra.nb; ++b) {
-      const uint4 w = src[(long long)b * (W / 2)];
-      if (is_max) { m.x = max(m.x, w.x); m.y = max(m.y, w.y); m.z = max(m.z, w.z); m.w = max(m.w, w.w); }
-      else { m.x = min(m.x, w.x); m.y = min(m.y, w.y); m.z = min(m.z, w.z); m.w = min(m.w, w.w); }
-    }
-    reinterpret_cast<uint4*>(mcol)[qd] = m;
-  }
-  if (tid < 9) sh->M[tid] = part[10 + tid];                      // band 0's camera (every band computed the same one)
-  else if (tid < 18) sh->Rg[tid - 9] = ((tid - 9) % 4 == 0) ? 1.0 : 0.0;   // no ground array: the identity (ground_rotation(nullptr))
-  if (tid == 18) { sh->bad_ground = 0; sh->order_inst = inst; sh->sep_bad = 0; }
-  double acc[5] = {0, 0, 0, 0, 0}, ylo = INFINITY, yhi = -INFINITY;
-  int nm = 0, flag = 0;
-  if (tid < ra.nb) {   // band b in lane b of wave 0: the wave sum of stage_moments_to_axis adds them in its fixed tree
-    const double* q = part + (long long)tid * ROWS_PART_D;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) acc[k] = q[k];
-    ylo = q[5]; yhi = q[6]; nm = (int)q[7]; flag = q[8] != 0.0 ? 1 : 0;
-  }
-  const int any_flag = __syncthreads_or(flag);   // (also publishes M / Rg / mcol)
-  double Mg[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) Mg[i] = uniform_f64(sh->M[i]);
-  if (!any_flag) {   // uniform
-    stage_moments_to_axis(sh, p, inst, acc, nm, nm, tid, wave, lane, true);
-    if (!sh->redo) {   // uniform
-      if (sh->st != LA3D_BOX_OK) return;
-      double N0[3], N2[3], ext[6];
-      yaw_rows(sh, Mg, N0, N2);
-      sep_col_extents(mcol, W, N0, N2, tid, ext);
-      ext[2] = ylo; ext[3] = yhi;
-      stage_extents_to_box(sh, p, inst, ext, tid, wave, lane);
-      stage_status_aux(sh, p, inst, tid);
-      return;
-    }
-    __syncthreads();
-  }
-  // a band could not take the single pass: the whole instance by this workgroup, generic row-linear two-pass walk over the plane
-  const float* dpl = p.depth + (long long)img * p.depth_plane_stride;
-  const unsigned char* mpl = p.mask + (long long)inst * p.HW;
-  double gacc[5] = {0, 0, 0, 0, 0};
-  int cnt = 0, nmask = 0;
-  sweep<true, false, 0>(p, dpl, mpl, nullptr, Mg, Mg + 3, Mg + 6, wave, lane, gacc, &cnt, &nmask);
-  stage_moments_to_axis(sh, p, inst, gacc, cnt, nmask, tid, wave, lane, false);
-  if (sh->st != LA3D_BOX_OK) return;
-  double ext[6] = {INFINITY, -INFINITY, INFINITY, -INFINITY, INFINITY, -INFINITY};
-  double N0[3], N2[3];
-  yaw_rows(sh, Mg, N0, N2);
-  int d0 = 0, d1 = 0;
-  sweep<true, false, 1>(p, dpl, mpl, nullptr, N0, Mg + 3, N2, wave, lane, ext, &d0, &d1);
-  stage_extents_to_box(sh, p, inst, ext, tid, wave, lane);
-  stage_status_aux(sh, p, inst, tid);
+  for (int u = tid; u < p.W; u += NT) { mcol[u] = 0xffffffffu; mcol[p.W + u] = 0u; }   // the identities: every band is merged in
+  rows_merge<false>(sh, p, ra, inst, img, mcol, tid, wave, lane);
 }
 
 // u8 planes, 16-byte aligned, full-mask mode, no ground array, B <= ROWS_MAX_B: LA3D_ENGINE=rows / opt_engine pins it, by default
 // it takes the batches up to config().rows_maxb
 inline bool rows_eligible(const FitParams& p, bool vec, bool sample, RowsArgs* ra) {
   const int e = p.opt_engine != LA3D_ENGINE_DEFAULT ? p.opt_engine : config().engine;
-  if (e != LA3D_ENGINE_DEFAULT && e != LA3D_ENGINE_ROWS) return false;
+  if (e != LA3D_ENGINE_DEFAULT && e != LA3D_ENGINE_ROWS && e != LA3D_ENGINE_ROWS2) return false;
   if (!vec || sample || p.mask == nullptr || p.ground != nullptr || p.sep_off || p.filter_boundary >= 0) return false;
   if ((p.opt_build != LA3D_BUILD_DEFAULT ? p.opt_build : config().retain) == LA3D_BUILD_RETAINING) return false;
   if (!rows_plan(p.B, p.H, p.W, ra)) return false;
-  return e == LA3D_ENGINE_ROWS || p.B <= config().rows_maxb;
+  return e == LA3D_ENGINE_ROWS || e == LA3D_ENGINE_ROWS2 || p.B <= config().rows_maxb;
 }
 
 int launch_fit_rows(const FitParams& p_in, RowsArgs ra, hipStream_t s, void* workspace) {
   FitParams p = p_in;
   p.ntx = p.W / 32; p.nty = p.H / 8;
   p.rcp_ntx = 1.0f / (float)p.ntx;
-  ra.part = static_cast<double*>(workspace);
-  ra.col = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(workspace) + (((size_t)p.B * ra.nb * ROWS_PART_D * 8 + 255) & ~(size_t)255));
+  unsigned char* w = static_cast<unsigned char*>(workspace);
+  const size_t part_bytes = ((size_t)p.B * ra.nb * ROWS_PART_D * 8 + 255) & ~(size_t)255;
+  const size_t col_bytes = ((size_t)p.B * ra.nb * 2 * p.W * 4 + 255) & ~(size_t)255;
+  ra.part = reinterpret_cast<double*>(w);
+  ra.col = reinterpret_cast<unsigned*>(w + part_bytes);
+  // One launch (round 6): the last band to arrive merges its instance.  Two launches - fit_rows_kernel, then merge_rows_kernel -
+  // when pinned (LA3D_ENGINE_ROWS2 / LA3D_ROWS_FUSED=0) and for a call captured into a HIP graph (it would replay with the same tag).
+  const int e = p.opt_engine != LA3D_ENGINE_DEFAULT ? p.opt_engine : config().engine;
+  bool fused = e != LA3D_ENGINE_ROWS2 && config().rows_fused != 0;
+  if (fused) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) fused = false;
+    (void)hipGetLastError();
+  }
+  ra.arrive = nullptr; ra.tag = 0;
+  if (fused) {
+    ra.arrive = reinterpret_cast<unsigned long long*>(w + part_bytes + col_bytes);
+    const unsigned long long t = (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
+    ra.tag = (((t * 0x9E3779B97F4A7C15ull) >> 13) ^ (unsigned long long)reinterpret_cast<uintptr_t>(workspace)) & 0xffffffffffffull;
+    if (ra.tag == 0) ra.tag = 1;
+  }
   const size_t lds = (size_t)ra.bits_bytes + sizeof(Shared) + (size_t)p.ntx * ra.trows * 2 + 16;
   allow_big_lds(reinterpret_cast<const void*>(fit_rows_kernel));
   hipLaunchKernelGGL(fit_rows_kernel, dim3(p.B * ra.nb), dim3(NT), lds, s, p, ra);
   const int rc = check_launch("fit_rows_kernel");
-  if (rc != LA3D_SUCCESS) return rc;
+  if (rc != LA3D_SUCCESS || fused) return rc;
   hipLaunchKernelGGL(merge_rows_kernel, dim3(p.B), dim3(NT), sizeof(Shared) + (size_t)2 * p.W * 4, s, p, ra);
   return check_launch("merge_rows_kernel");
 }
@@ -2827,7 +2975,7 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   const int eng = p.opt_engine != LA3D_ENGINE_DEFAULT ? p.opt_engine : config().engine;
   const bool single_pass_call = ground == nullptr && !sample && !p.sep_off && ldsmask && vec && W % 32 == 0 && W / 32 <= 255 &&
                                 (H + 7) / 8 <= 255 && ((W / 32) * ((H + 7) / 8) + NWAVE - 1) / NWAVE <= 256 &&
-                                (eng == LA3D_ENGINE_DEFAULT || eng == LA3D_ENGINE_ROWS) &&   // (rows pinned but not applicable: as by default)
+                                (eng == LA3D_ENGINE_DEFAULT || eng == LA3D_ENGINE_ROWS || eng == LA3D_ENGINE_ROWS2) &&   // (rows pinned but not applicable: as by default)
                                 (p.opt_build != LA3D_BUILD_DEFAULT ? p.opt_build : config().retain) != LA3D_BUILD_RETAINING;
   {
     RowsArgs ra;
@@ -3015,7 +3163,7 @@ int la3d_fit_instances_ex(const la3d_fit_args* args) {
   const bool filter_on = a.filter_boundary >= 0 && a.filter_max_edge > 0;
   const FilterArgs fa{a.filter_boundary, a.filter_min_area, a.filter_max_edge, a.stats};
   const ProjArgs pr{a.proj, a.image_width, a.image_height};
-  if (a.opt_engine < 0 || a.opt_engine > LA3D_ENGINE_ROWS || a.opt_launch_order < 0 || a.opt_launch_order > LA3D_ORDER_ON ||
+  if (a.opt_engine < 0 || a.opt_engine > LA3D_ENGINE_ROWS2 || a.opt_launch_order < 0 || a.opt_launch_order > LA3D_ORDER_ON ||
       a.opt_build < 0 || a.opt_build > LA3D_BUILD_RETAINING) {
     set_err("la3d_fit_instances_ex: bad opt_engine / opt_launch_order / opt_build");
     return LA3D_ERR_ARG;

@@ -38,6 +38,8 @@ struct Config {
   int band_default;    // LA3D_BAND_DEFAULT=0: the band engine only when pinned
   int band_maxb;       // LA3D_BAND_MAXB: largest batch the band engine takes by default
   int rows_maxb;       // LA3D_ROWS_MAXB: largest batch the row engine takes by default (u8 planes, no ground array)
+  int rows_fused;      // LA3D_ROWS_FUSED=0: the row engine in its two-launch form (a merge launch behind the band launch)
+  int rows_wgs;        // LA3D_ROWS_WGS: workgroups the row engine spreads a batch over, at most (default 640)
   int balance;         // LA3D_BALANCE=0 -> launch order off by default
   int balance_rounds;  // LA3D_BALANCE_ROUNDS: batches up to this many resident sets are ordered (default 3)
   int retain;          // LA3D_RETAIN=0|1 -> LA3D_BUILD_PLAIN / LA3D_BUILD_RETAINING (0 = by batch size)

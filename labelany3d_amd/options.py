@@ -6,7 +6,7 @@ build of the instance kernel is used are decided per call.  These options pin a 
 call through the keyword arguments of ``InstanceFitter.run``.  They steer SPEED only: records never depend on them (the split
 engine groups its fp64 partial sums by tile range, so split vs instance agree to rounding, not bit for bit - INTEGRATION.md).
 
-    with scheduling(engine="split"):            # or "instance", "band", "rows"
+    with scheduling(engine="split"):            # or "instance", "band", "rows", "rows2"
         boxes, status, aux = fit_instances(depth, masks, K)
     with scheduling(launch_order=False):         # a caller pipelining independent batches on several streams
         ...
@@ -18,13 +18,13 @@ from __future__ import annotations
 import contextlib
 import threading
 
-ENGINE = {None: 0, "instance": 1, "split": 2, "band": 3, "rows": 4}
+ENGINE = {None: 0, "instance": 1, "split": 2, "band": 3, "rows": 4, "rows2": 5}
 ORDER = {None: 0, False: 1, True: 2}
 BUILD = {None: 0, "plain": 1, "retaining": 2}
 
 
 class _Sched(threading.local):
-    engine = None          # None | "instance" | "split" | "band" | "rows"
+    engine = None          # None | "instance" | "split" | "band" | "rows" | "rows2"
     launch_order = None    # None | False | True
     build = None           # None | "plain" | "retaining"
 

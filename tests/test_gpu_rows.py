@@ -148,3 +148,40 @@ def test_row_engine_odd_band_splits(la, monkeypatch):
         assert rows[1][:n].tolist() == list(rst)
         ok = (rows[1][:n] == 0) & (rows[2][:n, 3] > 1e-6)
         assert_records(rows[0][:n][ok], ref[ok], f"row engine {H}x{W}", gap=rows[2][:n][ok, 3])
+
+
+@pytest.mark.parametrize("B", [1, 7, 40, 256, 384, 512])
+def test_row_engine_one_launch_equals_two_launches(la, monkeypatch, B):
+    """Round 6: the row engine is ONE launch - the band workgroup that arrives last at its instance's counter merges the instance
+    (agent-scope stores / loads through the workspace, tagged arrival words nobody clears).  The merge is the same code on the same
+    operands in the same order as the merge launch of the two-launch form ("rows2", what a graph-captured call takes): the records
+    must be equal bit for bit, call after call on the same workspace, and - B = 256 / 384 / 512, the batches it newly takes over -
+    agree with the instance engine to rounding and with the oracle."""
+    import torch
+
+    rs = np.random.RandomState(1000 + B)
+    H, W = 480, 640
+    depth = rs.uniform(0.5, 10, (B, H, W)).astype(np.float32)
+    masks = rect_masks(rs, B, H, W)
+    if B >= 7:
+        masks[3] = False                      # an empty instance
+        r, c = np.argwhere(masks[5])[0]
+        depth[5, r, c] = np.nan               # a band that raises its flag: the merging workgroup walks the plane itself
+    d_t, m_t, k_t = (torch.as_tensor(x, device="cuda") for x in (depth, masks.view(np.uint8), K640))
+    f = la.InstanceFitter(B, H, W, torch.device("cuda", 0))
+    out = {}
+    for eng in ("rows2", "rows", "instance"):
+        monkeypatch.setattr(SCHED(), "engine", eng)
+        for _ in range(3):                    # the same workspace call after call: every call carries its own tag
+            f.run(d_t, m_t, k_t)
+        torch.cuda.synchronize()
+        out[eng] = (np_(f.boxes[0]).copy(), np_(f.status[0]).copy(), np_(f.aux[0]).copy())
+    monkeypatch.setattr(SCHED(), "engine", None)
+    for a, b in zip(out["rows"], out["rows2"]):
+        np.testing.assert_array_equal(a, b)
+    _close(out["rows"], out["instance"], f"one-launch rows vs instance, B={B}")
+    n = min(B, 24)
+    ref, rst, _, nval = O.fit_instances(depth[:n], masks[:n], np.broadcast_to(K640, (n, 3, 3)))
+    assert out["rows"][1][:n].tolist() == list(rst)
+    ok = (out["rows"][1][:n] == 0) & (out["rows"][2][:n, 3] > 1e-6)
+    assert_records(out["rows"][0][:n][ok], ref[ok], f"one-launch rows B={B}", gap=out["rows"][2][:n][ok, 3])
