@@ -88,7 +88,7 @@ int la3d_pad_rows(const float* src, int64_t rows, int W, int Wp, float* dst, voi
 /* The library keeps NO mutable process state (re-entrant, no global state).  How a call is scheduled - which
  * engine, whether the size-balanced launch order runs, which build of the instance kernel - is decided per call from its
  * arguments; the three `opt_*` fields of la3d_fit_args override the decision for one call (0 = the library's choice).  The
- * LA3D_* environment variables the measurement scripts use (LA3D_ENGINE, LA3D_BALANCE, LA3D_RETAIN, ...) are read ONCE, at
+ * LA3D_* environment variables the measurement scripts use (LA3D_ENGINE, LA3D_BALANCE, LA3D_BUILD, ...) are read ONCE, at
  * the first call, into an immutable table of process defaults; they never change records, only speed.
  * (ABI 2: la3d_set_launch_order / la3d_get_launch_order of ABI 1 - a process-wide switch - are gone; use opt_launch_order.) */
 #define LA3D_ENGINE_DEFAULT 0
@@ -110,7 +110,11 @@ int la3d_pad_rows(const float* src, int64_t rows, int W, int Wp, float* dst, voi
 #define LA3D_BUILD_DEFAULT 0          /* 64 VGPRs, four workgroups per CU; un-grounded, skew-free cameras take the separable SINGLE pass
                                          (round 5: one walk over the depth, extents from per-column depth ranges), every other call two passes */
 #define LA3D_BUILD_PLAIN 1            /* the same build pinned to its two-pass form (pass-B tile culling) for every camera */
-#define LA3D_BUILD_RETAINING 2        /* 128 VGPRs, two workgroups per CU, depth tiles kept in registers between the passes */
+#define LA3D_BUILD_NOCULL 2           /* the two-pass form that walks EVERY active tile in pass B (no culling plan): the reference the culling
+                                         tests compare with, never faster */
+#define LA3D_BUILD_RETAINING LA3D_BUILD_NOCULL   /* rounds 2-5: a 128-VGPR build that kept depth tiles in registers between the passes -
+                                         fastest nowhere since round 4 (106 vs 81 us per 1024 instances) and deleted in round 6; the value
+                                         stays accepted and now selects the no-cull build (the same records: it never culled) */
 
 /* Bytes of device scratch la3d_fit_instances needs for (B,H,W); may be 0. */
 size_t la3d_workspace_bytes(int B, int H, int W);

@@ -5,9 +5,13 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = os.path.join(HERE, "csrc", "la3d.hip")
-SOURCES = [SRC, os.path.join(HERE, "csrc", "la3d_split.hip"), os.path.join(HERE, "csrc", "la3d_aux.hip"), os.path.join(HERE, "csrc", "la3d_json.cpp")]
-HEADERS = [os.path.join(HERE, "csrc", "la3d_device.hpp"), os.path.join(HERE, "csrc", "la3d_poly.hpp"), os.path.join(ROOT, "include", "la3d.h")]
+CSRC = os.path.join(HERE, "csrc")
+# one translation unit per engine (compiled side by side), the C-ABI + dispatcher, the other kernels, the host-side JSON writer (last:
+# it carries the build identity)
+SOURCES = [os.path.join(CSRC, f) for f in ("la3d_instance.hip", "la3d_band.hip", "la3d_rows.hip", "la3d_split.hip", "la3d_aux.hip", "la3d.hip",
+                                           "la3d_json.cpp")]
+HEADERS = [os.path.join(CSRC, f) for f in ("la3d_device.hpp", "la3d_walks.hpp", "la3d_stages.hpp", "la3d_engines.hpp", "la3d_poly.hpp")] + \
+          [os.path.join(ROOT, "include", "la3d.h")]
 LIB = os.environ.get("LA3D_LIB") or os.path.join(HERE, "lib", "libla3d.so")  # LA3D_LIB: experiment builds only
 INCLUDE = os.path.join(ROOT, "include")
 

@@ -5,7 +5,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-from ._build import HERE, INCLUDE, LIB, ROOT, SRC, build  # noqa: F401
+from ._build import HERE, INCLUDE, LIB, ROOT, SOURCES, build  # noqa: F401
 
 REC, AUX, NSAMPLE = 39, 4, 500
 BOX_OK, BOX_EMPTY, BOX_BAD_GROUND, BOX_TOO_FEW, BOX_NONFINITE, BOX_UNSUPPORTED, BOX_FILTERED = 0, 1, 2, 3, 4, 5, 6

@@ -42,10 +42,7 @@ struct Config {
   int rows_wgs;        // LA3D_ROWS_WGS: workgroups the row engine spreads a batch over, at most (default 640)
   int balance;         // LA3D_BALANCE=0 -> launch order off by default
   int balance_rounds;  // LA3D_BALANCE_ROUNDS: batches up to this many resident sets are ordered (default 3)
-  int retain;          // LA3D_RETAIN=0|1 -> LA3D_BUILD_PLAIN / LA3D_BUILD_RETAINING (0 = by batch size)
-  int retain_maxb;     // LA3D_RETAIN_MAXB (default RETAIN_MAXB_DEFAULT)
-  int retain_nomask;   // LA3D_RETAIN_NOMASK=1: retaining build for run-length / polygon input too
-  int ldskeep;         // LA3D_LDSKEEP=0: retaining build without its LDS-kept step
+  int build;           // LA3D_BUILD=plain|nocull (LA3D_RETAIN=0|1: the old spelling) -> LA3D_BUILD_PLAIN / LA3D_BUILD_NOCULL for every call
   int cull_min, cull_min_u8;   // LA3D_CULL_MIN (all inputs; 0: defaults), LA3D_CULL_MIN_U8 (u8 planes, default 128)
   int order_self;      // LA3D_ORDER_SELF=0: keep the estimate kernel in front of ordered launches of up to one resident set
   double stagger_us;   // LA3D_STAGGER_US (< 0: the computed default)
@@ -503,7 +500,6 @@ struct FitParams {
   int order_nch;       // chunks of consecutive instances (ceil(B / ORDER_CHUNK)), 0 = launch order off
   int order_resident;  // workgroups of the grid that are resident at once
   int order_shift;     // area_hint >> order_shift fits 18 bits
-  int lds_keep_off;    // retaining build: byte offset in dynamic LDS of the per-wave kept step (0: none)
   int cull_min;        // pass-B culling: instances with at least this many active tiles plan (cull_plan)
   int stagger_ticks;   // u8 planes: resident groups of 256 workgroups start this many 100 MHz ticks apart (0: off; see fit_instances_kernel)
   // instance filter fused into the fit (run-length / polygon input): boundary < 0 = off
@@ -547,7 +543,7 @@ struct alignas(16) Shared {
   double gap;      // relative eigenvalue gap (aux[3]), kept for the deferred aux write
   int nm;          // mask pixels (aux[2])
   int order_inst;  // the instance this workgroup fits (size-balanced launch order)
-  unsigned qhead;  // pass B: head of the LDS work queue over the not-retained part of the active-tile list
+  unsigned qhead;  // pass B: head of the LDS work queue over the survivor list
   int sep_bad;     // separable single pass: a NaN / inf / negative depth under the mask - re-run the general path
   unsigned qpad[2];
 #ifdef LA3D_TIMELINE
@@ -811,6 +807,7 @@ inline void allow_big_lds(const void* fn, int bytes = 160 * 1024) {
   done.emplace_back(fn, dev);
 }
 
+constexpr int CULL_MIN = 224;   // pass-B culling: active tiles from which an instance plans (run lengths / polygons; la3d_stages.hpp)
 constexpr int MAX_MASK_LDS = 128 * 1024;  // bit image budget; larger frames re-read the u8 mask instead
 
 }  // namespace la3d

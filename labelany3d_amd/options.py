@@ -10,7 +10,7 @@ engine groups its fp64 partial sums by tile range, so split vs instance agree to
         boxes, status, aux = fit_instances(depth, masks, K)
     with scheduling(launch_order=False):         # a caller pipelining independent batches on several streams
         ...
-    with scheduling(build="plain"):              # or "retaining": the 128-VGPR build of the instance kernel
+    with scheduling(build="plain"):              # or "nocull": two passes, every active tile walked in pass B
         ...
 """
 from __future__ import annotations
@@ -20,13 +20,13 @@ import threading
 
 ENGINE = {None: 0, "instance": 1, "split": 2, "band": 3, "rows": 4, "rows2": 5}
 ORDER = {None: 0, False: 1, True: 2}
-BUILD = {None: 0, "plain": 1, "retaining": 2}
+BUILD = {None: 0, "plain": 1, "nocull": 2, "retaining": 2}   # ("retaining": the deleted 128-VGPR build; its value now means "nocull")
 
 
 class _Sched(threading.local):
     engine = None          # None | "instance" | "split" | "band" | "rows" | "rows2"
     launch_order = None    # None | False | True
-    build = None           # None | "plain" | "retaining"
+    build = None           # None | "plain" | "nocull"
 
 
 sched = _Sched()

@@ -258,7 +258,7 @@ def test_upload_many_packs_host_arrays_into_one_buffer():
 @pytest.mark.gpu
 def test_scheduling_is_per_call_not_process_state():
     """SURVEY 8b 're-entrant ... no global state': two threads issue fits with DIFFERENT per-call scheduling (launch order on / off,
-    plain / retaining build of the instance kernel) at the same time, each on its own stream and workspace; both get the records
+    plain / no-cull build of the instance kernel) at the same time, each on its own stream and workspace; both get the records
     a lone two-pass call gets, bit for bit.  (ABI 1 had a process-wide la3d_set_launch_order; ABI 2 carries the choice in
     la3d_fit_args::opt_*.)"""
     import threading
@@ -292,7 +292,7 @@ def test_scheduling_is_per_call_not_process_state():
         except Exception as e:  # noqa: BLE001
             errors.append((name, e))
 
-    ths = [threading.Thread(target=worker, args=("a", True, "retaining")), threading.Thread(target=worker, args=("b", False, "plain"))]
+    ths = [threading.Thread(target=worker, args=("a", True, "nocull")), threading.Thread(target=worker, args=("b", False, "plain"))]
     for t in ths:
         t.start()
     for t in ths:
@@ -333,7 +333,7 @@ def test_scheduling_options_are_thread_local_and_validated():
     from labelany3d_amd import options
 
     assert options.codes() == (0, 0, 0)
-    assert options.codes(engine="band", launch_order=False, build="retaining") == (3, 1, 2)
+    assert options.codes(engine="band", launch_order=False, build="nocull") == (3, 1, 2)
     assert options.codes(engine="rows") == (4, 0, 0)
     seen = {}
 

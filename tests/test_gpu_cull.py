@@ -1,7 +1,7 @@
 """Pass-B tile culling of the instance engine's plain build (round 4): the extents are min / max
 over the points, so skipping tiles that provably cannot move them must leave the records BIT-identical.  Checked two ways on
 480x640 frames whose masks have enough active tiles for the culling plan to run: against the CPU oracle (the stated 1e-9), and
-bit for bit against the retaining build of the same kernel, which has no culling and walks every tile."""
+bit for bit against the no-cull build of the same kernel (opt_build = LA3D_BUILD_NOCULL), which has no culling plan and walks every tile."""
 import numpy as np
 import pytest
 
@@ -75,7 +75,7 @@ def _depths(rs, B, kind):
 
 def _fit(la, monkeypatch, depth, masks, K, ground, retain):
     monkeypatch.setattr(SCHED(), "engine", "instance")
-    monkeypatch.setattr(SCHED(), "build", {"0": "plain", "1": "retaining"}[retain])
+    monkeypatch.setattr(SCHED(), "build", {"0": "plain", "1": "nocull"}[retain])
     b, s, a = la.fit_instances(depth, masks, K, ground=ground)
     return np_(b), np_(s), np_(a)
 
@@ -90,7 +90,7 @@ def test_culled_pass_b_is_exact(la, monkeypatch, kind):
     ground[::3, 0] = np.nan   # every third instance without a ground plane
     K = K640 + np.array([[0, 0.7, 0], [0, 0, 0], [0, 0, 0]]) if kind == "plane" else K640
     got = _fit(la, monkeypatch, depth, masks, K, ground, "0")      # plain build: culling on
-    full = _fit(la, monkeypatch, depth, masks, K, ground, "1")     # retaining build: every tile walked
+    full = _fit(la, monkeypatch, depth, masks, K, ground, "1")     # no-cull build: every tile walked
     assert (got[1] == full[1]).all()
     np.testing.assert_array_equal(got[0], full[0], err_msg=f"{kind}: culled pass B changed a record")
     np.testing.assert_array_equal(got[2], full[2])
@@ -141,7 +141,7 @@ def test_culling_rle_and_polygon_input_match_planes(la, monkeypatch):
 
 # ------------------------------------------------------------------------------------------
 # Round 4, late: the speed knobs of the plain build - the staggered start of the resident groups, the culling threshold, the
-# retaining build - are read once per process (config()), so each setting runs in its own interpreter; records must not move by a bit.
+# no-cull build - are read once per process (config()), so each setting runs in its own interpreter; records must not move by a bit.
 # ------------------------------------------------------------------------------------------
 _KNOB_SCRIPT = r"""
 import hashlib, sys
@@ -185,17 +185,17 @@ def test_speed_knobs_leave_the_records_alone(la, tmp_path):
                       ("helper kernel", {"LA3D_ORDER_SELF": "0"}), ("self-estimate fallback", {"LA3D_ORDER_SELF": "2"}),
                       ("two-pass", two), ("two-pass, cull everything", dict(two, LA3D_CULL_MIN="1")),
                       ("two-pass, cull nothing", dict(two, LA3D_CULL_MIN="100000")), ("two-pass, no stagger", dict(two, LA3D_STAGGER_US="0")),
-                      ("retaining build", {"LA3D_RETAIN": "1"})):
+                      ("no-cull build", {"LA3D_BUILD": "nocull"})):
         e = dict(os.environ, LA3D_ENGINE="instance", **env)
         out = str(tmp_path / (name.replace(" ", "_").replace(",", "") + ".npy"))
         r = subprocess.run([sys.executable, "-c", _KNOB_SCRIPT % root, out], env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (name, r.stderr[-2000:])
         shas[name] = [ln for ln in r.stdout.splitlines() if ln.startswith("SHA")][0]
         recs[name] = np.load(out)
-    # the single pass groups its sums alike whatever the knobs; so does the two-pass plain build, and the retaining build groups them
+    # the single pass groups its sums alike whatever the knobs; so does the two-pass plain build, and the no-cull build groups them
     # like the two-pass plain one as long as the active tiles fit the plain build's list (rectangles below 400 x 500 px do)
-    single = {k: v for k, v in shas.items() if not k.startswith("two-pass") and k != "retaining build"}
-    double = {k: v for k, v in shas.items() if k.startswith("two-pass") or k == "retaining build"}
+    single = {k: v for k, v in shas.items() if not k.startswith("two-pass") and k != "no-cull build"}
+    double = {k: v for k, v in shas.items() if k.startswith("two-pass") or k == "no-cull build"}
     assert len(set(single.values())) == 1, single
     assert len(set(double.values())) == 1, double
     np.testing.assert_allclose(recs["default"][:, :15], recs["two-pass"][:, :15], rtol=1e-11, atol=1e-11)

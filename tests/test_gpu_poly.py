@@ -262,7 +262,7 @@ def test_the_reference_converters_own_polygons(la, monkeypatch):
         with _instance_engine():
             b1, s1, a1 = la.fit_instances_poly(depth, packed, K)
         # polygon input takes the plain build; pin it for the planes too: the 107 k-px blob has more active tiles (> 912) than the
-        # plain build's list holds and is walked densely there, which groups the partial sums differently from the retaining
+        # plain build's list holds and is walked densely there, which groups the partial sums differently from the no-cull
         # build's longer list (last-ulp differences; checked to rounding below)
         # (round 5: both inputs take the default build - the separable single pass where the camera allows - and must agree bit for
         # bit; the two-pass plain build agrees to rounding)

@@ -1,4 +1,4 @@
-"""The row engine (round 5, la3d.hip: fit_rows_kernel + merge_rows_kernel): small batches of u8 planes without a ground array are
+"""The row engine (round 5, la3d_rows.hip: fit_rows_kernel + merge_rows_kernel): small batches of u8 planes without a ground array are
 fitted by up to sixteen workgroups per instance, one per band of rows - the separable single pass split by rows, the bands' partial
 sums / extents / per-column depth ranges merged by a second short launch.  Checked here: parity with the CPU oracle (reference
 src/util_3dbox.py:106-178 composed with src/util.py:52-75), agreement with the instance engine to rounding, every status, the ways

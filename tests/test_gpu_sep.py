@@ -1,4 +1,4 @@
-"""The separable single pass of the instance engine (round 5, la3d.hip: sweep_sep).  For a camera without ground rotation and
+"""The separable single pass of the instance engine (round 5, la3d_walks.hpp: sweep_sep).  For a camera without ground rotation and
 without skew the x ray depends on the column only, the y ray on the row only and z is the depth itself, so the moments factor into
 per-column sums and all six extents follow from per-column depth ranges + a per-pixel y: ONE walk over the depth instead of two
 passes and a cull plan.  Checked here: parity with the CPU oracle (reference src/util_3dbox.py:106-178 composed with

@@ -167,9 +167,9 @@ def test_config5_size_distribution(la, B):
     np.testing.assert_allclose(got[:, 15:], ref[:, 15:], rtol=0, atol=2e-2)
 
 
-def test_pipelined_batches_and_retaining_build_give_the_same_records(la, monkeypatch):
+def test_pipelined_batches_and_nocull_build_give_the_same_records(la, monkeypatch):
     """Scheduling never shows in the records: (a) batches issued through fit_batches (two streams, launch order off) and
-    (b) the 128-VGPR retaining build (LA3D_RETAIN=1, depth tiles kept in registers / LDS between the passes) are bit-identical
+    (b) the no-cull build (opt_build = LA3D_BUILD_NOCULL: two passes, every active tile walked in pass B) are bit-identical
     to plain serial calls."""
     import torch
 
@@ -199,23 +199,23 @@ def test_pipelined_batches_and_retaining_build_give_the_same_records(la, monkeyp
             if k >= 1:
                 assert torch.equal(views[k - 1][0], want[k - 1][0])
         assert SCHED().launch_order is True      # fit_batches did not touch the caller's setting
-    # the retaining build = the two-pass plain build bit for bit; the default build takes the separable single pass for these
+    # the no-cull build = the two-pass plain build bit for bit; the default build takes the separable single pass for these
     # un-grounded calls (round 5): equal to rounding
     for (depth, masks, K), w in zip(batches[:2], want[:2]):
         monkeypatch.setattr(SCHED(), "build", "plain")
         w2 = tuple(t.clone() for t in la.fit_instances(depth, masks, K))
-        monkeypatch.setattr(SCHED(), "build", "retaining")
+        monkeypatch.setattr(SCHED(), "build", "nocull")
         b, s, a = la.fit_instances(depth, masks, K)
         assert torch.equal(b, w2[0]) and torch.equal(s, w2[1]) and torch.equal(a, w2[2])
         assert torch.equal(s, w[1])
         torch.testing.assert_close(b[:, :15], w[0][:, :15], rtol=1e-11, atol=1e-11)
-    # a batch with masks above the retained capacity (160 tiles per instance) and a non-finite depth (checked re-run)
+    # a batch with masks of more than 160 active tiles and a non-finite depth (checked re-run)
     depth, masks, K, _, _ = bench.make_config5(600, dev, 9)
     depth[3, 200, 300] = float("inf")
     masks[3, 190:260, 280:400] = 1
     monkeypatch.setattr(SCHED(), "build", "plain")
     w = la.fit_instances(depth, masks, K)
-    monkeypatch.setattr(SCHED(), "build", "retaining")
+    monkeypatch.setattr(SCHED(), "build", "nocull")
     g = la.fit_instances(depth, masks, K)
     assert torch.equal(g[0], w[0]) and torch.equal(g[1], w[1])
     monkeypatch.setattr(SCHED(), "build", None)       # default: single pass; instance 3 (inf under the mask) re-runs the two-pass path
