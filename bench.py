@@ -136,24 +136,30 @@ def required_bytes(masks, image_index=None, num_images=0):
     return B * h * w + depth_tiles * 1024 + B * 39 * 8, tiles
 
 
-def measured_stream_ceiling(masks, min_ms=30.0):
+def measured_stream_ceiling(mask_sets, min_ms=30.0):
     """Read-only stream over the SAME mask planes the fit reads (la3d_mask_counts: 16-byte loads, nothing else), timed with HIP
     events on the launch stream: the bandwidth this box delivers to a pure reader in this run ('also report against
-    a measured read-only stream ceiling').  Runs before the warm-up steps, for at least min_ms of GPU time."""
+    a measured read-only stream ceiling').  Like the timed steps it rotates through the resident batches (launch k reads the mask
+    planes of batch k % R: ~0.9 GB in rotation at R = 3, against 256 MB of Infinity Cache - reading ONE batch's 315 MB over and
+    over, as rounds 1-5 did, is served partly from that cache).  Runs before the warm-up steps, for at least min_ms of GPU time."""
     import ctypes as C
 
     from labelany3d_amd._lib import check, lib
-    B, Hh, Ww = masks.shape
-    counts = torch.empty(B, dtype=torch.int32, device=masks.device)
+    if isinstance(mask_sets, torch.Tensor):
+        mask_sets = [mask_sets]
+    B, Hh, Ww = mask_sets[0].shape
+    counts = torch.empty(B, dtype=torch.int32, device=mask_sets[0].device)
     st = torch.cuda.current_stream()
+    R = len(mask_sets)
+    ptrs = [C.c_void_p(m.data_ptr()) for m in mask_sets]
 
-    def run():
-        check(lib.la3d_mask_counts(C.c_void_p(masks.data_ptr()), B, Hh, Ww, C.c_void_p(counts.data_ptr()), C.c_void_p(st.cuda_stream)),
+    def run(k):
+        check(lib.la3d_mask_counts(ptrs[k % R], B, Hh, Ww, C.c_void_p(counts.data_ptr()), C.c_void_p(st.cuda_stream)),
               "la3d_mask_counts")
-    for _ in range(5):
-        run()
+    for k in range(5):
+        run(k)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    nbytes = float(masks.numel())
+    nbytes = float(mask_sets[0].numel())
     # ~min_ms at 5 TB/s; at most 600 launches (a small --batch would otherwise issue thousands of short launches: under a rocprofv3
     # counter pass, which serialises every launch, that alone took 20 minutes at --batch 64)
     iters = min(600, max(20, int(min_ms * 1e-3 * 5.0e12 / nbytes)))
@@ -161,8 +167,8 @@ def measured_stream_ceiling(masks, min_ms=30.0):
     while total_ms < min_ms and reps < 8:
         torch.cuda.synchronize()
         e0.record(st)
-        for _ in range(iters):
-            run()
+        for k in range(iters):
+            run(k)
         e1.record(st)
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)
@@ -874,7 +880,7 @@ def main():
 
     # measured read-only stream ceiling of THIS run (also what brings the chip to its working clocks before the warm-up steps:
     # a 20-step timed region entered from an idle chip reads ~5 % slower, profiles/r03/exp_step_ramp.py)
-    stream_GBps, _, ceiling_launches = measured_stream_ceiling(masks)
+    stream_GBps, _, ceiling_launches = measured_stream_ceiling([x["all_masks"] for x in inputs])
     run.prepare([dict(slot=k, stream=streams[k % len(streams)], ws_slot=(k % len(streams)) if len(streams) > 1 else 0) for k in range(steps)])
     for w_ in range(warmup):
         run(slot=0, stream=stream, batch=w_ % R)

@@ -95,12 +95,42 @@ _SIGS = {
 EXPORTS = tuple(_SIGS)
 
 
+def _refresh_if_stale() -> None:
+    """The library carries the hash of the sources it was compiled from (la3d_build_info).  A library that travelled with a
+    snapshot but was built from OTHER sources than the tree's is rebuilt here, once, under a file lock (several test processes
+    may import at the same time) - when hipcc is there; otherwise it is used as it is, loudly.  LA3D_NO_AUTOBUILD=1 switches
+    the rebuild off (the library is then loaded as it is; bench.py's `build.lib_built_from_tree` tells)."""
+    import sys
+
+    from . import _build
+    try:
+        have = _build.embedded_info(LIB)
+        if have is not None and have[0] == _build.source_sha256():
+            return
+        if os.environ.get("LA3D_NO_AUTOBUILD") == "1" or os.environ.get("LA3D_LIB"):
+            return
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        if not os.path.exists(hipcc):
+            print(f"labelany3d_amd: {LIB} was NOT built from the sources in this tree and there is no hipcc to rebuild it", file=sys.stderr)
+            return
+        import fcntl
+        with open(LIB + ".lock", "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            have = _build.embedded_info(LIB)                    # (another process may have rebuilt it meanwhile)
+            if have is None or have[0] != _build.source_sha256():
+                print(f"labelany3d_amd: {os.path.basename(LIB)} is stale (built from other sources): rebuilding for gfx950 ...", file=sys.stderr)
+                _build.build(force=True)
+    except Exception as e:  # noqa: BLE001 - never in the way of loading what is there
+        print(f"labelany3d_amd: could not refresh {LIB}: {e!r}", file=sys.stderr)
+
+
 def load() -> C.CDLL:
     if not os.path.exists(LIB):
         raise ImportError(
             f"{LIB} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(needs hipcc; cross-compiles gfx950 without a GPU). There is no CPU fallback."
         )
+    _refresh_if_stale()
     # PyTorch bundles its own libamdhip64; load it FIRST so that libla3d.so binds to the same HIP runtime instance as the
     # tensors it is handed (loaded the other way round, the process ends up with two runtimes and the library's stream /
     # event calls fail with "no ROCm-capable device is detected")

@@ -1,27 +1,22 @@
-// la3d.hip — MI355X (gfx950 / CDNA4) kernels and C-ABI for the LabelAny3D geometric hot path:
-// pinhole back-projection of masked depth pixels -> per-object moments -> closed-form PCA yaw
-// -> extents along the principal axes -> 39-double box record.
+// la3d.hip — the C-ABI of la3d_fit_instances* and its dispatcher (MI355X, gfx950 / CDNA4): the LabelAny3D geometric hot path -
+// pinhole back-projection of masked depth pixels -> per-object moments -> closed-form PCA yaw -> extents along the principal
+// axes -> 39-double box record.
 //
 // Reference semantics (behaviour only; nothing is copied):
 //   depth_to_points   /root/reference/src/util.py:52-75
 //   estimate_bbox     /root/reference/src/util_3dbox.py:106-178   (+ helpers :20-103, PCA yaw :181-186)
 //
-// Memory-bound integer/byte + fp64 reduction work: no MFMA.  Layout, kernel design and measurements are in
-// DESIGN.md.  This file holds the INSTANCE and BAND ENGINES of la3d_fit_instances (one workgroup per instance; used for
-// B > 272 (u8 planes) / 288 (run lengths, polygon parts), for the fused instance filter, for reference-subsample mode and
-// for frames the split engine does not take - la3d_split.hip is the other engine) and every other kernel of the C-ABI.  `fit_instances_kernel` in short:
-//   one 512-thread workgroup (8 wave64) per instance, 64 VGPRs / 40 KB LDS -> 4 workgroups per CU (the 128-VGPR "retaining" build of rounds
-//            2-5, which kept depth tiles in registers between the passes, was fastest nowhere since round 4 and is gone: round 6);
-//   order    256 < B <= 3 resident sets: which instance a workgroup fits is decided in the kernel (order_select) from the sort
-//            keys of ONE estimate kernel (or the caller's area hints: no helper launch) - size-balanced, speed only;
-//   phase 0  streams the u8 mask plane once with 16-byte non-temporal loads (or decodes COCO run lengths / rasterises polygon
-//            parts) into a 1-bit-per-pixel image in LDS (38.4 KB for 640x480); meanwhile one lane computes K^-1, Rg, M;
-//   list     deterministic compaction of the 32 px x 8 row tiles that contain a set bit;
-//   pass A   4 listed tiles per wave-step, their float4 depth loads issued back to back; branch-free fp64
-//            accumulation of Sx, Sz, Sxx, Sxz, Szz -> DPP wave reduction -> LDS -> wave 0 (fixed order);
-//   yaw      closed-form 2x2 principal axis with scikit-learn's sign rule, no trigonometry (one lane);
-//   pass B   same walk, six extents in the yaw frame with NaN-ignoring raw v_min/v_max_f64;
-//   epilog   wave 0 writes center / dims / R_cam / fp16-quantised vertices, one lane per output group.
+// Memory-bound integer/byte + fp64 reduction work: no MFMA.  Layout, kernel design and measurements: DESIGN.md.  Round 6 split the
+// former 3 000-line file by engine, one translation unit each (compiled side by side):
+//   la3d_instance.hip   one workgroup per instance: every call the others do not take (fit_instances_kernel)
+//   la3d_rows.hip       up to sixteen workgroups per instance, one per band of rows: un-grounded u8 batches up to 160 instances
+//   la3d_band.hip       two / four workgroups per instance that meet through the workspace: grounded u8 batches of 16..256
+//   la3d_split.hip      scan -> plan -> walk -> axis -> walk -> final over tile ranges: grounded small batches of every mask format
+//   la3d_walks.hpp      the walks over an instance's pixels (generic, tiled two-pass, separable single pass)
+//   la3d_stages.hpp     moments -> axis, extents -> record, the in-kernel launch order, the culling plan, workgroup hand-off primitives
+//   la3d_aux.hip        every other kernel of the C-ABI;  la3d_json.cpp  the host-side writer of 3dbbox.json + the build identity
+// This file: the process defaults read once from the environment (config), workspace sizing, argument checks, and which engine
+// fits a call (fit_dispatch; profiles/r06/r06_engines_by_batch.txt has the row in which each engine is the fastest).
 #include <atomic>
 #include <chrono>
 #include <cstdint>

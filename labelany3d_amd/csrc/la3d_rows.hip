@@ -1,4 +1,5 @@
-// la3d_rows.hip - the ROW ENGINE of la3d_fit_instances (rounds 5-6).
+// la3d_rows.hip - the ROW ENGINE of la3d_fit_instances (rounds 5-6): fit_rows_kernel (one launch: the band that arrives last merges
+// its instance), merge_rows_kernel (the two-launch form) and their launcher.  Un-grounded u8 batches up to 160 instances by default.
 #include <atomic>
 #include <chrono>
 #include <cstdint>
