@@ -219,7 +219,7 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
   }
 
   // ---- active-tile list (deterministic two-pass compaction: count, prefix, write) ----------------
-  int nactive = 0;
+  int nactive = 0, nfull = 0;
   // plain build: the bit image is compacted to the active tiles (eight row words per list entry) and the LDS that frees keeps
   // depth tiles between the passes (sweep_tiled)
   constexpr bool LK = TILED && !SAMPLE;
@@ -236,12 +236,13 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
       // of a tile are read back to back (rows past the frame re-read the last one), no integer division
       unsigned long long bal[4];
       unsigned wrd[LK ? 4 : 1][8];
-      int wcount = 0;
+      int wcount = 0, fcount = 0;
+      unsigned fl = 0;   // bit k: this lane's k-th tile lies completely inside the mask (all eight row words all ones)
       if ((p.H & 7) == 0) {   // uniform: every tile row is complete (the common frame heights) - no row clamp, no select per word
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int t = tbeg + k * 64 + lane;
-          unsigned any = 0;
+          unsigned any = 0, all = 0xffffffffu;
           if (t < tend) {
             const int ty = (int)(((float)t + 0.5f) * p.rcp_ntx), tx = t - ty * p.ntx;  // exact: see fit_dispatch
             const unsigned* bw = bits + (ty * 8) * p.ntx + tx;
@@ -249,17 +250,22 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
             for (int rr = 0; rr < 8; ++rr) {
               const unsigned w = bw[rr * p.ntx];
               any |= w;
-              if constexpr (LK) wrd[k][rr] = w;
+              if constexpr (LK) { wrd[k][rr] = w; all &= w; }
             }
           }
           bal[k] = __ballot(any != 0);
           wcount += __popcll(bal[k]);
+          if constexpr (LK) {
+            const bool f = t < tend && all == 0xffffffffu;
+            fcount += __popcll(__ballot(f));
+            fl |= (f ? 1u : 0u) << k;
+          }
         }
       } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int t = tbeg + k * 64 + lane;
-          unsigned any = 0;
+          unsigned any = 0, all = 0xffffffffu;
           if (t < tend) {
             const int ty = (int)(((float)t + 0.5f) * p.rcp_ntx), tx = t - ty * p.ntx;  // exact: see fit_dispatch
             const int rmax = p.H - 1 - ty * 8;                                        // >= 0
@@ -268,48 +274,57 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
             for (int rr = 0; rr < 8; ++rr) {
               const unsigned w = bw[min(rr, rmax) * p.ntx];
               any |= w;
-              if constexpr (LK) wrd[k][rr] = rr <= rmax ? w : 0u;
+              if constexpr (LK) { wrd[k][rr] = rr <= rmax ? w : 0u; all &= wrd[k][rr]; }
             }
           }
           bal[k] = __ballot(any != 0);
           wcount += __popcll(bal[k]);
+          if constexpr (LK) {
+            const bool f = t < tend && all == 0xffffffffu;   // (a tile row past the frame is stored as zeros: never "full")
+            fcount += __popcll(__ballot(f));
+            fl |= (f ? 1u : 0u) << k;
+          }
         }
       }
-      if (lane == 0) sh->scan[wave] = (unsigned)wcount;
+      if (lane == 0) sh->scan[wave] = (unsigned)wcount | ((unsigned)fcount << 16);   // (at most 256 tiles per wave)
       __syncthreads();
       LA3D_STAMP(14);
+      // Round 6: the list holds the tiles that lie completely inside the mask FIRST ([0, nfull): the separable pass walks them with
+      // a body that needs no mask bits), the others behind them - each class in tile order.  Any order of the list gives a valid
+      // walk; the order only decides how the fp64 partial sums are grouped.
+      int fbase = 0;
       for (int w = 0; w < NWAVE; ++w) {
-        const int c = (int)sh->scan[w];
-        if (w < wave) base += c;
+        const int c = (int)(sh->scan[w] & 0xffffu), f = (int)(sh->scan[w] >> 16);
+        if (w < wave) { base += c - f; fbase += f; }
         nactive += c;
+        nfull += f;
       }
       if (nactive > p.list_cap) {
         nactive = -1;  // uniform: every thread sees the same total
+        nfull = 0;
       } else {
-        int off = base;
+        // (with pass-B culling the compact image also holds the survivor list / the depth ranges behind the entries)
+        // every wave read its row words before the barrier above: the image region can be overwritten in place
+        if constexpr (LK) compact = (nactive * 32 + cull_rng_words(nactive) * 4 <= p.mask_lds_bytes) ? 1 : 0;   // uniform
+        int foff = fbase, poff = nfull + base;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+          const bool isf = LK && ((fl >> k) & 1u);
+          const unsigned long long bf = LK ? __ballot(isf) : 0ull, bp = bal[k] & ~bf, lt = (1ull << lane) - 1ull;
           if ((bal[k] >> lane) & 1ull) {
             const int t = tbeg + k * 64 + lane;
             const int ty = (int)(((float)t + 0.5f) * p.rcp_ntx), tx = t - ty * p.ntx;
-            list[off + __popcll(bal[k] & ((1ull << lane) - 1ull))] = (unsigned short)((ty << 8) | tx);
-          }
-          off += __popcll(bal[k]);
-        }
-        // (with pass-B culling the compact image also holds the survivor list / the depth ranges behind the entries)
-        if constexpr (LK) if (nactive * 32 + cull_rng_words(nactive) * 4 <= p.mask_lds_bytes) {   // uniform
-          // every wave read its row words before the barrier above: the image region can be overwritten in place
-          compact = 1;
-          off = base;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            if ((bal[k] >> lane) & 1ull) {
-              uint4* e = reinterpret_cast<uint4*>(bits) + 2 * (off + __popcll(bal[k] & ((1ull << lane) - 1ull)));
+            const int idx = isf ? foff + __popcll(bf & lt) : poff + __popcll(bp & lt);
+            list[idx] = (unsigned short)((ty << 8) | tx);
+            if constexpr (LK) if (compact) {   // uniform
+              uint4* e = reinterpret_cast<uint4*>(bits) + 2 * idx;
               e[0] = make_uint4(wrd[k][0], wrd[k][1], wrd[k][2], wrd[k][3]);
               e[1] = make_uint4(wrd[k][4], wrd[k][5], wrd[k][6], wrd[k][7]);
             }
-            off += __popcll(bal[k]);
           }
+          foff += __popcll(bf); poff += __popcll(bp);
+        }
+        if constexpr (LK) if (compact) {   // uniform
           if (sep_cam && nactive * 32 + sep_col_words(p.W) * 4 <= p.mask_lds_bytes) {   // uniform
             sep = true;   // per-column depth range behind the entries: [min | max], the identities of unsigned min / max
             unsigned* col = bits + nactive * 8;
@@ -359,8 +374,8 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
       unsigned* col = bits + nactive * 8;
       double sacc[5] = {0, 0, 0, 0, 0}, yx[2] = {INFINITY, -INFINITY};
       unsigned unsafe = 0u;
-      if (p.H & 7) sweep_sep<true>(p, dpl, bits, list, nactive, Mg, col, wave, lane, sacc, yx, &unsafe);   // uniform
-      else sweep_sep<false>(p, dpl, bits, list, nactive, Mg, col, wave, lane, sacc, yx, &unsafe);
+      if (p.H & 7) sweep_sep<true>(p, dpl, bits, list, nactive, Mg, col, wave, lane, sacc, yx, &unsafe, 0, nfull);   // uniform
+      else sweep_sep<false>(p, dpl, bits, list, nactive, Mg, col, wave, lane, sacc, yx, &unsafe, 0, nfull);
       if (__ballot(unsafe >= 0x7f800000u) != 0ull && lane == 0) sh->sep_bad = 1;   // NaN / inf / negative depth under the mask
       // (the wave's y extent waits in scalar registers while the axis is computed: four vector registers fewer across that stage)
       const double ylo_w = uniform_f64(wave_min(yx[0])), yhi_w = uniform_f64(wave_max(yx[1]));
