@@ -762,6 +762,8 @@ def main():
     ap.add_argument("--no-steady", action="store_true", help="skip the steady-state secondary figure (counter passes: profiles/run_profile.sh "
                                                              "divides the counters by the launches of --steps + --warmup)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the secondary two-stream pipelined measurement")
+    ap.add_argument("--no-same-batch", action="store_true", help="skip the secondary loop of K steps that all read batch 0 (counter passes divide "
+                                                                 "by the launches of --steps + --warmup)")
     ap.add_argument("--rle", action="store_true",
                     help="feed the masks as COCO run lengths (la3d_fit_instances_rle) instead of u8 planes; NOT the "
                          "BASELINE config-2 input format, reported for the mask-ingestion row only")
@@ -921,7 +923,7 @@ def main():
     # GPU time, HIP events on the launch stream) - what a caller that keeps fitting batches sees.
     # secondary, right behind the timed region: the same K serial steps all reading batch 0 (the protocol of rounds 1-5), HIP events
     same_batch_ms = None
-    if R > 1 and len(streams) == 1:
+    if R > 1 and len(streams) == 1 and not args.no_same_batch:
         sb0, sb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         sb0.record(stream)

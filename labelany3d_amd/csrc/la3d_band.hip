@@ -67,31 +67,48 @@ __device__ inline void band_moments_to_axis(Shared* sh, const FitParams& p, int 
     for (int k = 0; k < 5; ++k) { s[k] += dpp_f64<DPP_XOR1>(s[k]); s[k] += dpp_f64<DPP_XOR2>(s[k]); s[k] += dpp_f64<DPP_HALF_MIRROR>(s[k]); }
     n += dpp_i32<DPP_XOR1>(n); n += dpp_i32<DPP_XOR2>(n); n += dpp_i32<DPP_HALF_MIRROR>(n);
     nm += dpp_i32<DPP_XOR1>(nm); nm += dpp_i32<DPP_XOR2>(nm); nm += dpp_i32<DPP_HALF_MIRROR>(nm);
+    // Round 6: the record goes out as four 16-byte write-through stores and comes back as ONE batch of four 16-byte loads per band,
+    // band b's record into lane b, all bands at once (rounds 4-5: seven 8-byte agent-scope stores, then 7 x NB agent-scope loads
+    // one after the other - the compiler waits for every atomic load -: ~25 of the ~35 us of a small grounded call)
+    double* x = band_xch<NB>(p, inst);
+    int timeout_i = 0;
     if (lane == 0) {
-      double* x = band_xch<NB>(p, inst);
-      double* mine = x + (h * 2 + round) * BAND_XD;
-#pragma unroll
-      for (int k = 0; k < 5; ++k) st_agent(mine + k, s[k]);
-      st_agent(mine + 5, (double)n); st_agent(mine + 6, (double)nm);
+      uint4* mine = reinterpret_cast<uint4*>(x + (h * 2 + round) * BAND_XD);
+      auto pair = [](double a, double b) {
+        return make_uint4((unsigned)__double2loint(a), (unsigned)__double2hiint(a), (unsigned)__double2loint(b), (unsigned)__double2hiint(b));
+      };
+      st16_through(mine + 0, pair(s[0], s[1]));
+      st16_through(mine + 1, pair(s[2], s[3]));
+      st16_through(mine + 2, pair(s[4], (double)n));
+      st16_through(mine + 3, pair((double)nm, 0.0));
       band_release();                                      // the record's stores are acknowledged before the arrival is issued
       unsigned long long* arrive = p.band_arrive + (long long)inst * 4 + round;
       const unsigned spin_max = p.band_test == 1 ? (1u << 10) : BAND_SPIN_MAX;
       unsigned spins = 0;
-      if (tagged_arrive(arrive, p.band_tag) < (unsigned)NB)
+      if (tagged_arrive_many(arrive, p.band_tag) < (unsigned)NB)
       while (tagged_count(arrive, p.band_tag) < (unsigned)NB && spins < spin_max) {
         __builtin_amdgcn_s_sleep(4);
         ++spins;
       }
-      const bool timeout = spins >= spin_max;
-      band_acquire();                                      // the other bands' records are read after their arrivals were seen
-      double t[5] = {0, 0, 0, 0, 0}, tn = 0, tm = 0;
-#pragma unroll 1   // (unrolled, the compiler keeps all NB records in flight: 56 registers at NB = 4 -> spills)
-      for (int hb = 0; hb < NB; ++hb) {                    // band order: the same sum in every band of the instance
-        const double* r = x + (hb * 2 + round) * BAND_XD;
+      timeout_i = spins >= spin_max ? 1 : 0;
+    }
+    const bool timeout = __builtin_amdgcn_readfirstlane(timeout_i) != 0;
+    band_acquire();                                        // the other bands' records are read after their arrivals were seen
+    // lane 4 b + q holds granule q of band b's record: ONE 16-byte load per lane, all of them in flight together
+    double d0 = 0.0, d1 = 0.0;
+    if (lane < 4 * NB) {
+      const u32x4 g = ld16_through(reinterpret_cast<const u32x4*>(x + ((lane >> 2) * 2 + round) * BAND_XD) + (lane & 3));
+      d0 = __hiloint2double((int)g[1], (int)g[0]); d1 = __hiloint2double((int)g[3], (int)g[2]);
+    }
+    double t[5] = {0, 0, 0, 0, 0}, tn = 0, tm = 0;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) t[k] += ld_agent(r + k);
-        tn += ld_agent(r + 5); tm += ld_agent(r + 6);
-      }
+    for (int hb = 0; hb < NB; ++hb) {                      // band order: the same sum in every band of the instance
+      t[0] += readlane_f64(d0, 4 * hb); t[1] += readlane_f64(d1, 4 * hb);
+      t[2] += readlane_f64(d0, 4 * hb + 1); t[3] += readlane_f64(d1, 4 * hb + 1);
+      t[4] += readlane_f64(d0, 4 * hb + 2); tn += readlane_f64(d1, 4 * hb + 2);
+      tm += readlane_f64(d0, 4 * hb + 3);
+    }
+    if (lane == 0) {
       const int nt = (int)tn;
       double gap = NAN;
       int st = LA3D_BOX_OK;
@@ -392,21 +409,30 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_bands_kernel(const FitParams 
   }
   double* xe = band_xch<NB>(p, inst_p) + NB * 2 * BAND_XD;   // [NB][6]
   int last = 0;
-  if (lane == 0) {
+  if (lane == 0) {   // three 16-byte write-through stores: (lo, hi) of x, y, z
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { st_agent(xe + h * 6 + 2 * k, lo[k]); st_agent(xe + h * 6 + 2 * k + 1, hi[k]); }
+    for (int k = 0; k < 3; ++k)
+      st16_through(reinterpret_cast<uint4*>(xe + h * 6) + k, make_uint4((unsigned)__double2loint(lo[k]), (unsigned)__double2hiint(lo[k]),
+                                                                        (unsigned)__double2loint(hi[k]), (unsigned)__double2hiint(hi[k])));
     band_release();
-    last = tagged_arrive(p.band_arrive + (long long)inst_p * 4 + 2, p.band_tag) == (unsigned)NB ? 1 : 0;
-    band_acquire();
+    last = tagged_arrive_many(p.band_arrive + (long long)inst_p * 4 + 2, p.band_tag) == (unsigned)NB ? 1 : 0;
   }
   last = __builtin_amdgcn_readfirstlane(last);
   if (!last) return;
+  band_acquire();
+  {   // lane 4 b + k holds (lo, hi) of axis k of band b: one 16-byte load per lane, then min / max over the bands
+    double el = INFINITY, eh = -INFINITY;
+    if (lane < 4 * NB && (lane & 3) < 3) {
+      const u32x4 g = ld16_through(reinterpret_cast<const u32x4*>(xe + (lane >> 2) * 6) + (lane & 3));
+      el = __hiloint2double((int)g[1], (int)g[0]); eh = __hiloint2double((int)g[3], (int)g[2]);
+    }
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {   // min / max over the bands (uniform loads: every lane reads the same words)
-    double l = ld_agent(xe + 2 * k), u = ld_agent(xe + 2 * k + 1);
-#pragma unroll 1
-    for (int hb = 1; hb < NB; ++hb) { l = fmin(l, ld_agent(xe + hb * 6 + 2 * k)); u = fmax(u, ld_agent(xe + hb * 6 + 2 * k + 1)); }
-    lo[k] = uniform_f64(l); hi[k] = uniform_f64(u);
+    for (int k = 0; k < 3; ++k) {
+      double l = readlane_f64(el, k), u = readlane_f64(eh, k);
+#pragma unroll
+      for (int hb = 1; hb < NB; ++hb) { l = fmin(l, readlane_f64(el, 4 * hb + k)); u = fmax(u, readlane_f64(eh, 4 * hb + k)); }
+      lo[k] = uniform_f64(l); hi[k] = uniform_f64(u);
+    }
   }
   double Rg[9];
 #pragma unroll

@@ -640,6 +640,12 @@ __device__ inline void st16_through(void* q, uint4 v) {
 // Four independent 16-byte loads of such data in flight at once, then one wait: the compiler puts an s_waitcnt vmcnt(0) behind EVERY
 // agent-scope atomic load (measured: the merge of sixteen bands through __hip_atomic_load took 20 us), and it cannot see into inline
 // assembly, so the wait is part of the block.  (Early-clobber outputs: no result register doubles as a later address.)
+// one such load (and its wait): where the loads of a hand-off can be spread over lanes instead of batched in one
+__device__ inline u32x4 ld16_through(const void* q) {
+  u32x4 r;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(q) : "memory");
+  return r;
+}
 __device__ inline void ld16x4_through(const void* p0, const void* p1, const void* p2, const void* p3, u32x4* a, u32x4* b, u32x4* c, u32x4* d) {
   u32x4 r0, r1, r2, r3;
   asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\t"

@@ -14,7 +14,7 @@ from collections import defaultdict
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from summarize import short  # noqa: E402
 
-OURS = ("fit_instances_kernel", "fit_bands_kernel", "size_estimate_kernel", "scan_kernel", "plan_kernel", "walk_kernel", "axis_kernel", "final_kernel", "geo_kernel",
+OURS = ("fit_instances_kernel", "fit_bands_kernel", "fit_rows_kernel", "merge_rows_kernel", "size_estimate_kernel", "scan_kernel", "plan_kernel", "walk_kernel", "axis_kernel", "final_kernel", "geo_kernel",
         "fit_points", "project_boxes_kernel", "mask_counts_kernel")
 
 

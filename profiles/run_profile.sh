@@ -13,10 +13,10 @@ OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $REPO/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-pipelined --no-steady $EXTRA"
+BENCH="python $REPO/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-pipelined --no-steady --no-same-batch $EXTRA"
 # 1) per-kernel time of the default-length command
 if [ "${LIGHT:-0}" != "1" ]; then
-  rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o stats -- python $REPO/bench.py --no-cpu-baseline --no-pipelined $EXTRA > $OUT/stats.log 2>&1
+  rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o stats -- python $REPO/bench.py --no-cpu-baseline --no-pipelined --no-same-batch $EXTRA > $OUT/stats.log 2>&1
 fi
 # 2) HBM traffic counters, one pass each (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2); never with sys/hip traces
 rocprofv3 --output-format csv --kernel-trace --stats --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- $BENCH > $OUT/fetch.log 2>&1
