@@ -345,11 +345,11 @@ void la3d_host_release(void);   /* frees the calling thread's staging memory and
  * decode + the reference's keep rule + fit (la3d_fit_instances_ex with the filter fields) -> records.  `args` is a la3d_fit_args in which
  * `depth` is a DEVICE pointer (the image's depth plane(s), resident) and EVERY OTHER pointer is a HOST pointer: rle_counts / rle_offsets
  * or poly_xy / ring_offsets / inst_rings, K, image_index, ground, area_hint in; out / status / aux / stats out.  mask, sample_idx, proj
- * and workspace must be NULL / are ignored (the library uses the calling thread's staging memory and private stream).
- * `stream` = the stream the depth plane(s) were PRODUCED on (NULL = the legacy default stream): the private stream is ordered behind
- * everything that stream holds at the time of the call (one event), so a depth map a model / an upload / la3d_pad_rows has only
- * enqueued there is complete before the fit reads it.  Depth produced on any other stream must be complete before the call.  The
- * depth must live on the CURRENT device of the calling thread (hipSetDevice before the call).
+ * and workspace must be NULL / are ignored (the library uses the calling thread's staging memory).
+ * `stream` = the stream the depth plane(s) were PRODUCED on (NULL = the legacy default stream): the call's upload, fit and completion
+ * flag are enqueued on THAT stream, behind everything it holds, so a depth map a model / an upload / la3d_pad_rows has only enqueued
+ * there is complete before the fit reads it.  Depth produced on any other stream must be complete before the call.  The depth must
+ * live on the CURRENT device of the calling thread (hipSetDevice before the call).
  * Synchronous.  Replaces read_bounding_boxes_segmentations + the per-object fit for one image: src/util.py:336-383, util_3dbox.py:250-281. */
 int la3d_fit_annotations_host(const la3d_fit_args* args);
 

@@ -1781,7 +1781,6 @@ namespace {
 struct HostCtx {
   int device = -1;
   hipStream_t stream = nullptr;
-  hipEvent_t after = nullptr;        // orders the private stream behind the stream that produced the caller's device data
   unsigned char* pin = nullptr;      // pinned host block, mapped into the device's address space
   unsigned char* pin_dev = nullptr;  // ... its device address
   size_t pin_bytes = 0;
@@ -1793,7 +1792,6 @@ thread_local HostCtx t_host;
 
 void host_ctx_release(HostCtx& c) {
   if (c.stream) { (void)hipStreamSynchronize(c.stream); (void)hipStreamDestroy(c.stream); }
-  if (c.after) (void)hipEventDestroy(c.after);
   if (c.pin) (void)hipHostFree(c.pin);
   if (c.dev) (void)hipFree(c.dev);
   c = HostCtx();
@@ -1814,9 +1812,6 @@ int host_ctx(HostCtx** out, size_t pin_need, size_t dev_need, const char* who) {
     c.device = dev;
     if (hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) != hipSuccess) {
       snprintf(g_err, sizeof(g_err), "%s: hipStreamCreate failed", who); (void)hipGetLastError(); c = HostCtx(); return LA3D_ERR_HIP;
-    }
-    if (hipEventCreateWithFlags(&c.after, hipEventDisableTiming) != hipSuccess) {
-      snprintf(g_err, sizeof(g_err), "%s: hipEventCreate failed", who); (void)hipGetLastError(); (void)hipStreamDestroy(c.stream); c = HostCtx(); return LA3D_ERR_HIP;
     }
   }
   auto grow = [](size_t need) { size_t n = 64 * 1024; while (n < need) n *= 2; return n; };
@@ -1991,12 +1986,12 @@ int la3d_fit_annotations_host(const la3d_fit_args* args) {
   if (a.ground) memcpy(h + o_ground, a.ground, (size_t)B * 32);
   if (a.area_hint) memcpy(h + o_hint, a.area_hint, (size_t)B * 4);
   *reinterpret_cast<volatile unsigned*>(h) = 0;   // the completion flag: la3d_estimate_bbox_host (hull) writes offsets over it
-  // The depth plane(s) were produced on the CALLER's stream (a depth model's output, an upload, la3d_pad_rows ...), the fit runs on
-  // this thread's private non-blocking stream: order the latter behind everything the former holds so far.  args->stream names the
-  // producer stream; NULL = the legacy default stream.
-  if (hipEventRecord(c->after, static_cast<hipStream_t>(a.stream)) != hipSuccess || hipStreamWaitEvent(c->stream, c->after, 0) != hipSuccess)
-    return check_launch("la3d_fit_annotations_host: ordering behind the producer stream");
-  if (hipMemcpyAsync(c->dev + 64, h + 64, in_end - 64, hipMemcpyHostToDevice, c->stream) != hipSuccess) return check_launch("la3d_fit_annotations_host: upload");
+  // The depth plane(s) were produced on the CALLER's stream (a depth model's output, an upload, la3d_pad_rows ...): the whole call -
+  // upload, fit, flag - is enqueued on THAT stream (args->stream; NULL = the legacy default stream), behind everything it holds, so
+  // no cross-stream ordering is needed (an event record + a stream wait on the thread's private stream cost 8 us per call).  The
+  // call is synchronous either way: it returns when the flag behind the fit has been raised.
+  const hipStream_t ws = static_cast<hipStream_t>(a.stream);
+  if (hipMemcpyAsync(c->dev + 64, h + 64, in_end - 64, hipMemcpyHostToDevice, ws) != hipSuccess) return check_launch("la3d_fit_annotations_host: upload");
   la3d_fit_args d = a;
   d.struct_size = (int32_t)sizeof(la3d_fit_args);
   d.image_index = a.image_index ? reinterpret_cast<const int32_t*>(c->dev + o_idx) : nullptr;
@@ -2011,12 +2006,12 @@ int la3d_fit_annotations_host(const la3d_fit_args* args) {
   d.status = reinterpret_cast<int32_t*>(c->pin_dev + o_status);
   d.stats = a.stats ? reinterpret_cast<int32_t*>(c->pin_dev + o_stats) : nullptr;
   d.workspace = c->dev + d_ws;
-  d.stream = c->stream;
+  d.stream = ws;
   const int frc = la3d_fit_instances_ex(&d);
   if (frc != LA3D_SUCCESS) return frc;
   if (++c->seq == 0) c->seq = 1;
   volatile unsigned* done = reinterpret_cast<volatile unsigned*>(c->pin);
-  hipLaunchKernelGGL(host_flag_kernel, dim3(1), dim3(1), 0, c->stream, reinterpret_cast<unsigned*>(c->pin_dev), c->seq);
+  hipLaunchKernelGGL(host_flag_kernel, dim3(1), dim3(1), 0, ws, reinterpret_cast<unsigned*>(c->pin_dev), c->seq);
   const int lrc = check_launch("host_flag_kernel");
   if (lrc != LA3D_SUCCESS) return lrc;
   bool seen = false;
@@ -2027,7 +2022,7 @@ int la3d_fit_annotations_host(const la3d_fit_args* args) {
         std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > 5000) break;
   }
   std::atomic_thread_fence(std::memory_order_acquire);
-  if (!seen && hipStreamSynchronize(c->stream) != hipSuccess) return check_launch("la3d_fit_annotations_host");
+  if (!seen && hipStreamSynchronize(ws) != hipSuccess) return check_launch("la3d_fit_annotations_host");
   memcpy(a.out, h + o_out, (size_t)B * LA3D_REC * 8);
   if (a.aux) memcpy(a.aux, h + o_aux, (size_t)B * LA3D_AUX * 8);
   memcpy(a.status, h + o_status, (size_t)B * 4);

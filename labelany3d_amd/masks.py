@@ -505,6 +505,15 @@ def fit_annotations_all(annotations, image_size, depth, K, ground=None, image_in
     return boxes, status
 
 
+def _raw_stream(dev_index: int) -> int:
+    """torch's current stream of a device as a hipStream_t value (the private accessor is ~10 x cheaper than building a Stream object:
+    this sits on a ~100 us per-image path)."""
+    try:
+        return torch._C._cuda_getCurrentRawStream(dev_index)
+    except AttributeError:
+        return torch.cuda.current_stream(dev_index).cuda_stream
+
+
 def _fit_annotations_host(annotations, groups, W_img, H_img, depth, K, ground, image_index, flt):
     """``fit_annotations(to_host=True)`` with the depth plane(s) resident and everything else on the host: ONE foreign call per
     segmentation kind (``la3d_fit_annotations_host``: the small arrays go up through the library's pinned block, the records come back
@@ -512,6 +521,7 @@ def _fit_annotations_host(annotations, groups, W_img, H_img, depth, K, ground, i
     from ._lib import FitArgs
 
     P = depth.shape[0] if depth.dim() == 3 else 1
+    dev_index = depth.device.index if depth.device.index is not None else torch.cuda.current_device()
     Wp = padded_width(W_img)
     if Wp != W_img:   # a frame of odd width: rows padded to the next multiple of 32, frame_width says where the image ends
         depth, _ = pad_depth_rows(depth, depth.device)
@@ -563,11 +573,14 @@ def _fit_annotations_host(annotations, groups, W_img, H_img, depth, K, ground, i
         out = np.empty((B, REC), np.float64)
         st = np.empty(B, np.int32)
         a.out, a.status = out.ctypes.data, st.ctypes.data
-        # the C entry fits on the library's private stream of this thread, on the thread's CURRENT device: make that the depth's
-        # device and name the stream the depth (and the padding above) was produced on, which the entry orders itself behind
-        with torch.cuda.device(depth.device):
-            a.stream = torch.cuda.current_stream(depth.device).cuda_stream
+        # the C entry enqueues on the stream it is handed, on the thread's CURRENT device: the depth's device, and the stream the
+        # depth (and the padding above) was produced on - torch's current stream of that device
+        a.stream = _raw_stream(dev_index)
+        if dev_index == torch.cuda.current_device():
             check(lib.la3d_fit_annotations_host(C.byref(a)), "la3d_fit_annotations_host")
+        else:
+            with torch.cuda.device(dev_index):
+                check(lib.la3d_fit_annotations_host(C.byref(a)), "la3d_fit_annotations_host")
         sels.append(sel); recs.append(out); sts.append(st)
     if not sels:
         return [], np.zeros(0, np.int64), [], np.zeros((0, REC)), np.zeros(0, np.int32)
