@@ -77,6 +77,11 @@ def one(B, sizes="bench"):
         _run = f.run
         f.run = lambda d, m, k: _run(d, m, k, sample_idx=si)
         sizes += " (subsample mode)"
+    if os.environ.get("TL_GROUND"):  # one ground plane per instance (the two-pass form; u8 planes only)
+        gr = torch.as_tensor(np.array([[0.02, -0.97, 0.1, 1.2]] * B) + 0.03 * np.random.RandomState(77).randn(B, 4), device=dev)
+        _run2 = f.run
+        f.run = lambda d, m, k: _run2(d, m, k, ground=gr)
+        sizes += " (grounded)"
     for _ in range(5):
         f.run(depth, masks, K)
     torch.cuda.synchronize()
