@@ -521,11 +521,11 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
       constexpr bool SP = !SAMPLE;
       const bool specA = SP && Mg[6] == 0.0 && Mg[7] == 0.0 && Mg[8] == 1.0;   // uniform
       if (LK && cull) {
-        if (specA) sweep_tiled<0, false, true, SP>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, nullptr, compact, rng_words);
-        else sweep_tiled<0, false, true>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, nullptr, compact, rng_words);
+        if (specA) sweep_tiled<0, false, true, SP>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, nullptr, compact, rng_words, -1, nfull);
+        else sweep_tiled<0, false, true>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, nullptr, compact, rng_words, -1, nfull);
       } else {
-        if (specA) sweep_tiled<0, false, false, SP>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, nullptr, compact, rng_words);
-        else sweep_tiled<0, false>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, nullptr, compact, rng_words);
+        if (specA) sweep_tiled<0, false, false, SP>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, nullptr, compact, rng_words, -1, nfull);
+        else sweep_tiled<0, false>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, nullptr, compact, rng_words, -1, nfull);
       }
       cnt = nmask;   // the optimistic pass does not count: with every masked depth finite, valid pixels = mask pixels
     }
@@ -540,8 +540,8 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
     for (int i = 0; i < 5; ++i) acc[i] = 0;
     cnt = 0;
     checked = true;
-    if (LK && cull) sweep_tiled<0, true, true>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, nullptr, compact, rng_words);
-    else sweep_tiled<0, true>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, nullptr, compact, rng_words);
+    if (LK && cull) sweep_tiled<0, true, true>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, nullptr, compact, rng_words, -1, nfull);
+    else sweep_tiled<0, true>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, nullptr, compact, rng_words, -1, nfull);
     stage_moments_to_axis(sh, p, inst_p, acc, cnt, nmask, tid, wave, lane, false);
   }
   LA3D_STAMP(4);

@@ -145,7 +145,7 @@ __device__ inline void tile_coords(const TileCtx& c, const unsigned short* list,
 // "defines" the quad without an instruction).  That is harmless by construction: every consumer gates a quad through its
 // nibble (pass A ANDs the validity word into the bits, pass B ORs its complement, tile_range does both), and saves four moves
 // per tile.
-template <int PASS, bool LK, bool SURV = false, bool ZERO = true>
+template <int PASS, bool LK, bool SURV = false, bool ZERO = true, bool FULLC = false>
 __device__ inline unsigned tile_fetch(const TileCtx& c, const float* __restrict__ dpl, const unsigned* bits,
                                       const unsigned short* list, int nsteps, bool dense, int j0, int rev_base, uint4* dq,
                                       int* tcs = nullptr) {   // tcs (SURV): the tiles' coordinates for tile_compute, which then need not look them up again
@@ -170,7 +170,10 @@ __device__ inline unsigned tile_fetch(const TileCtx& c, const float* __restrict_
       } else {
         tile_coords<false>(c, list, dense, j, rev_base, &txs[g], &tys[g]);
       }
-      if (LK && c.compact) {   // uniform
+      if (FULLC) {   // a tile of the list's first class: every pixel is a mask pixel - no row word to fetch (round 6)
+        ent[g] = j;
+        nib[g] = 0xFu;
+      } else if (LK && c.compact) {   // uniform
         if (!SURV) ent[g] = rev_base >= 0 ? rev_base - j : j;
         nib[g] = (bits[ent[g] * 8 + c.r] >> (c.cq * 4)) & 0xFu;   // rows past the frame were stored as zeros
       } else {
@@ -198,7 +201,7 @@ __device__ inline unsigned tile_fetch(const TileCtx& c, const float* __restrict_
 // maximum an unsigned max over (bits & valid) (invalid -> 0).  A negative, infinite or NaN depth makes the maximum >= 0x7f800000,
 // which cull_bound1's caller reads as "unbounded: never cull".  Six DPP steps per value leave the wave's result in lane 63, which stores it.
 constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
-template <bool CHK>
+template <bool CHK, bool FULLC = false>
 __device__ inline void tile_range(const TileCtx& c, int e, unsigned nib, const unsigned* db) {
   // per pixel: the validity word m (0 / -1) and db & m are the pixel math's own values (same expressions: shared after inlining);
   // db | ~m is one v_bfi_b32 (m ? db : ones).  The cross-lane steps carry the operation's identity as `old`, which lets the
@@ -206,6 +209,7 @@ __device__ inline void tile_range(const TileCtx& c, int e, unsigned nib, const u
   unsigned w[4], v[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
+    if (FULLC && !CHK) { v[k] = db[k]; w[k] = db[k]; continue; }   // every pixel valid: nothing to gate
     int m = -(int)((nib >> k) & 1u);
     if (CHK) m = (((int)(db[k] & 0x7fffffffu) - 0x7f800000) >> 31) & m;
     v[k] = db[k] & (unsigned)m;
@@ -225,7 +229,7 @@ __device__ inline void tile_range(const TileCtx& c, int e, unsigned nib, const u
 }
 
 // stage 2: the pixel math of a step on quads dq / nibbles pk (all lanes; unmasked lanes carry zeros / NaNs)
-template <int PASS, bool CHK, bool LK = false, bool SURV = false, bool RNG = false, bool SPEC = false>
+template <int PASS, bool CHK, bool LK = false, bool SURV = false, bool RNG = false, bool SPEC = false, bool FULLC = false>
 __device__ inline void tile_compute(const TileCtx& c, const unsigned short* list, int nsteps, bool dense, int j0, int rev_base,
                                     const uint4* dq, unsigned pk, double* sv, int* n, const int* tcs = nullptr) {
 #pragma unroll
@@ -233,8 +237,8 @@ __device__ inline void tile_compute(const TileCtx& c, const unsigned short* list
     const int j = j0 + g;
     if (j >= nsteps) continue;   // wave-uniform
     if (LK && PASS == 0 && j < c.keepn) c.keep[j * 64 + (c.r * 8 + c.cq)] = dq[g];   // (pass A walks the list forwards: entry = j)
-    const unsigned nib = (pk >> (4 * g)) & 0xFu;
-    if (dense && __ballot(nib != 0) == 0) continue;
+    const unsigned nib = FULLC ? 0xFu : (pk >> (4 * g)) & 0xFu;
+    if (!FULLC && dense && __ballot(nib != 0) == 0) continue;
     int tx, ty;
     if (SURV && tcs) { tx = tcs[g] & 0xff; ty = tcs[g] >> 8; }
     else tile_coords<SURV>(c, list, dense, j, rev_base, &tx, &ty);
@@ -245,7 +249,7 @@ __device__ inline void tile_compute(const TileCtx& c, const unsigned short* list
     double r1 = 0;
     if (PASS == 1) r1 = fma(c.a10, ud, fma(c.a11, vd, c.a12));
     quad_math<PASS, CHK, SPEC>(nib, db, r0, r1, r2, c.a00, c.a10, c.a20, sv, n);
-    if (RNG && PASS == 0) tile_range<CHK>(c, j, nib, db);
+    if (RNG && PASS == 0) tile_range<CHK, FULLC>(c, j, nib, db);
   }
 }
 
@@ -264,7 +268,9 @@ template <int PASS, bool CHK, bool RNG = false, bool SPEC = false>
 __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__ dpl, const unsigned* bits,
                                    const unsigned short* list, int nactive, const double* A0, const double* A1,
                                    const double* A2, int wave, int lane, double* acc, int* cnt,
-                                   unsigned* qhead = nullptr, int compact = 0, int rng_words = 0, int nsurv = -1) {
+                                   unsigned* qhead = nullptr, int compact = 0, int rng_words = 0, int nsurv = -1, int nfull = 0) {
+  // nfull (pass A, compact image): list entries [0, nfull) are tiles completely inside the mask - walked by a loop of their own whose
+  // body fetches no row words and gates no pixel (round 6: what the separable pass does, for the calls that need two passes)
   constexpr bool LK = true;   // (the compact image / LDS-kept tiles / survivor walk apply whenever the caller hands over `compact`)
   TileCtx c;
   c.W = p.W; c.H = p.H; c.ntx = p.ntx; c.r = lane >> 3; c.cq = lane & 7;
@@ -302,7 +308,16 @@ __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__
       tile_compute<PASS, CHK, LK, true, false, SPEC>(c, list, nsurv, false, j0, -1, dq, pk, sv, &n, tcs);
     }
   } else {
-    for (int j0 = jstart; j0 < nsteps; j0 += NWAVE * TG) {
+    int jfirst = jstart;
+    if (PASS == 0 && nfull > 0 && c.compact && !dense) {   // uniform
+      for (int j0 = jstart; j0 < nfull; j0 += NWAVE * TG) {
+        uint4 dq[TG];
+        const unsigned pk = tile_fetch<PASS, LK, false, false, true>(c, dpl, bits, list, nfull, false, j0, -1, dq);
+        tile_compute<PASS, CHK, LK, false, RNG && LK, SPEC, true>(c, list, nfull, false, j0, -1, dq, pk, sv, &n);
+      }
+      jfirst = nfull + jstart;
+    }
+    for (int j0 = jfirst; j0 < nsteps; j0 += NWAVE * TG) {
       uint4 dq[TG];
       const unsigned pk = tile_fetch<PASS, LK, false, false>(c, dpl, bits, list, nsteps, dense, j0, rev_base, dq);
       tile_compute<PASS, CHK, LK, false, RNG && LK, SPEC>(c, list, nsteps, dense, j0, rev_base, dq, pk, sv, &n);
