@@ -197,7 +197,7 @@ def kernel_source_sha256():
     import hashlib
     h = hashlib.sha256()
     for f in ("la3d.hip", "la3d_instance.hip", "la3d_band.hip", "la3d_rows.hip", "la3d_walks.hpp", "la3d_stages.hpp", "la3d_engines.hpp",
-              "la3d_device.hpp", "la3d_poly.hpp", "la3d_split.hip", "la3d_aux.hip"):
+              "la3d_device.hpp", "la3d_poly.hpp", "la3d_split.hip", "la3d_points.hip", "la3d_masks.hip", "la3d_consumers.hip"):
         h.update(open(os.path.join(ROOT, "labelany3d_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 # one translation unit per engine (compiled side by side), the C-ABI + dispatcher, the other kernels, the host-side JSON writer (last:
 # it carries the build identity)
-SOURCES = [os.path.join(CSRC, f) for f in ("la3d_instance.hip", "la3d_band.hip", "la3d_rows.hip", "la3d_split.hip", "la3d_aux.hip", "la3d.hip",
+SOURCES = [os.path.join(CSRC, f) for f in ("la3d_instance.hip", "la3d_band.hip", "la3d_rows.hip", "la3d_split.hip", "la3d_points.hip", "la3d_masks.hip", "la3d_consumers.hip", "la3d.hip",
                                            "la3d_json.cpp")]
 HEADERS = [os.path.join(CSRC, f) for f in ("la3d_device.hpp", "la3d_walks.hpp", "la3d_stages.hpp", "la3d_engines.hpp", "la3d_poly.hpp")] + \
           [os.path.join(ROOT, "include", "la3d.h")]

@@ -14,7 +14,9 @@
 //   la3d_split.hip      scan -> plan -> walk -> axis -> walk -> final over tile ranges: grounded small batches of every mask format
 //   la3d_walks.hpp      the walks over an instance's pixels (generic, tiled two-pass, separable single pass)
 //   la3d_stages.hpp     moments -> axis, extents -> record, the in-kernel launch order, the culling plan, workgroup hand-off primitives
-//   la3d_aux.hip        every other kernel of the C-ABI;  la3d_json.cpp  the host-side writer of 3dbbox.json + the build identity
+//   la3d_points.hip     explicit point clouds (la3d_fit_points) and the host-pointer single calls
+//   la3d_masks.hip      whole-frame depth_to_points, mask decode / statistics;  la3d_consumers.hip  box consumers, depth statistics, matcher geometry
+//   la3d_json.cpp       the host-side writer of 3dbbox.json + the build identity
 // This file: the process defaults read once from the environment (config), workspace sizing, argument checks, and which engine
 // fits a call (fit_dispatch; profiles/r06/r06_engines_by_batch.txt has the row in which each engine is the fastest).
 #include <atomic>
@@ -221,7 +223,7 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
   if (!single_pass_call && !sample && p.frame_w == W && split_eligible(p, vec, ldsmask)) {   // (the split engine's decoders know no padded rows)
     const int rc = split_fit(p, workspace, s);   // (the split engine's final kernel does not project: one small follow-up launch)
     if (rc != LA3D_SUCCESS || !p.proj) return rc;
-    return la3d_project_boxes(out, K, k_stride, image_index, B, p.proj_w, p.proj_h, p.proj, stream);   // (la3d_aux.hip)
+    return la3d_project_boxes(out, K, k_stride, image_index, B, p.proj_w, p.proj_h, p.proj, stream);   // (la3d_consumers.hip)
   }
   return instance_fit(p, vec, ldsmask, sample, lds, poly_stage, s, workspace, who);
 }
