@@ -44,7 +44,7 @@ extern "C" {
 #define LA3D_BOX_BAD_GROUND 2 /* ground parallel/antiparallel to [0,-1,0] or zero: NaN rotation (:37-55)   */
 #define LA3D_BOX_TOO_FEW 3    /* one valid point: scikit-learn PCA(2) ValueError (:183-184)              */
 #define LA3D_BOX_NONFINITE 4  /* +-inf coordinate reaches PCA: scikit-learn ValueError (:183-184)        */
-#define LA3D_BOX_UNSUPPORTED 5 /* convex_hull on more than 512 valid points (the reference feeds it <= 500)  */
+#define LA3D_BOX_UNSUPPORTED 5 /* convex_hull on more than 2048 valid points (the reference feeds it <= 500) */
 #define LA3D_BOX_FILTERED 6   /* dropped by the instance filter of the *_filtered entry points (src/util.py:375)        */
 
 /* yaw method (reference src/util_3dbox.py:146-151) */
@@ -317,7 +317,7 @@ int la3d_unproject_matches(const float* depth, int H, int W, const double* uv, i
  * reference src/util_3dbox.py:106-178 (caller :273-278, 500 mesh samples per object).
  * points   dev f64 [total][3];  offsets dev i64 [B+1] (cloud n = rows offsets[n]..offsets[n+1])
  * ground / sample_idx / out / status / aux as above (sample ranks index the cloud's rows).
- * method   LA3D_METHOD_PCA or LA3D_METHOD_CONVEX_HULL (_estimate_yaw_convex_hull, :189-224; at most 512
+ * method   LA3D_METHOD_PCA or LA3D_METHOD_CONVEX_HULL (_estimate_yaw_convex_hull, :189-224; at most 2048
  *          valid rows per cloud after sampling, else that box gets LA3D_BOX_UNSUPPORTED). */
 int la3d_fit_points(const double* points, const int64_t* offsets, const double* ground,
                     const int32_t* sample_idx, int method, int B,

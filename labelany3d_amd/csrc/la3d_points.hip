@@ -33,7 +33,8 @@ struct PtsParams {
   double* aux;
 };
 
-constexpr int HULL_MAX = 512;  // points the convex-hull method holds in LDS (the reference feeds it <= 500, :123)
+constexpr int HULL_MAX = 2048;  // points the convex-hull method holds in LDS (the reference feeds it <= 500, :123; round 6: 512 -> 2048,
+                                // 24 bytes of LDS per point: coordinates, candidate list, survivor flags, chain stacks)
 
 struct alignas(16) SharedP {
   double part[NWAVEP][8];
@@ -52,9 +53,11 @@ struct alignas(16) SharedP {
 // LDS of the convex-hull method (separate struct: only the hull instantiation pays for it)
 struct alignas(16) SharedHull {
   double x[HULL_MAX], z[HULL_MAX];      // valid (x', z') footprint, sorted lexicographically
-  double area[HULL_MAX];                // enclosing-rectangle area per hull edge
-  double yaw[HULL_MAX];
+  unsigned short cand[HULL_MAX];        // current candidates of the chain, in sorted order
+  unsigned short flag[HULL_MAX];        // survivor flags by point
   unsigned short hull[2 * HULL_MAX + 2];
+  double best_area[NTP / 64], best_yaw[NTP / 64];   // per wave: the first strict minimum among its edges ...
+  int best_edge[NTP / 64];                          // ... and that edge's index (ties across waves go to the smaller index)
 };
 
 // One pass of Andrew's monotone chain: visits cnt entries of the candidate list cl starting at position q0 in direction dq, pushes
@@ -90,12 +93,14 @@ __device__ inline int chain_pass(const SharedHull* hs, const unsigned short* cl,
 // vertices: Qhull raises there and the reference falls back to PCA, :222-224).
 __device__ inline bool hull_yaw(SharedHull* hs, SharedP* sh, int tid, double* yaw_out) {
   const int n = sh->nvalid;
-  // pad to a power of two for the bitonic network
-  for (int i = n + tid; i < HULL_MAX; i += NTP) { hs->x[i] = INFINITY; hs->z[i] = INFINITY; }
+  // pad to a power of two for the bitonic network: the smallest one that holds the cloud (512 for the reference's 500 points)
+  int P2 = 64;
+  while (P2 < n) P2 <<= 1;                                             // uniform; n <= HULL_MAX
+  for (int i = n + tid; i < P2; i += NTP) { hs->x[i] = INFINITY; hs->z[i] = INFINITY; }
   __syncthreads();
-  for (int k = 2; k <= HULL_MAX; k <<= 1)
+  for (int k = 2; k <= P2; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < HULL_MAX; i += NTP) {
+      for (int i = tid; i < P2; i += NTP) {
         const int l = i ^ j;
         if (l > i) {
           const double xi = hs->x[i], zi = hs->z[i], xl = hs->x[l], zl = hs->z[l];
@@ -115,20 +120,20 @@ __device__ inline bool hull_yaw(SharedHull* hs, SharedP* sh, int tid, double* ya
   // may be kept by one form and dropped by the other: the hulls then differ by a vertex that moves no edge beyond rounding, and the
   // minimum-area yaw can only move between edges whose areas tie to rounding (the documented don't-care; profiles/r03/stress_hull.py
   // holds both forms to the oracle with a yaw / area tolerance).  The two stack tops live in registers (chain_pass).
-  unsigned short* cl = reinterpret_cast<unsigned short*>(hs->yaw);   // current candidates in sorted order (yaw[] is written after the chain)
+  unsigned short* cl = hs->cand;   // current candidates in sorted order
   for (int i = tid; i < n; i += NTP) cl[i] = (unsigned short)i;
   int m = n;
   for (int level = 0; level < 2; ++level) {
     const int nch = level == 0 ? 16 : 4;
     if (m <= 4 * nch) continue;                                      // uniform
-    for (int i = tid; i < n; i += NTP) hs->area[i] = 0.0;            // survivor flags by point (area[] is written after the chain)
+    for (int i = tid; i < n; i += NTP) hs->flag[i] = 0;              // survivor flags by point
     __syncthreads();
     if (tid < nch) {
       const int lo = (int)((long long)m * tid / nch), hi = (int)((long long)m * (tid + 1) / nch);
       unsigned short* S = hs->hull + lo;                             // this lane's stack: as many slots as its chunk has entries
       for (int pass = 0; pass < 2; ++pass) {                         // lower hull left -> right, then upper hull right -> left
         const int k = chain_pass(hs, cl, pass == 0 ? lo : hi - 1, pass == 0 ? 1 : -1, hi - lo, S, 0, 2);
-        for (int q = 0; q < k; ++q) hs->area[S[q]] = 1.0;
+        for (int q = 0; q < k; ++q) hs->flag[S[q]] = 1;
       }
     }
     __syncthreads();
@@ -137,7 +142,7 @@ __device__ inline bool hull_yaw(SharedHull* hs, SharedP* sh, int tid, double* ya
       for (int i0 = 0; i0 < m; i0 += 64) {
         const int i = i0 + tid;
         const unsigned short id = i < m ? cl[i] : (unsigned short)0;
-        const bool on = i < m && hs->area[id] != 0.0;
+        const bool on = i < m && hs->flag[id] != 0;
         const unsigned long long bal = __ballot(on);
         if (on) cl[base + __popcll(bal & ((1ull << tid) - 1ull))] = id;
         base += __popcll(bal);
@@ -157,8 +162,12 @@ __device__ inline bool hull_yaw(SharedHull* hs, SharedP* sh, int tid, double* ya
   __syncthreads();
   const int h = sh->hull_n;
   if (h < 3) return false;
-  // one hull edge per wave at a time, lanes over the points (min / max are order independent: the areas are those of a serial sweep)
+  // one hull edge per wave at a time, lanes over the points (min / max are order independent: the areas are those of a serial sweep);
+  // every wave keeps the FIRST strict minimum among its edges (e = wave, wave + 8, ... ascending), thread 0 then takes the smallest
+  // area over the waves, ties to the smaller edge index: the first strict minimum of the serial sweep (:216), with no per-edge array
   const int lane = tid & 63, wave = tid >> 6;
+  double wbest = INFINITY, wyaw = 0.0;
+  int wedge = 0x7fffffff;
   for (int e = wave; e < h; e += NTP / 64) {
     const int i0 = hs->hull[e], i1 = hs->hull[(e + 1 == h) ? 0 : e + 1];
     const double yaw = atan2(hs->z[i1] - hs->z[i0], hs->x[i1] - hs->x[i0]);
@@ -170,21 +179,22 @@ __device__ inline bool hull_yaw(SharedHull* hs, SharedP* sh, int tid, double* ya
       xlo = fmin(xlo, rx); xhi = fmax(xhi, rx); zlo = fmin(zlo, rz); zhi = fmax(zhi, rz);
     }
     xlo = wave_min(xlo); xhi = wave_max(xhi); zlo = wave_min(zlo); zhi = wave_max(zhi);
-    if (lane == 0) {
-      // (area[] / yaw[] slots below h: the survivor flags and the survivor list are dead by now - the barrier above)
-      hs->area[e] = (xhi - xlo) * (zhi - zlo);
-      hs->yaw[e] = yaw;
-    }
+    const double area = (xhi - xlo) * (zhi - zlo);
+    if (area < wbest) { wbest = area; wyaw = yaw; wedge = e; }   // (every lane holds the wave's values)
   }
+  if (lane == 0) { hs->best_area[wave] = wbest; hs->best_yaw[wave] = wyaw; hs->best_edge[wave] = wedge; }
   __syncthreads();
   if (tid == 0) {
     double best = INFINITY, by = 0.0;
-    for (int e = 0; e < h; ++e)
-      if (hs->area[e] < best) { best = hs->area[e]; by = hs->yaw[e]; }
-    hs->yaw[0] = by;
+    int be = 0x7fffffff;
+    for (int w = 0; w < NTP / 64; ++w) {
+      const double a = hs->best_area[w];
+      if (a < best || (a == best && hs->best_edge[w] < be)) { best = a; by = hs->best_yaw[w]; be = hs->best_edge[w]; }
+    }
+    hs->best_yaw[0] = by;
   }
   __syncthreads();
-  *yaw_out = hs->yaw[0];
+  *yaw_out = hs->best_yaw[0];
   return true;
 }
 

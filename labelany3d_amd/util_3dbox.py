@@ -29,7 +29,7 @@ _MESSAGES = {
     _lib.BOX_BAD_GROUND: "No valid points after removing NaN values",  # NaN rotation -> every row NaN -> :143
     _lib.BOX_TOO_FEW: "n_components=2 must be between 0 and min(n_samples, n_features)=1 with svd_solver='full'",
     _lib.BOX_NONFINITE: "Input X contains infinity or a value too large for dtype('float64').",
-    _lib.BOX_UNSUPPORTED: "convex_hull on more than 512 valid points is not supported (the reference subsamples to 500)",
+    _lib.BOX_UNSUPPORTED: "convex_hull on more than 2048 valid points is not supported (the reference subsamples to 500)",
 }
 
 
@@ -127,7 +127,7 @@ def _estimate_yaw_pca(rotated_pc):
 
 def _estimate_yaw_convex_hull(rotated_pc):
     """Yaw of the minimum-area enclosing rectangle over hull edges (reference :189-224)."""
-    # PCA fallback (:222-224) happens inside the kernel; no subsampling (clouds above 512 valid points are not supported by
+    # PCA fallback (:222-224) happens inside the kernel; no subsampling (clouds above 2048 valid points are not supported by
     # the hull kernel - the reference only ever feeds this helper the <= 500 points estimate_bbox kept)
     _, aux = _fit_one(rotated_pc, None, "convex_hull", subsample=False)
     return np.float64(aux[0])

@@ -117,7 +117,7 @@ def test_estimate_bbox_host_equals_the_device_pointer_path():
     clouds.append(clouds[0]); grounds.append(np.array([np.nan, 0, 0, 0]))                                          # NaN first entry = None
     for method, name in ((_lib.METHOD_PCA, "pca"), (_lib.METHOD_CONVEX_HULL, "convex_hull")):
         for c, g in zip(clouds, grounds):
-            if method == _lib.METHOD_CONVEX_HULL and len(c) > 512:
+            if method == _lib.METHOD_CONVEX_HULL and len(c) > 2048:
                 continue
             rec, aux, st = _host_fit(c, g, method)
             gg = None if g is None else g[None]

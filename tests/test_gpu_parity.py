@@ -485,9 +485,15 @@ def test_convex_hull_method(la):
     v, c, d, R, _ = _run_estimate(U, big, None, "convex_hull")
     ref = O.pack39(*O.estimate_bbox(big, None, None, "convex_hull", rand_ind=idx))
     assert_records(O.pack39(v, c, d, R)[None], ref[None], "hull-sampled")
-    # batched ABI without sampling: more than 512 valid points is reported per box, not as a failed call
-    _, st, _ = la.fit_points([big, clouds[0]], None, None, "convex_hull")
-    assert np_(st).tolist() == [5, 0]
+    # batched ABI without sampling: the hull kernel holds up to 2048 valid points (round 6; 512 before) - a cloud of 1500 is fitted
+    # and equals the oracle's hull walk over ALL its points; beyond 2048 the box is reported as unsupported, not as a failed call
+    mid = rs.rand(1500, 3) * [2, 1, 1.3] + [0, 0, 4]
+    b, st, a = la.fit_points([big, clouds[0], mid], None, None, "convex_hull")
+    assert np_(st).tolist() == [5, 0, 0]
+    ref = O.pack39(*O.estimate_bbox(mid, None, None, "convex_hull", rand_ind=False))
+    assert_records(np_(b)[2:3], ref[None], "hull-1500")
+    assert float(np_(a)[2, 0]) == pytest.approx(O.yaw_convex_hull(mid), abs=1e-9)
+    assert U._estimate_yaw_convex_hull(mid) == pytest.approx(O.yaw_convex_hull(mid), abs=1e-9)     # the direct helper on 1500 points
 
 
 def test_convex_hull_rectangular_footprint_ties(la):
