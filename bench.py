@@ -193,11 +193,13 @@ def traffic_mode_key(args, B):
 
 
 def kernel_source_sha256():
-    """Hash of the kernel sources: stamps the PMC traffic figure so that a stale constant is detectable."""
+    """Hash of the sources the FIT kernels are compiled from (engines, walks, stages, shared device code, dispatcher): stamps the PMC
+    traffic / VALU figures so that a stale constant is detectable.  The other kernels of the library (point clouds, mask decode /
+    statistics, consumers) are not part of any bench step and do not enter."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("la3d.hip", "la3d_instance.hip", "la3d_band.hip", "la3d_rows.hip", "la3d_walks.hpp", "la3d_stages.hpp", "la3d_engines.hpp",
-              "la3d_device.hpp", "la3d_poly.hpp", "la3d_split.hip", "la3d_points.hip", "la3d_masks.hip", "la3d_consumers.hip"):
+    for f in ("la3d.hip", "la3d_instance.hip", "la3d_band.hip", "la3d_rows.hip", "la3d_split.hip", "la3d_walks.hpp", "la3d_stages.hpp",
+              "la3d_engines.hpp", "la3d_device.hpp", "la3d_poly.hpp"):
         h.update(open(os.path.join(ROOT, "labelany3d_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 
