@@ -54,6 +54,9 @@ extern "C" {
  * sampling) - true for the reference's own calls (500 mesh samples per object).  PCA method: one WAVE per cloud instead of one
  * workgroup - no LDS, no barriers, four clouds per workgroup.  Larger clouds stay correct, only slow. */
 #define LA3D_HINT_SMALL_CLOUDS 0x100
+#define LA3D_HINT_HULL_512 0x200     /* OR into `method` (convex hull): no cloud holds more than 512 valid rows - the reference's own call path
+                                        (<= 500 mesh samples) - so the kernel takes its small-LDS form (eight workgroups per CU instead of
+                                        three); implied by a sample_idx array.  A cloud that breaks the promise gets LA3D_BOX_UNSUPPORTED. */
 
 int la3d_version(void);
 /* "LA3D_BUILD_INFO:<sha256 of the sources this library was compiled from>:<sha256 of the compile command>" - static storage. */

@@ -11,6 +11,7 @@ REC, AUX, NSAMPLE = 39, 4, 500
 BOX_OK, BOX_EMPTY, BOX_BAD_GROUND, BOX_TOO_FEW, BOX_NONFINITE, BOX_UNSUPPORTED, BOX_FILTERED = 0, 1, 2, 3, 4, 5, 6
 METHOD_PCA, METHOD_CONVEX_HULL = 0, 1
 HINT_SMALL_CLOUDS = 0x100
+HINT_HULL_512 = 0x200
 ERR_UNSUPPORTED = -2
 
 class FitArgs(C.Structure):

@@ -334,15 +334,20 @@ def fit_instances(depth, masks, K, ground=None, sample_idx=None, image_index=Non
         return out
 
 
-def fit_points(clouds, ground=None, sample_idx=None, method: str = "pca", stream=None, device=None, small_clouds=None, _packed=False):
+def fit_points(clouds, ground=None, sample_idx=None, method: str = "pca", stream=None, device=None, small_clouds=None, _packed=False,
+               hull_512=None):
     """estimate_bbox for a list of (N_i,3) clouds in one launch (reference src/util_3dbox.py:106-178).
 
     clouds: list of arrays/tensors, or a tuple (points (T,3) f64, offsets (B+1,) i64).
     small_clouds: True promises that no cloud has more than a few thousand rows to visit (LA3D_HINT_SMALL_CLOUDS: one wave per
     cloud); None = decided here when the cloud sizes are known on the host (a list of clouds, or sample_idx given).
+    hull_512 (method="convex_hull"): True promises that no cloud holds more than 512 valid rows (LA3D_HINT_HULL_512: the kernel's
+    small-LDS form, what the reference's 500-point clouds want); None = decided here from the cloud sizes when they are known on the
+    host.  A cloud that breaks the promise comes back with status 5; without the promise the kernel holds 2048 rows per cloud.
     Returns (boxes (B,39), status (B,), aux (B,4)) on the GPU.
     """
     dev = _dev(device)
+    hull512 = bool(hull_512)
     if isinstance(clouds, tuple):
         pts = _as_dev(clouds[0], torch.float64, dev)
         off = _as_dev(clouds[1], torch.int64, dev)
@@ -350,6 +355,8 @@ def fit_points(clouds, ground=None, sample_idx=None, method: str = "pca", stream
             small_clouds = sample_idx is not None
     else:
         lens = [int(len(c)) for c in clouds]
+        if hull_512 is None:
+            hull512 = max(lens, default=0) <= 512      # (convex hull: the small-LDS form of the kernel, LA3D_HINT_HULL_512)
         if small_clouds is None:
             small_clouds = sample_idx is not None or max(lens, default=0) <= 4096
         offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
@@ -376,7 +383,7 @@ def fit_points(clouds, ground=None, sample_idx=None, method: str = "pca", stream
     aux = packed[B * REC:B * (REC + AUX)].view(B, AUX)
     status = packed[B * (REC + AUX):].view(torch.int32)[:B]
     with torch.cuda.device(dev):
-        check(lib.la3d_fit_points(_ptr(pts), _ptr(off), _ptr(g), _ptr(si), meth | (_lib.HINT_SMALL_CLOUDS if small_clouds else 0), B, _ptr(boxes), _ptr(status),
+        check(lib.la3d_fit_points(_ptr(pts), _ptr(off), _ptr(g), _ptr(si), meth | (_lib.HINT_SMALL_CLOUDS if small_clouds else 0) | (_lib.HINT_HULL_512 if hull512 else 0), B, _ptr(boxes), _ptr(status),
                                   _ptr(aux), _stream(stream)), "la3d_fit_points")
     _record(stream, pts, off, g, si, packed)
     if _packed:

@@ -35,6 +35,9 @@ struct PtsParams {
 
 constexpr int HULL_MAX = 2048;  // points the convex-hull method holds in LDS (the reference feeds it <= 500, :123; round 6: 512 -> 2048,
                                 // 24 bytes of LDS per point: coordinates, candidate list, survivor flags, chain stacks)
+constexpr int HULL_SMALL = 512; // ... and the form for calls that promise at most 512 valid rows per cloud (LA3D_HINT_HULL_512, a sample_idx
+                                // array, the scalar drop-in's <= 500 points): 12 KB of LDS instead of 48 - eight workgroups per CU instead
+                                // of three (the chain is one lane's serial work: 7.4 M vs 5.7 M clouds/s on 500-point batches)
 
 struct alignas(16) SharedP {
   double part[NWAVEP][8];
@@ -51,11 +54,12 @@ struct alignas(16) SharedP {
 };
 
 // LDS of the convex-hull method (separate struct: only the hull instantiation pays for it)
-struct alignas(16) SharedHull {
-  double x[HULL_MAX], z[HULL_MAX];      // valid (x', z') footprint, sorted lexicographically
-  unsigned short cand[HULL_MAX];        // current candidates of the chain, in sorted order
-  unsigned short flag[HULL_MAX];        // survivor flags by point
-  unsigned short hull[2 * HULL_MAX + 2];
+template <int HCAP>
+struct alignas(16) SharedHullT {
+  double x[HCAP], z[HCAP];              // valid (x', z') footprint, sorted lexicographically
+  unsigned short cand[HCAP];            // current candidates of the chain, in sorted order
+  unsigned short flag[HCAP];            // survivor flags by point
+  unsigned short hull[2 * HCAP + 2];
   double best_area[NTP / 64], best_yaw[NTP / 64];   // per wave: the first strict minimum among its edges ...
   int best_edge[NTP / 64];                          // ... and that edge's index (ties across waves go to the smaller index)
 };
@@ -64,6 +68,7 @@ struct alignas(16) SharedHull {
 // point indices on the stack S (k0 entries on entry; a pop needs at least t), returns the stack size.  The coordinates of the two
 // stack tops are carried in registers, so a step that pops nothing waits for no dependent LDS read.  The turn test is the textbook
 // cross(o, a, b) = (xa - xo)(zb - zo) - (za - zo)(xb - xo) <= 0 -> pop.
+template <typename SharedHull>
 __device__ inline int chain_pass(const SharedHull* hs, const unsigned short* cl, int q0, int dq, int cnt, unsigned short* S, int k0, int t) {
   int k = k0;
   double ox = 0, oz = 0, ax = 0, az = 0;
@@ -91,6 +96,7 @@ __device__ inline int chain_pass(const SharedHull* hs, const unsigned short* cl,
 // [[cos,-sin],[sin,cos]] (:204-208); area of the axis-aligned extent; the FIRST strict minimum wins
 // (:216) in counter-clockwise vertex order.  Returns false when there is no 2-D hull (fewer than 3
 // vertices: Qhull raises there and the reference falls back to PCA, :222-224).
+template <typename SharedHull>
 __device__ inline bool hull_yaw(SharedHull* hs, SharedP* sh, int tid, double* yaw_out) {
   const int n = sh->nvalid;
   // pad to a power of two for the bitonic network: the smallest one that holds the cloud (512 for the reference's 500 points)
@@ -198,13 +204,13 @@ __device__ inline bool hull_yaw(SharedHull* hs, SharedP* sh, int tid, double* ya
   return true;
 }
 
-template <bool HULL> struct HullStore {};
-template <> struct HullStore<true> { SharedHull h; };
+template <bool HULL, int HCAP> struct HullStore {};
+template <int HCAP> struct HullStore<true, HCAP> { SharedHullT<HCAP> h; };
 
-template <bool HULL>
+template <bool HULL, int HCAP = HULL_SMALL>
 __global__ __launch_bounds__(NTP) void fit_points_kernel(const PtsParams p) {
   __shared__ SharedP sh;
-  __shared__ HullStore<HULL> hstore;
+  __shared__ HullStore<HULL, HCAP> hstore;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: lives in an SGPR
   const int c = blockIdx.x;
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(NTP) void fit_points_kernel(const PtsParams p) {
       n += 1;
       if constexpr (HULL) {  // footprint for the hull method (order is irrelevant: it is sorted next)
         const int slot = atomicAdd(&sh.fill, 1);
-        if (slot < HULL_MAX) { hstore.h.x[slot] = x; hstore.h.z[slot] = z; }
+        if (slot < HCAP) { hstore.h.x[slot] = x; hstore.h.z[slot] = z; }
       }
     }
   }
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(NTP) void fit_points_kernel(const PtsParams p) {
     else if (nn == 1) st = LA3D_BOX_TOO_FEW;
     double cy = NAN, sy = NAN, gap = NAN;
     if (st == LA3D_BOX_OK) axis_from_sums((double)nn, s[0], s[1], s[2], s[3], s[4], &cy, &sy, &gap);
-    if (HULL && st == LA3D_BOX_OK && nn > HULL_MAX) st = LA3D_BOX_UNSUPPORTED;
+    if (HULL && st == LA3D_BOX_OK && nn > HCAP) st = LA3D_BOX_UNSUPPORTED;
     sh.cyaw = cy; sh.syaw = sy; sh.st = st; sh.nvalid = nn;
     if (p.aux) {
       double* a = p.aux + (long long)c * LA3D_AUX;
@@ -469,7 +475,8 @@ int la3d_fit_points(const double* points, const int64_t* offsets, const double* 
     return LA3D_ERR_ARG;
   }
   const bool small = (method & LA3D_HINT_SMALL_CLOUDS) != 0;
-  method &= ~LA3D_HINT_SMALL_CLOUDS;
+  const bool hull512 = (method & LA3D_HINT_HULL_512) != 0 || sample_idx != nullptr;   // (sampled clouds hold 500 rows)
+  method &= ~(LA3D_HINT_SMALL_CLOUDS | LA3D_HINT_HULL_512);
   if (method != LA3D_METHOD_PCA && method != LA3D_METHOD_CONVEX_HULL) {
     set_err("la3d_fit_points: unknown method");
     return LA3D_ERR_ARG;
@@ -478,8 +485,10 @@ int la3d_fit_points(const double* points, const int64_t* offsets, const double* 
   PtsParams p;
   p.points = points; p.offsets = reinterpret_cast<const long long*>(offsets); p.ground = ground;
   p.sample_idx = sample_idx; p.B = B; p.method = method; p.out = out; p.status = status; p.aux = aux;
-  if (method == LA3D_METHOD_CONVEX_HULL)
-    hipLaunchKernelGGL(fit_points_kernel<true>, dim3(B), dim3(NTP), 0, static_cast<hipStream_t>(stream), p);
+  if (method == LA3D_METHOD_CONVEX_HULL && hull512)
+    hipLaunchKernelGGL((fit_points_kernel<true, HULL_SMALL>), dim3(B), dim3(NTP), 0, static_cast<hipStream_t>(stream), p);
+  else if (method == LA3D_METHOD_CONVEX_HULL)
+    hipLaunchKernelGGL((fit_points_kernel<true, HULL_MAX>), dim3(B), dim3(NTP), 0, static_cast<hipStream_t>(stream), p);
   else if (small)
     hipLaunchKernelGGL(fit_points_wave_kernel, dim3((B + NTP / 64 - 1) / (NTP / 64)), dim3(NTP), 0, static_cast<hipStream_t>(stream), p);
   else
@@ -605,7 +614,8 @@ int la3d_estimate_bbox_host(const double* points, int64_t n, const double* groun
     p.ground = has_ground ? reinterpret_cast<const double*>(c->pin_dev + 32) : nullptr; p.sample_idx = nullptr; p.B = 1; p.method = method;
     p.out = reinterpret_cast<double*>(c->pin_dev + 64); p.status = reinterpret_cast<int*>(c->pin_dev + 408);
     p.aux = reinterpret_cast<double*>(c->pin_dev + 376);
-    hipLaunchKernelGGL(fit_points_kernel<true>, dim3(1), dim3(NTP), 0, c->stream, p);
+    if (n <= HULL_SMALL) hipLaunchKernelGGL((fit_points_kernel<true, HULL_SMALL>), dim3(1), dim3(NTP), 0, c->stream, p);
+    else hipLaunchKernelGGL((fit_points_kernel<true, HULL_MAX>), dim3(1), dim3(NTP), 0, c->stream, p);
     const int lrc = check_launch("fit_points_kernel");
     if (lrc != LA3D_SUCCESS) return lrc;
     if (hipStreamSynchronize(c->stream) != hipSuccess) return check_launch("la3d_estimate_bbox_host");

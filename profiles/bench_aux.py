@@ -52,7 +52,7 @@ def main():
     pts = torch.as_tensor(rs.randn(B * 500, 3) * [1.0, 0.3, 0.5] + [0, 0, 5.0], device="cuda")
     off = torch.arange(0, B * 500 + 1, 500, device="cuda", dtype=torch.int64)
     for method in ("pca", "convex_hull"):
-        t = timed(lambda: la.fit_points((pts, off), None, None, method), n=20)
+        t = timed(lambda: la.fit_points((pts, off), None, None, method, hull_512=True), n=20)    # (500-row clouds: LA3D_HINT_HULL_512)
         out[f"fit_points_500pt_{method}"] = dict(s=t, boxes_per_s=B / t, bytes=B * 500 * 24 * 2, GBps=B * 500 * 48 / t / 1e9)
         if method == "pca":
             t = timed(lambda: la.fit_points((pts, off), None, None, method, small_clouds=True), n=20)
