@@ -43,11 +43,11 @@ const Config& config() {
              : (e && !strcmp(e, "band")) ? LA3D_ENGINE_BAND : (e && !strcmp(e, "rows")) ? LA3D_ENGINE_ROWS
              : (e && !strcmp(e, "rows2")) ? LA3D_ENGINE_ROWS2 : LA3D_ENGINE_DEFAULT;
     e = getenv("LA3D_BANDS");
-    k.bands = (e && (atoi(e) == 4 || atoi(e) == 2)) ? atoi(e) : 0;
+    k.bands = (e && (atoi(e) == 8 || atoi(e) == 4 || atoi(e) == 2)) ? atoi(e) : 0;
     e = getenv("LA3D_BAND_DEFAULT");      // 0: the band engine only when asked for (LA3D_ENGINE=band / opt_engine)
     k.band_default = !(e && e[0] == '0');
     e = getenv("LA3D_BAND_MAXB");
-    k.band_maxb = (e && atoi(e) > 0) ? atoi(e) : 256;
+    k.band_maxb = (e && atoi(e) > 0) ? atoi(e) : 160;
     e = getenv("LA3D_ROWS_MAXB");
     k.rows_maxb = e ? atoi(e) : 160;   // largest batch the row engine takes by default (0: never); above, one workgroup per instance is as fast
                                        // (round 6, us per call, instance | rows: B = 128: 37.1 | 30.3; 192: 39.8 | 41.1 - profiles/r06/r06_rows_engine.txt)

@@ -455,8 +455,9 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_bands_kernel(const FitParams 
 
 
 // ---- band engine (fit_bands_kernel) ----
-constexpr int BAND_NB_MAX = 4;
-constexpr int BAND_MINB = 16;   // smallest batch the band engine takes by default (48 while a memset preceded the launch)
+constexpr int BAND_NB_MAX = 8;
+constexpr int BAND_MINB = 1;    // smallest batch the band engine takes by default (round 6: with eight bands per instance it leads from one
+                                // instance on - 23 vs 32 us through the split engine; rounds 4-5: 16)
 constexpr size_t band_xch_doubles(int nb) { return (size_t)nb * (2 * BAND_XD + 6); }
 
 // workspace of the band engine: [B] u32 sort keys | [B][4] u64 tagged arrival words | [B][NB_MAX * 22] f64 exchange records
@@ -471,21 +472,24 @@ inline bool band_frame_ok_impl(int H, int W, int nb) {
   return (long long)ntx * tmax <= 256 * NWAVE;          // one-pass tile list: <= 256 tiles per wave
 }
 
-// Bands per instance: LA3D_BANDS pins 2 or 4; otherwise four up to 288 instances, two beyond (measured, us per call, u8 planes,
-// split | instance | two bands | four bands - profiles/r04/r04_band.txt: B = 4: 34 | 37 | 44 | 31; 64: 43 | 56 | 51 | 38;
-// 256: 67 | 67 | 64 | 63; 320: 80 | 76 | 68 | 69; 384: - | 75 | 73 | 77; 512: - | 80 | 85 | 95; 1024: - | 107 | 134 | 168).
+// Bands per instance: LA3D_BANDS pins 2, 4 or 8; otherwise eight up to 128 instances (round 6), four up to 288, two beyond.  Measured, us
+// per call, u8 planes - round 4 (profiles/r04/r04_band.txt; split | instance | two bands | four bands): B = 4: 34 | 37 | 44 | 31;
+// 64: 43 | 56 | 51 | 38; 256: 67 | 67 | 64 | 63; 320: 80 | 76 | 68 | 69; 384: - | 75 | 73 | 77; 512: - | 80 | 85 | 95; 1024: - | 107 | 134 | 168;
+// round 6, grounded calls after the exchange rewrite (profiles/r06/r06_engines_by_batch.txt; four | eight | sixteen bands):
+// B = 1: 33.3 | 23.2 | 30.0; 4: - | 28.3 | 35.0; 16: 33.7 | 27.6 | 36.3; 32: - | 31.8 | 38.8; 64: 35.2 | 34.3 | 58.4; 128: 45.3 | 45.1 | -;
+// 192: 57.2 | 64.8 | -.
 inline int band_count(const FitParams& p) {
-  int nb = config().bands ? config().bands : (p.B <= 288 ? 4 : 2);
+  int nb = config().bands ? config().bands : (p.B <= 128 ? 8 : p.B <= 288 ? 4 : 2);
+  if (nb == 8 && !band_frame_ok_impl(p.H, p.W, 8)) nb = 4;
   if (nb == 4 && !band_frame_ok_impl(p.H, p.W, 4)) nb = 2;
   return nb;
 }
 
-// u8 planes, 16-byte aligned, full-mask mode.  By default the band engine takes 16 <= B <= 256: below, it ties with the split
-// engine (32-34 us per call either way) and the split engine stays (us per call, split | four bands, once the band launch lost its
-// memset: B = 1: 32.2 | 32.3; 4: 32.9 | 33.3; 16: 34.9 | 33.9; 32: 36.0 | 34.0; 48: 39.5 | 35.9; 64: 42.1 | 36.6); above, the instance engine - since the
-// end of round 4 with the staggered start and without a helper launch - is as fast or faster (us per call, instance | two bands | four
-// bands: B = 256: 59.7 | 58.6 | 60.0; 288: 61.4 | 62.9 | 66.2; 320: 64.5 | 62.4 | 69.9; 384: 63.4 | 66.2 | 78.1; 448: 63.4 | 70.6 |
-// 83.3; until then the bands held up to 400).  LA3D_ENGINE=band / opt_engine pins it for any batch, LA3D_BAND_MAXB moves the limit.
+// u8 planes, 16-byte aligned, full-mask mode.  By default the band engine takes the GROUNDED calls of 1 <= B <= 160 instances (round
+// 6: eight bands per instance put it ahead of the split engine from one instance on - B = 1 / 16 / 64: 23 / 28 / 34 us vs 32 / 36 / 43 -,
+// and above ~160 one workgroup per instance is as fast or faster: B = 192: 57 vs 54 us).  History - round 4, us per call, split | four
+// bands once the band launch lost its memset: B = 1: 32.2 | 32.3; 16: 34.9 | 33.9; 64: 42.1 | 36.6; instance | two | four bands:
+// B = 256: 59.7 | 58.6 | 60.0; 384: 63.4 | 66.2 | 78.1.  LA3D_ENGINE=band / opt_engine pins it for any batch, LA3D_BAND_MAXB moves the limit.
 inline bool band_eligible_impl(const FitParams& p, bool vec, bool sample) {
   const int e = p.opt_engine != LA3D_ENGINE_DEFAULT ? p.opt_engine : config().engine;
   if (e == LA3D_ENGINE_INSTANCE || e == LA3D_ENGINE_SPLIT) return false;
@@ -560,6 +564,7 @@ bool band_eligible(const FitParams& p, bool vec, bool sample) { return ::band_el
 bool band_frame_ok(int H, int W, int nb) { return ::band_frame_ok_impl(H, W, nb); }
 size_t band_workspace_bytes(int B) { return ::band_workspace_bytes_impl(B); }
 int band_fit(const FitParams& p, hipStream_t s, void* workspace) {
-  return band_count(p) == 4 ? launch_fit_bands<4>(p, s, workspace) : launch_fit_bands<2>(p, s, workspace);
+  const int nb = band_count(p);
+  return nb == 8 ? launch_fit_bands<8>(p, s, workspace) : nb == 4 ? launch_fit_bands<4>(p, s, workspace) : launch_fit_bands<2>(p, s, workspace);
 }
 }  // namespace la3d

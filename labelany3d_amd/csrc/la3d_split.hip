@@ -190,7 +190,7 @@ __global__ __launch_bounds__(SNT) void scan_kernel(const SplitParams sp) {
 // ------------------------------------------------------------------------------------------
 constexpr int DNT = 512;
 #ifndef LA3D_SPLIT_MAXB_NOMASK
-#define LA3D_SPLIT_MAXB_NOMASK 288   // measured crossover with the instance engine (see split_eligible)
+#define LA3D_SPLIT_MAXB_NOMASK 160   // measured crossover with the instance engine (see split_eligible; round 6: grounded run lengths, split | instance: B = 128: 48 | 53, 192: 52.6 | 51.2, 256: 58 | 51)
 #endif
 constexpr int DEC_SCRATCH_BYTES = POLY_STAGE_BYTES > 8192 ? POLY_STAGE_BYTES : 8192;
 template <int SRC>
@@ -638,7 +638,9 @@ bool split_eligible(const FitParams& p, bool vec, bool ldsmask) {
     return p.B <= LA3D_SPLIT_MAXB_NOMASK;
   }
   if (e == LA3D_ENGINE_SPLIT) return true;
-  return p.B <= 272;
+  // round 6: u8 planes up to 160 instances only (where the band engine does not apply: it is the faster one there); above, one
+  // workgroup per instance leads - grounded u8, split | instance: B = 192: 56.8 | 54.2, 256: 66.7 | 56.9 (profiles/r06/r06_engines_by_batch.txt)
+  return p.B <= 160;
 }
 
 // One call = one batch.  Sub-batch j: scan on the scan stream (scans are bandwidth-bound, so they run
