@@ -97,7 +97,7 @@ int la3d_pad_rows(const float* src, int64_t rows, int W, int Wp, float* dst, voi
 #define LA3D_ENGINE_DEFAULT 0
 #define LA3D_ENGINE_INSTANCE 1        /* one workgroup per instance */
 #define LA3D_ENGINE_SPLIT 2           /* band scan + tile-range-balanced passes (falls back to the instance engine where it does not apply) */
-#define LA3D_ENGINE_BAND 3            /* two (or four) workgroups per instance, one per band of tile rows (u8 planes, tiled frames; falls back likewise) */
+#define LA3D_ENGINE_BAND 3            /* two, four or eight workgroups per instance, one per band of tile rows (u8 planes, tiled frames; falls back likewise) */
 #define LA3D_ENGINE_ROWS 4            /* up to sixteen workgroups per instance, one per band of rows (u8 planes, no ground array, at most 512
                                          instances; falls back likewise).  Round 6: ONE launch - the band that finishes last merges its
                                          instance's partial sums and writes the record */

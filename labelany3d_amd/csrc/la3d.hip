@@ -10,8 +10,8 @@
 // former 3 000-line file by engine, one translation unit each (compiled side by side):
 //   la3d_instance.hip   one workgroup per instance: every call the others do not take (fit_instances_kernel)
 //   la3d_rows.hip       up to sixteen workgroups per instance, one per band of rows: un-grounded u8 batches up to 160 instances
-//   la3d_band.hip       two / four workgroups per instance that meet through the workspace: grounded u8 batches of 16..256
-//   la3d_split.hip      scan -> plan -> walk -> axis -> walk -> final over tile ranges: grounded small batches of every mask format
+//   la3d_band.hip       two / four / eight workgroups per instance that meet through the workspace: grounded u8 batches of 1..160
+//   la3d_split.hip      scan -> plan -> walk -> axis -> walk -> final over tile ranges: grounded run-length / polygon batches up to 160
 //   la3d_walks.hpp      the walks over an instance's pixels (generic, tiled two-pass, separable single pass)
 //   la3d_stages.hpp     moments -> axis, extents -> record, the in-kernel launch order, the culling plan, workgroup hand-off primitives
 //   la3d_points.hip     explicit point clouds (la3d_fit_points) and the host-pointer single calls
@@ -219,7 +219,7 @@ static int fit_dispatch(const float* depth, int64_t depth_plane_stride, const in
     int rc = LA3D_SUCCESS;
     if (rows_fit_if_eligible(p, vec, sample, s, workspace, &rc)) return rc;
   }
-  if (!single_pass_call && band_eligible(p, vec, sample)) return band_fit(p, s, workspace);   // u8 planes, 16 <= B <= 256 (or pinned): two / four workgroups per instance, ONE launch
+  if (!single_pass_call && band_eligible(p, vec, sample)) return band_fit(p, s, workspace);   // grounded u8 planes, 1 <= B <= 160 (or pinned): two / four / eight workgroups per instance, ONE launch
   if (!single_pass_call && !sample && p.frame_w == W && split_eligible(p, vec, ldsmask)) {   // (the split engine's decoders know no padded rows)
     const int rc = split_fit(p, workspace, s);   // (the split engine's final kernel does not project: one small follow-up launch)
     if (rc != LA3D_SUCCESS || !p.proj) return rc;

@@ -1,5 +1,5 @@
 // la3d_band.hip - the BAND ENGINE of la3d_fit_instances (round 4): fit_bands_kernel<2|4> and its launcher.  Since round 5 it takes
-// only GROUNDED u8 batches of 16..256 instances by default (profiles/r06/r06_engines_by_batch.txt: fastest at B = 64 / 128).
+// only GROUNDED u8 batches by default - 1..160 instances since round 6, eight bands per instance up to 128 (profiles/r06/r06_engines_by_batch.txt).
 #include <atomic>
 #include <chrono>
 #include <cstdint>

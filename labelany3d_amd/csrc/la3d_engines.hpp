@@ -7,7 +7,7 @@ namespace la3d {
 // Shared, `poly_stage` = the polygon side stage; picks the instantiation of fit_instances_kernel for the frame and launches it.
 int instance_fit(FitParams p, bool vec, bool ldsmask, bool sample, size_t lds, size_t poly_stage, hipStream_t s, void* workspace,
                  const char* who);
-// band engine (la3d_band.hip): two / four workgroups per instance that meet through the workspace (grounded u8 batches of 16..256)
+// band engine (la3d_band.hip): two / four / eight workgroups per instance that meet through the workspace (grounded u8 batches of 1..160)
 bool band_eligible(const FitParams& p, bool vec, bool sample);
 bool band_frame_ok(int H, int W, int nb);
 size_t band_workspace_bytes(int B);
