@@ -120,9 +120,14 @@ __device__ inline void band_moments_to_axis(Shared* sh, const FitParams& p, int 
       else if (nt == 0) st = LA3D_BOX_EMPTY;
       else if (nt == 1) st = LA3D_BOX_TOO_FEW;
       const double chk = (t[0] + t[1]) + (t[2] + t[3]) + t[4];
-      sh->redo = (allow_redo && !timeout && !sh->bad_ground && !(fabs(chk) <= 1.79769313486231570815e308)) ? 1 : 0;
+      const bool nonfinite = !(fabs(chk) <= 1.79769313486231570815e308);
       double cy = NAN, sy = NAN;
-      if (st == LA3D_BOX_OK) axis_from_sums((double)nt, t[0], t[1], t[2], t[3], t[4], &cy, &sy, &gap);
+      bool ill = false;
+      if (st == LA3D_BOX_OK) ill = axis_from_sums((double)nt, t[0], t[1], t[2], t[3], t[4], &cy, &sy, &gap);
+      // (the summed moments are the same in every band: all of them take the same decision and the same pivot - stage_moments_to_axis)
+      sh->redo = (allow_redo && !timeout && !sh->bad_ground) ? (nonfinite ? 1 : (ill ? 2 : 0)) : 0;
+      set_pivot(sh, (ill && !nonfinite) ? t[0] / (double)nt : 0.0, (ill && !nonfinite) ? t[1] / (double)nt : 0.0);
+      if (ill && !allow_redo) gap = 0.0;
       sh->cyaw = cy; sh->syaw = sy;
       sh->qhead = 0u;
       sh->st = st;
@@ -359,13 +364,17 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_bands_kernel(const FitParams 
     return;
   }
   if (sh->redo) {   // uniform, and the same in every band of the instance: the summed moments decide
-    __syncthreads();
+    __syncthreads();   // (the pivot - zero unless the summed moments were ill-conditioned: axis_from_sums - stays in LDS)
 #pragma unroll
     for (int i = 0; i < 5; ++i) acc[i] = 0;
     cnt = 0;
-    checked = true;
-    if (cull) sweep_tiled<0, true, true>(pb, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, nullptr, compact, rng_words);
-    else sweep_tiled<0, true>(pb, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, nullptr, compact, rng_words);
+    if (sh->redo == 2) {   // ill-conditioned sums: the moments about the pivot; the optimistic pass's tile ranges and pass B stand
+      pivot_pass(pb, dpl, bits, list, nactive, Mg, Mg + 6, wave, lane, compact, pivot_ptr(sh), acc, &cnt);
+    } else {
+      checked = true;
+      if (cull) sweep_tiled<0, true, true>(pb, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, nullptr, compact, rng_words);
+      else sweep_tiled<0, true>(pb, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, nullptr, compact, rng_words);
+    }
     band_moments_to_axis<NB>(sh, p, inst_p, h, 1, acc, cnt, nmask, tid, wave, lane, false);
     if (sh->st >= BAND_ST_TAKEOVER) {   // uniform
       if (sh->st == BAND_ST_TAKEOVER) band_takeover(sh, p, inst_p, tid, wave, lane);

@@ -192,7 +192,18 @@ __device__ inline int ground_rotation(const double* ground, double* Rg) {
 // (cos yaw, sin yaw), obtained without trigonometry from cos 2t = (a-c)/2r, sin 2t = b/r by the
 // stable half-angle form (agrees with the trig route to ~1 ulp; keeps fp64 libm range reduction out
 // of the streaming kernel's register budget and off the per-workgroup serial path).
-__device__ inline void axis_from_sums(double n, double sx, double sz, double sxx, double sxz, double szz,
+//
+// Returns true when the sums are ILL-CONDITIONED for this (round 6, found by profiles/r06/fuzz_engines.py): the covariance entries
+// a, b, c are differences of raw second moments and carry an absolute rounding error of a few 2^-52 (sxx + szz), so their relative
+// error is ~2^-50 kappa with kappa = (sxx + szz) / l1 = (mean square distance from the ORIGIN of the sums) / (variance along the
+// axis).  The reference centres the points before its SVD / eigh and has no such term.  kappa > 2^17 (a cloud whose spread in the
+// x'z' plane is below ~1/360 of its distance: a one-pixel column at constant depth, a sliver 0.5 mm wide 48 m away) would put the
+// axis error above ~1e-10 / gap: the caller then re-runs the moments about a pivot next to the cloud (the mean of the first pass;
+// the sums handed over afterwards are translated and this function is translation invariant), or - where a path has no second
+// pass, and for clouds that stay unresolved about their own mean (no spread at all: the reference's axis is rounding noise too) -
+// reports gap = 0, the documented "don't care" value.
+constexpr double ILL_KAPPA = 131072.0;   // 2^17
+__device__ inline bool axis_from_sums(double n, double sx, double sz, double sxx, double sxz, double szz,
                                       double* cyaw, double* syaw, double* gap) {
   const double a = sxx - sx * sx / n;
   const double c = szz - sz * sz / n;
@@ -201,10 +212,11 @@ __device__ inline void axis_from_sums(double n, double sx, double sz, double sxx
   const double rad = sqrt(half * half + b * b);
   const double l1 = 0.5 * (a + c) + rad;
   *gap = (l1 > 0) ? 2.0 * rad / l1 : 0.0;
+  const bool ill = !((sxx + szz) <= ILL_KAPPA * l1);   // (also true for NaN sums and for l1 <= 0 < sxx + szz)
   if (b == 0 && a == c) {  // exact isotropy: eigh branch (n >= 20) -> yaw = pi/2; SVD branch recorded as 0
     if (n >= 20) { *cyaw = 6.123233995736766e-17; *syaw = 1.0; }  // np.cos(pi/2), np.sin(pi/2)
     else { *cyaw = 1.0; *syaw = 0.0; }
-    return;
+    return ill;
   }
   const double c2 = half / rad, s2 = b / rad;
   double vx, vz;  // (cos t, sin t), t in [-pi/2, pi/2]
@@ -216,6 +228,7 @@ __device__ inline void axis_from_sums(double n, double sx, double sz, double sxx
     vx = -vx; vz = -vz;
   }
   *cyaw = vx; *syaw = vz;
+  return ill;
 }
 
 // Steps (6)-(12) of estimate_bbox (reference src/util_3dbox.py:157-176) from the extents.
@@ -597,9 +610,11 @@ __device__ inline float max_f32_raw(float a, float b) {
   return r;
 }
 
-template <int PASS, bool CHK = true, bool SPEC = false>
+// PIV (pass 0, checked form only): the moments about the pivot (px0, pz0) - the re-run of an ill-conditioned instance (axis_from_sums)
+template <int PASS, bool CHK = true, bool SPEC = false, bool PIV = false>
 __device__ inline void quad_math(unsigned nib, const unsigned* db, double r0, double r1, double r2, double a00,
-                                 double a10, double a20, double* s, int* n) {
+                                 double a10, double a20, double* s, int* n, double px0 = 0.0, double pz0 = 0.0) {
+  static_assert(!PIV || (PASS == 0 && CHK && !SPEC), "the pivot exists in the checked general pass A only");
   float fk[4];   // SPEC pass 1: the quad's depths with NaN for invalid pixels (ignored by min / max)
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -617,7 +632,8 @@ __device__ inline void quad_math(unsigned nib, const unsigned* db, double r0, do
         s[0] += x; s[1] += d;
         s[2] = fma(x, x, s[2]); s[3] = fma(x, d, s[3]); s[4] = fma(d, d, s[4]);
       } else {
-        const double x = d * r0, z = d * r2;
+        double x = d * r0, z = d * r2;
+        if (PIV) { x = fma(d, r0, m ? -px0 : 0.0); z = fma(d, r2, m ? -pz0 : 0.0); }   // (an invalid pixel still contributes nothing)
         s[0] += x; s[1] += z;
         s[2] = fma(x, x, s[2]); s[3] = fma(x, z, s[3]); s[4] = fma(z, z, s[4]);
       }

@@ -533,15 +533,32 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
   }
 
   LA3D_STAMP(3);
-  stage_moments_to_axis(sh, p, inst_p, acc, cnt, nmask, tid, wave, lane, TILED && !sampled);
-  if (TILED && sh->redo) {  // uniform
-    __syncthreads();        // everyone has read sh->redo and the partials before they are rewritten
+  stage_moments_to_axis(sh, p, inst_p, acc, cnt, nmask, tid, wave, lane, true);
+  if (sh->redo) {  // uniform: non-finite sums (the optimistic tiled pass) or ill-conditioned ones (axis_from_sums) - the checked pass
+                   // about the pivot the stage left (zero unless the sums were ill-conditioned)
+    __syncthreads();        // everyone has read sh->redo and the partials before they are rewritten (the pivot stays where it is)
 #pragma unroll
     for (int i = 0; i < 5; ++i) acc[i] = 0;
     cnt = 0;
-    checked = true;
-    if (LK && cull) sweep_tiled<0, true, true>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, nullptr, compact, rng_words, -1, nfull);
-    else sweep_tiled<0, true>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, nullptr, compact, rng_words, -1, nfull);
+    if (sampled) {
+      if (pok) {
+        const double x = px - pivot_ptr(sh)[0], z = pz - pivot_ptr(sh)[1];
+        acc[0] = x; acc[1] = z; acc[2] = x * x; acc[3] = x * z; acc[4] = z * z;
+        cnt = 1;
+      }
+    } else if (TILED) {
+      if (sh->redo == 2) {   // ill-conditioned sums: the moments about the pivot; the optimistic pass's tile ranges and pass B stand
+        pivot_pass(p, dpl, bits, list, nactive, Mg, Mg + 6, wave, lane, compact, pivot_ptr(sh), acc, &cnt);
+      } else {
+        checked = true;
+        if (LK && cull) sweep_tiled<0, true, true>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, nullptr, compact, rng_words, -1, nfull);
+        else sweep_tiled<0, true>(p, dpl, bits, list, nactive, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, nullptr, compact, rng_words, -1, nfull);
+      }
+    } else {
+      double piv[2];
+      get_pivot(sh, piv);
+      sweep<VEC, LDSMASK, 0, true>(p, dpl, mpl, bits, Mg, Mg + 3, Mg + 6, wave, lane, acc, &cnt, &nmask, piv);
+    }
     stage_moments_to_axis(sh, p, inst_p, acc, cnt, nmask, tid, wave, lane, false);
   }
   LA3D_STAMP(4);

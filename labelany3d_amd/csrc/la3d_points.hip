@@ -280,7 +280,8 @@ __global__ __launch_bounds__(NTP) void fit_points_kernel(const PtsParams p) {
     else if (ni > 0) st = LA3D_BOX_NONFINITE;
     else if (nn == 1) st = LA3D_BOX_TOO_FEW;
     double cy = NAN, sy = NAN, gap = NAN;
-    if (st == LA3D_BOX_OK) axis_from_sums((double)nn, s[0], s[1], s[2], s[3], s[4], &cy, &sy, &gap);
+    // (ill-conditioned raw sums - axis_from_sums - of a cloud far from the origin of its frame: the gap says "axis unresolved")
+    if (st == LA3D_BOX_OK && axis_from_sums((double)nn, s[0], s[1], s[2], s[3], s[4], &cy, &sy, &gap)) gap = 0.0;
     if (HULL && st == LA3D_BOX_OK && nn > HCAP) st = LA3D_BOX_UNSUPPORTED;
     sh.cyaw = cy; sh.syaw = sy; sh.st = st; sh.nvalid = nn;
     if (p.aux) {
@@ -385,7 +386,7 @@ __device__ __forceinline__ void fit_cloud_wave(const double* pts, long long n_in
   else if (ni > 0) st = LA3D_BOX_NONFINITE;
   else if (nn == 1) st = LA3D_BOX_TOO_FEW;
   double cy = NAN, sy = NAN, gap = NAN;
-  if (st == LA3D_BOX_OK) axis_from_sums((double)nn, s0, s1, s2, s3, s4, &cy, &sy, &gap);
+  if (st == LA3D_BOX_OK && axis_from_sums((double)nn, s0, s1, s2, s3, s4, &cy, &sy, &gap)) gap = 0.0;   // (see fit_points_kernel)
   if (lane == 0) {
     if (aux) { aux[0] = atan2(sy, cy); aux[1] = (double)nn; aux[2] = (double)n_in; aux[3] = gap; }
     *status = st;

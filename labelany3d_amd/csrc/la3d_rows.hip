@@ -76,9 +76,12 @@ inline size_t rows_workspace_bytes_impl(int B, int H, int W) {
 
 // The plainest walk over one instance: thread t visits pixels t, t + NT, ... of the u8 plane, one at a time.  PASS 0: count and
 // moments of (x', z'); PASS 1: the six extents (A0 / A1 / A2 as in `sweep`).  Used where a path is rare and registers are scarce.
+// piv (pass 0, LDS): the pivot of the moments - zeros, or the mean an ill-conditioned first pass left (axis_from_sums); read per pixel
+// (x + -0.0 is x, bit for bit: the walk about zero gives the sums it always gave).
 template <int PASS>
 __device__ inline void sweep_plain(const FitParams& p, const float* __restrict__ dpl, const unsigned char* __restrict__ mpl,
-                                   const double* A0, const double* A1, const double* A2, int tid, double* acc, int* cnt, int* nmask) {
+                                   const double* A0, const double* A1, const double* A2, int tid, double* acc, int* cnt, int* nmask,
+                                   const double* piv = nullptr) {
 #pragma clang loop unroll(disable) vectorize(disable)
   for (int i = tid; i < p.HW; i += NT) {
     if (!mpl[i]) continue;
@@ -88,7 +91,9 @@ __device__ inline void sweep_plain(const FitParams& p, const float* __restrict__
     unsigned u, v;
     pix_uv((unsigned)i, p.W, p.rcpW, &u, &v);
     const double ud = (double)u, vd = (double)v, d = (double)df;
-    const double x = d * fma(A0[0], ud, fma(A0[1], vd, A0[2])), z = d * fma(A2[0], ud, fma(A2[1], vd, A2[2]));
+    double x, z;
+    if (PASS == 0) { x = fma(d, fma(A0[0], ud, fma(A0[1], vd, A0[2])), -piv[0]); z = fma(d, fma(A2[0], ud, fma(A2[1], vd, A2[2])), -piv[1]); }
+    else { x = d * fma(A0[0], ud, fma(A0[1], vd, A0[2])); z = d * fma(A2[0], ud, fma(A2[1], vd, A2[2])); }
     if (PASS == 0) {
       acc[0] += x; acc[1] += z;
       acc[2] = fma(x, x, acc[2]); acc[3] = fma(x, z, acc[3]); acc[4] = fma(z, z, acc[4]);
@@ -136,7 +141,7 @@ __device__ inline void rows_merge(Shared* sh, const FitParams& p, const RowsArgs
   if (!XCH && tid < 9) sh->M[tid] = part[10 + tid];              // band 0's camera (every band computed the same one; a band
                                                                   // that merges keeps its own: the same expression of the same K)
   else if (tid >= 9 && tid < 18) sh->Rg[tid - 9] = ((tid - 9) % 4 == 0) ? 1.0 : 0.0;   // no ground array: the identity (ground_rotation(nullptr))
-  if (tid == 18) { sh->bad_ground = 0; sh->order_inst = inst; sh->sep_bad = 0; }
+  if (tid == 18) { sh->bad_ground = 0; sh->order_inst = inst; sh->sep_bad = 0; set_pivot(sh, 0.0, 0.0); }
   double acc[5] = {0, 0, 0, 0, 0}, ylo = INFINITY, yhi = -INFINITY;
   int nm = 0, flag = 0;
   if (tid < ra.nb) {   // band b's record in lane b of wave 0: its first four granules
@@ -157,15 +162,25 @@ __device__ inline void rows_merge(Shared* sh, const FitParams& p, const RowsArgs
   // by this workgroup, pixel by pixel straight from the planes (sweep_plain: rare, written for few registers, not for speed)
   if (!generic) {   // uniform
     stage_moments_to_axis(sh, p, inst, acc, nm, nm, tid, wave, lane, true);
-    if (sh->redo) { generic = true; __syncthreads(); }   // uniform: non-finite sums
+    if (sh->redo) { generic = true; __syncthreads(); }   // uniform: non-finite or ill-conditioned sums (then the stage left a pivot)
   }
   const float* dpl = p.depth + (long long)img * p.depth_plane_stride;
   const unsigned char* mpl = p.mask + (long long)inst * p.HW;
   if (generic) {
+    // at most two walks: about the pivot at hand (zero, or the mean of ill-conditioned merged sums), then - should THESE sums be
+    // ill-conditioned (the first walk ran about zero) - about their mean
     double gacc[5] = {0, 0, 0, 0, 0};
     int cnt = 0, nmask = 0;
-    sweep_plain<0>(p, dpl, mpl, sh->M, sh->M + 3, sh->M + 6, tid, gacc, &cnt, &nmask);
-    stage_moments_to_axis(sh, p, inst, gacc, cnt, nmask, tid, wave, lane, false);
+    sweep_plain<0>(p, dpl, mpl, sh->M, sh->M + 3, sh->M + 6, tid, gacc, &cnt, &nmask, pivot_ptr(sh));
+    stage_moments_to_axis(sh, p, inst, gacc, cnt, nmask, tid, wave, lane, true);
+    if (sh->redo) {   // uniform
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 5; ++i) gacc[i] = 0;
+      cnt = 0; nmask = 0;
+      sweep_plain<0>(p, dpl, mpl, sh->M, sh->M + 3, sh->M + 6, tid, gacc, &cnt, &nmask, pivot_ptr(sh));
+      stage_moments_to_axis(sh, p, inst, gacc, cnt, nmask, tid, wave, lane, false);
+    }
   }
   if (sh->st != LA3D_BOX_OK) return;
   double ext[6] = {INFINITY, -INFINITY, INFINITY, -INFINITY, INFINITY, -INFINITY};

@@ -506,7 +506,8 @@ __global__ __launch_bounds__(SNT) void axis_kernel(const SplitParams sp) {
     else if (n == 0) st = LA3D_BOX_EMPTY;
     else if (n == 1) st = LA3D_BOX_TOO_FEW;
     double cy = NAN, sy = NAN, gap = NAN;
-    if (st == LA3D_BOX_OK) axis_from_sums((double)n, s[0], s[1], s[2], s[3], s[4], &cy, &sy, &gap);
+    // (ill-conditioned raw sums - axis_from_sums: this engine has no second moments pass, the record's gap says "axis unresolved")
+    if (st == LA3D_BOX_OK && axis_from_sums((double)n, s[0], s[1], s[2], s[3], s[4], &cy, &sy, &gap)) gap = 0.0;
     double* ax = sp.axis + (long long)inst * 4;
     ax[0] = cy; ax[1] = sy; ax[2] = (double)st; ax[3] = 0;
     if (p.aux) {

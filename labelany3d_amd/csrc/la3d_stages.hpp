@@ -13,8 +13,15 @@ namespace {
 // moments of all waves -> wave 0 (fixed xor tree: bit-reproducible) -> status, yaw axis.
 // On return sh->st / sh->cyaw / sh->syaw are valid for every thread.  The aux record (with its atan2) is
 // written at the end of the kernel (stage_status_aux), off everybody's critical path.
-// allow_redo: the sums come from the optimistic pass (quad_math<0, false>); if they are not finite, set sh->redo and return
-// without deciding anything - the caller re-runs the checked pass and calls again with allow_redo = false.
+// allow_redo: the sums come from the optimistic pass (quad_math<0, false>); if they are not finite - or ill-conditioned
+// (axis_from_sums) - set sh->redo (1 / 2) and return without deciding anything: the caller re-runs the checked pass (1) or the
+// moments about the pivot left in LDS (2: pivot_pass) and calls again with allow_redo = false.
+// The pivot of an ill-conditioned instance's second moments pass lives in two doubles of `part` that no stage uses between the axis
+// stage and the checked pass A (the moments stage writes part[w][0..4], the extents stages part[w][0..5] later on).
+__device__ inline void set_pivot(Shared* sh, double x, double z) { sh->part[NWAVE - 1][5] = x; sh->part[NWAVE - 1][6] = z; }
+__device__ inline const double* pivot_ptr(const Shared* sh) { return &sh->part[NWAVE - 1][5]; }
+__device__ inline void get_pivot(const Shared* sh, double* piv) { piv[0] = uniform_f64(sh->part[NWAVE - 1][5]); piv[1] = uniform_f64(sh->part[NWAVE - 1][6]); }
+
 __device__ inline void stage_moments_to_axis(Shared* sh, const FitParams& p, int inst, const double* acc, int cnt,
                                              int nmask, int tid, int wave, int lane, bool allow_redo = false) {
   {
@@ -50,9 +57,14 @@ __device__ inline void stage_moments_to_axis(Shared* sh, const FitParams& p, int
     else if (n == 0) st = LA3D_BOX_EMPTY;
     else if (n == 1) st = LA3D_BOX_TOO_FEW;
     const double chk = (s[0] + s[1]) + (s[2] + s[3]) + s[4];
-    sh->redo = (allow_redo && !sh->bad_ground && !(fabs(chk) <= 1.79769313486231570815e308)) ? 1 : 0;
+    const bool nonfinite = !(fabs(chk) <= 1.79769313486231570815e308);
     double cy = NAN, sy = NAN;
-    if (st == LA3D_BOX_OK) axis_from_sums((double)n, s[0], s[1], s[2], s[3], s[4], &cy, &sy, &gap);
+    bool ill = false;
+    if (st == LA3D_BOX_OK) ill = axis_from_sums((double)n, s[0], s[1], s[2], s[3], s[4], &cy, &sy, &gap);
+    // redo: non-finite sums -> the checked pass; ill-conditioned sums (axis_from_sums) -> the checked pass about the pivot left here
+    sh->redo = (allow_redo && !sh->bad_ground) ? (nonfinite ? 1 : (ill ? 2 : 0)) : 0;
+    set_pivot(sh, (ill && !nonfinite) ? s[0] / (double)n : 0.0, (ill && !nonfinite) ? s[1] / (double)n : 0.0);
+    if (ill && !allow_redo) gap = 0.0;   // unresolved about its own mean, or a path without a second pass: the "don't care" value
     sh->cyaw = cy; sh->syaw = sy;
     sh->qhead = 0u;   // pass B's work queue starts at the first tile
     sh->st = st;

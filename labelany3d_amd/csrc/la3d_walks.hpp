@@ -10,10 +10,13 @@ namespace {
 // 256 pixels per wave, 4 per lane.  PASS 0: count + moments of (x', z').  PASS 1: extents of all three
 // axes in the yaw frame.  A0/A1/A2 are the rows mapping [u,v,1] to the ray components: PASS 0 uses rows 0
 // and 2 of M; PASS 1 uses N0, M row 1, N2.
-template <bool VEC, bool LDSMASK, int PASS>
+// PIV (pass 0): the moments about pivot[0 .. 2) - the re-run of an ill-conditioned instance (axis_from_sums).
+template <bool VEC, bool LDSMASK, int PASS, bool PIV = false>
 __device__ inline void sweep(const FitParams& p, const float* __restrict__ dpl, const unsigned char* __restrict__ mpl,
                              const unsigned* bits, const double* A0, const double* A1, const double* A2,
-                             int wave, int lane, double* acc, int* cnt, int* nmask) {
+                             int wave, int lane, double* acc, int* cnt, int* nmask, const double* pivot = nullptr) {
+  double px0 = 0, pz0 = 0;
+  if constexpr (PIV) { px0 = pivot[0]; pz0 = pivot[1]; }
   const int HW = p.HW, W = p.W;
   const int nquads = (HW + 3) >> 2;
   const int nchunks = (nquads + 63) >> 6;
@@ -38,7 +41,7 @@ __device__ inline void sweep(const FitParams& p, const float* __restrict__ dpl, 
           for (int k = 0; k < 4; ++k)
             if (i0 + k < HW && mpl[i0 + k]) nib |= 1u << k;
         }
-        if (PASS == 0) nm += __popc(nib);
+        if (PASS == 0 && !PIV) nm += __popc(nib);   // (the re-run counts the mask pixels no second time)
       }
     }
     if (__ballot(nib != 0) == 0) continue;  // wave-uniform skip: nothing of this 256-pixel chunk is masked
@@ -75,7 +78,8 @@ __device__ inline void sweep(const FitParams& p, const float* __restrict__ dpl, 
         }
         if (PASS == 0) {
           const double d = ok ? (double)dk[k] : 0.0;
-          const double x = d * r0, z = d * r2;
+          double x = d * r0, z = d * r2;
+          if (PIV) { x = fma(d, r0, ok ? -px0 : 0.0); z = fma(d, r2, ok ? -pz0 : 0.0); }
           s0 += x; s1 += z;
           s2 = fma(x, x, s2); s3 = fma(x, z, s3); s4 = fma(z, z, s4);
           n += ok ? 1 : 0;
@@ -326,6 +330,36 @@ __device__ inline void sweep_tiled(const FitParams& p, const float* __restrict__
 #pragma unroll
   for (int i = 0; i < (PASS == 0 ? 5 : 6); ++i) acc[i] = sv[i];
   if (PASS == 0) *cnt = n;
+}
+
+// The moments of an ILL-CONDITIONED instance about a pivot (axis_from_sums; round 6): one tile per wave and step, one quad per lane,
+// the checked pixel math - written for few registers, not for speed (the walk is rare and must not cost the common path a register:
+// the tiled kernels sit at their 64-register budget).  The tile list / compact image as pass A left them; depth from memory (L2).
+__device__ inline void pivot_pass(const FitParams& p, const float* __restrict__ dpl, const unsigned* bits, const unsigned short* list,
+                                  int nactive, const double* A0, const double* A2, int wave, int lane, int compact,
+                                  const double* piv, double* acc, int* cnt) {
+  const int r = lane >> 3, cq = lane & 7;
+  const bool dense = nactive < 0;
+  const int nsteps = dense ? p.ntx * p.nty : nactive;
+  int n = 0;
+#pragma clang loop unroll(disable)
+  for (int j = wave; j < nsteps; j += NWAVE) {
+    int tx, ty;
+    if (dense) { ty = j / p.ntx; tx = j - ty * p.ntx; }
+    else { const unsigned t = __builtin_amdgcn_readfirstlane((unsigned)list[j]); tx = (int)(t & 0xffu); ty = (int)(t >> 8); }
+    const int row = ty * 8 + r;
+    unsigned nib = 0;
+    if (compact) nib = (bits[j * 8 + r] >> (cq * 4)) & 0xFu;
+    else if (row < p.H) nib = (bits[row * p.ntx + tx] >> (cq * 4)) & 0xFu;
+    if (nib) {
+      const uint4 dq = *reinterpret_cast<const uint4*>(dpl + (long long)row * p.W + tx * 32 + cq * 4);
+      const unsigned db[4] = {dq.x, dq.y, dq.z, dq.w};
+      const double vd = (double)row, ud = (double)(tx * 32 + cq * 4);
+      quad_math<0, true, false, true>(nib, db, fma(A0[0], ud, fma(A0[1], vd, A0[2])), 0.0, fma(A2[0], ud, fma(A2[1], vd, A2[2])),
+                                      A0[0], 0.0, A2[0], acc, &n, piv[0], piv[1]);
+    }
+  }
+  *cnt = n;
 }
 
 // ------------------------------------------------------------------------------------------

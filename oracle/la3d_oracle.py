@@ -167,11 +167,34 @@ def yaw_pca_closed_form(rotated_pc):
         )
     if not (np.isfinite(x).all() and np.isfinite(z).all()):
         raise ValueError("Input X contains infinity or a value too large for dtype('float64').")
+    if n < 20:
+        # the 'full' solver: LAPACK SVD of the CENTRED data - its axis is that of the centred second moments, with no
+        # cancellation however far the cloud lies from the origin (round 6: rounds 1-5 formed the raw-sum expression below for
+        # every n, which differs from the reference by ~2^-52 kappa / gap, kappa = pca_kappa(): visible for slivers far away)
+        xc, zc = x - x.mean(), z - z.mean()
+        return yaw_from_cov(np.dot(xc, xc), np.dot(xc, zc), np.dot(zc, zc), n)
+    # the 'covariance_eigh' solver forms C from RAW sums (C = X^T X - n mu mu^T): restated as it is, cancellation included - for
+    # kappa >> 1 the reference's own axis carries a rounding error of ~2^-52 kappa / gap that depends on its summation order
     sx, sz = x.sum(), z.sum()
     a = np.dot(x, x) - sx * sx / n
     c = np.dot(z, z) - sz * sz / n
     b = np.dot(x, z) - sx * sz / n
     return yaw_from_cov(a, b, c, n)
+
+
+def pca_kappa(rotated_pc):
+    """Conditioning of the raw-sum covariance of the (x, z) footprint: (sum x^2 + sum z^2) / (n * largest eigenvalue of the
+    centred second moments); 1 for a cloud centred on the origin, (distance / spread)^2 for a small cloud far away.  A diagnostic
+    for the tests (tolerances of n >= 20 clouds, where the reference itself works from raw sums), not part of the reference."""
+    x = np.asarray(rotated_pc[:, 0], np.longdouble)
+    z = np.asarray(rotated_pc[:, 2], np.longdouble)
+    if len(x) == 0 or not (np.isfinite(x).all() and np.isfinite(z).all()):
+        return float("nan")
+    raw = float((x * x).sum() + (z * z).sum())
+    xc, zc = x - x.mean(), z - z.mean()
+    a, b, c = float((xc * xc).sum()), float((xc * zc).sum()), float((zc * zc).sum())
+    l1 = 0.5 * (a + c) + math.sqrt((0.5 * (a - c)) ** 2 + b * b)
+    return raw / l1 if l1 > 0 else float("inf")
 
 
 def yaw_convex_hull(rotated_pc):
@@ -275,7 +298,7 @@ def estimate_bbox(in_pc, cat_name=None, ground_equ=None, method="pca", rand_ind=
         dimension = [dz, dy, dx]  # :175
         R_cam = Rg.T @ rotate_y(-yaw)  # :176
     if return_aux:
-        return verts, center_cam, dimension, R_cam, dict(yaw=float(yaw), n_valid=len(rotated))
+        return verts, center_cam, dimension, R_cam, dict(yaw=float(yaw), n_valid=len(rotated), kappa=pca_kappa(rotated))
     return verts, center_cam, dimension, R_cam
 
 
@@ -318,13 +341,13 @@ def fit_points(pts, ground=None, rand_ind=False, method="pca"):
     return pack39(v, c, d, R), ST_OK, aux
 
 
-def fit_instances(depth, masks, K, ground=None, sample_idx=None, depth_index=None, method="pca"):
+def fit_instances(depth, masks, K, ground=None, sample_idx=None, depth_index=None, method="pca", return_kappa=False):
     """Batched composition.  depth (P,H,W) or (H,W); masks (B,H,W); K (P,3,3) or (3,3).
 
     ``depth_index[n]`` selects the depth plane / K of instance n (default n, or 0 when a
     single plane is given).  ``sample_idx`` (B,500) int, rows ignored where the mask has
     <= 500 pixels; ``None`` = full-mask mode.
-    Returns records (B,39) f64, status (B,) i32, yaw (B,), n_valid (B,).
+    Returns records (B,39) f64, status (B,) i32, yaw (B,), n_valid (B,) [, kappa (B,): pca_kappa of every fitted cloud].
     """
     depth = np.asarray(depth)
     if depth.ndim == 2:
@@ -338,6 +361,7 @@ def fit_instances(depth, masks, K, ground=None, sample_idx=None, depth_index=Non
     status = np.zeros(B, np.int32)
     yaw = np.full(B, np.nan)
     nval = np.zeros(B, np.int64)
+    kappa = np.full(B, np.nan)
     cache = {}
     for n in range(B):
         img = int(depth_index[n]) if depth_index is not None else (n if depth.shape[0] > 1 else 0)
@@ -351,6 +375,9 @@ def fit_instances(depth, masks, K, ground=None, sample_idx=None, depth_index=Non
             ri = np.asarray(sample_idx[n])
         out[n], status[n], aux = fit_points(pts, g, ri, method)
         yaw[n], nval[n] = aux["yaw"], aux["n_valid"]
+        kappa[n] = aux.get("kappa", np.nan)
+    if return_kappa:
+        return out, status, yaw, nval, kappa
     return out, status, yaw, nval
 
 
