@@ -78,7 +78,18 @@ __device__ inline int chain_pass(const SharedHull* hs, const unsigned short* cl,
     const int i = cl[q];
     const double px = hs->x[i], pz = hs->z[i];
     while (k >= t) {
-      const double cr = (ax - ox) * (pz - oz) - (az - oz) * (px - ox);
+      // both products ROUNDED (no contraction into an fma, which keeps one product exact: for a point that repeats the stack top -
+      // the reference's subsample draws with replacement, src/util_3dbox.py:124 - the two products are the same two factors and
+      // the difference must be exactly zero, so that the repeat is popped; fused, the difference was the rounding error of one
+      // product, of either sign, and a repeated hull vertex could stay: a zero-length edge, i.e. a candidate yaw of 0 the
+      // reference never tries.  Found by profiles/r06/fuzz_points.py (round 6): every batched call with sample_idx and
+      // method = convex_hull was exposed, the scalar drop-in too)
+      double cr;
+      {
+#pragma clang fp contract(off)
+        const double t0 = (ax - ox) * (pz - oz), t1 = (az - oz) * (px - ox);
+        cr = t0 - t1;
+      }
       if (!(cr <= 0)) break;
       --k;
       ax = ox; az = oz;

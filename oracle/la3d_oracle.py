@@ -161,12 +161,14 @@ def yaw_pca_closed_form(rotated_pc):
     x = rotated_pc[:, 0]
     z = rotated_pc[:, 2]
     n = len(x)
+    # (scikit-learn validates the array - finiteness - before it looks at n_components: one infinite point gives the infinity
+    # message, not the n_components one; checked against scikit-learn in the build container, round 6)
+    if not (np.isfinite(x).all() and np.isfinite(z).all()):
+        raise ValueError("Input X contains infinity or a value too large for dtype('float64').")
     if n < 2:
         raise ValueError(
             "n_components=2 must be between 0 and min(n_samples, n_features)=%d with svd_solver='full'" % n
         )
-    if not (np.isfinite(x).all() and np.isfinite(z).all()):
-        raise ValueError("Input X contains infinity or a value too large for dtype('float64').")
     if n < 20:
         # the 'full' solver: LAPACK SVD of the CENTRED data - its axis is that of the centred second moments, with no
         # cancellation however far the cloud lies from the origin (round 6: rounds 1-5 formed the raw-sum expression below for
@@ -207,6 +209,10 @@ def yaw_convex_hull(rotated_pc):
     different, equally minimal, edges; tests avoid exact ties.
     """
     pts = np.asarray(rotated_pc)[:, [0, 2]]
+    if not np.isfinite(pts).all():
+        # Qhull rejects an infinite coordinate (QhullError QH6006, checked with scipy in the build container) -> the except branch
+        # (:222-224) -> PCA, where scikit-learn raises on the same coordinate
+        return yaw_pca_closed_form(rotated_pc)
     hull = _monotone_chain(pts)
     if len(hull) < 3:
         return yaw_pca_closed_form(rotated_pc)  # Qhull raises -> PCA fallback (:222-224)

@@ -85,6 +85,25 @@ def one_mask(rs, H, W):
     return m
 
 
+def one_polygon_mask(rs, H, W):
+    """A polygon annotation (1-3 parts, 1-24 vertices each, fractional coordinates, some outside the frame, some degenerate) and
+    the mask the reference's cv2.fillPoly gives for it (oracle/poly_oracle.py)."""
+    from oracle import poly_oracle as P
+
+    seg = []
+    for _ in range(rs.randint(1, 4)):
+        nv = int(rs.choice([1, 2, 3, 4, 5, 8, 12, 24]))
+        cx, cy = rs.uniform(-0.1 * W, 1.1 * W), rs.uniform(-0.1 * H, 1.1 * H)
+        ang = np.sort(rs.uniform(0, 2 * np.pi, nv))
+        rad = rs.uniform(0.5, 0.45 * min(H, W)) * rs.uniform(0.3, 1.0, nv)
+        xy = np.stack([cx + rad * np.cos(ang), cy + rad * np.sin(ang)], 1)
+        if rs.rand() < 0.3:
+            xy = np.round(xy)
+        seg.append([float(v) for v in xy.ravel()])
+    m, _ = P.create_boolean_mask_from_polygon((W, H), seg)
+    return m, seg
+
+
 def one_plane(rs, H, W):
     kind = rs.randint(0, 5)
     yy, xx = np.mgrid[:H, :W]
@@ -114,6 +133,9 @@ def make_case(seed):
     rs = np.random.RandomState(seed)
     H, W = HS[rs.randint(len(HS))], WS[rs.randint(len(WS))]
     B = BS[rs.randint(len(BS))]
+    poly_case = rs.rand() < 0.3              # every mask of the case is a polygon annotation: the case also runs through the polygon entry
+    if poly_case:                            # (the oracle's rasteriser is a Python loop: smaller frames, fewer instances)
+        H, W, B = min(H, 240), min(W, 333), min(B, 33)
     while B * H * W > 24_000_000 and B > 1:
         B = max(1, B // 2)
     mode = rs.randint(0, 3)                  # 0: one shared plane, 1: private planes, 2: P planes + image_index
@@ -135,9 +157,13 @@ def make_case(seed):
         K[p] = [[f, rs.uniform(-5, 5) if skew else 0.0, W / 2 + rs.uniform(-0.3, 0.3) * W], [0, f * rs.uniform(0.8, 1.25), H / 2 + rs.uniform(-0.3, 0.3) * H], [0, 0, 1]]
     if rs.rand() < 0.5:
         K[:] = K[0]
-    masks, mkind = [], []
+    masks, mkind, segs = [], [], []
     for _ in range(B):
-        masks.append(one_mask(rs, H, W)); mkind.append(one_mask.kind)
+        if poly_case:
+            m, seg = one_polygon_mask(rs, H, W)
+            masks.append(m); mkind.append(14); segs.append(seg)
+        else:
+            masks.append(one_mask(rs, H, W)); mkind.append(one_mask.kind)
     masks = np.stack(masks)
     mb = masks.astype(np.uint8)
     bytes_kind = rs.randint(0, 3)
@@ -167,7 +193,7 @@ def make_case(seed):
             if c > 500:
                 sidx[n] = rs.randint(0, int(c), 500)
     return dict(seed=seed, H=H, W=W, B=B, P=P, depth=depth, K=K, masks=masks, mb=mb, ground=ground, image_index=image_index, sidx=sidx,
-                skew=skew, mkind=mkind, dkind=dkind)
+                skew=skew, mkind=mkind, dkind=dkind, segs=segs if poly_case else None)
 
 
 def oracle_case(seed):
@@ -188,6 +214,10 @@ def oracle_case(seed):
     return seed, rec, st, nv, kap
 
 
+# the annotation entries (run lengths decoded / polygons rasterised inside the fit kernel): the same masks as run lengths for every
+# case, as polygons for the polygon cases
+ANN_RUNS = [dict(entry="rle"), dict(entry="rle", engine="instance"), dict(entry="rle", engine="split"),
+            dict(entry="poly"), dict(entry="poly", engine="instance"), dict(entry="poly", engine="split")]
 RUNS = [dict(), dict(engine="instance"), dict(engine="band"), dict(engine="rows"), dict(engine="rows2"), dict(engine="split"),
         dict(build="plain"), dict(build="nocull"), dict(engine="instance", launch_order=False), dict(engine="band", launch_order=False)]
 
@@ -211,26 +241,42 @@ def main():
     import torch
 
     import labelany3d_amd as la
+    from labelany3d_amd.masks import fit_instances_poly, fit_instances_rle, pack_polygons
     from labelany3d_amd.options import scheduling
+    from oracle import la3d_oracle as O
     from tests.test_gpu_parity import assert_records, reference_axis_noise
 
     assert torch.cuda.is_available(), "the campaign needs the GPU"
     np_ = lambda t: t.detach().cpu().numpy()
-    n_inst = n_rec = n_tie = 0
+    n_inst = n_rec = n_tie = n_poly = 0
     fails = []
-    per_run = {repr(r): 0 for r in RUNS}
-    n_ill = {repr(r): 0 for r in RUNS}
+    all_runs = RUNS + ANN_RUNS
+    per_run = {repr(r): 0 for r in all_runs}
+    n_ill = {repr(r): 0 for r in all_runs}
     worst = 0.0
     t0 = time.time()
     for s in seeds:
         c = make_case(s)
         rec, st, nv, kap = ref[s]
         n_inst += c["B"]
+        n_poly += c["segs"] is not None
         nm = c["masks"].reshape(c["B"], -1).sum(1)
-        for r in RUNS:
-            with scheduling(**r):
+        rles = None
+        for r in all_runs:
+            entry = r.get("entry")
+            if entry == "poly" and c["segs"] is None:
+                continue
+            with scheduling(**{k: v for k, v in r.items() if k != "entry"}):
                 try:
-                    b, stg, aux = la.fit_instances(c["depth"], c["mb"], c["K"], ground=c["ground"], sample_idx=c["sidx"], image_index=c["image_index"])
+                    kw = dict(ground=c["ground"], sample_idx=c["sidx"], image_index=c["image_index"])
+                    if entry == "rle":
+                        if rles is None:
+                            rles = [O.rle_encode(m) for m in c["masks"]]
+                        b, stg, aux = fit_instances_rle(c["depth"], rles, c["K"], **kw)
+                    elif entry == "poly":
+                        b, stg, aux = fit_instances_poly(c["depth"], pack_polygons(c["segs"], c["H"], c["W"]), c["K"], **kw)
+                    else:
+                        b, stg, aux = la.fit_instances(c["depth"], c["mb"], c["K"], **kw)
                     b, stg, aux = np_(b), np_(stg), np_(aux)
                 except Exception as e:   # noqa: BLE001 - a campaign records every failure and goes on
                     fails.append((s, r, f"call failed: {e!r}"))
@@ -265,7 +311,7 @@ def main():
                                         f"gap {aux[n, 3]:.3g} kappa {kap[n]:.3g} | d center/dims {np.abs(b[n, :6] - rec[n, :6]).max():.3g} (scale {np.abs(rec[n, :6]).max():.3g}) "
                                         f"dR {np.abs(b[n, 6:15] - rec[n, 6:15]).max():.3g} dV {np.nanmax(np.abs(b[n, 15:] - rec[n, 15:])):.3g} dims {rec[n, 3:6].round(6).tolist()}"))
     t_gpu = time.time() - t0
-    lines = [f"fuzz_engines: {len(seeds)} cases (seeds {seeds[0]}..{seeds[-1]}), {n_inst} instances, {len(RUNS)} runs per case",
+    lines = [f"fuzz_engines: {len(seeds)} cases (seeds {seeds[0]}..{seeds[-1]}), {n_inst} instances, {len(RUNS)} runs per case through the u8 entry + {len(ANN_RUNS)} through the annotation entries (3 as run lengths, 3 as polygons for the {n_poly} polygon cases)",
              f"oracle: {t_or:.0f} s on {a.workers} host cores; GPU runs + comparison: {t_gpu:.0f} s",
              f"records compared with the oracle: {n_rec} (+ {n_tie} exact ties held to status / counts only)",
              f"worst relative error of center / dims among records with an eigen-gap above 1e-4: {worst:.2e}",

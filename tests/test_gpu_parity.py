@@ -886,6 +886,34 @@ def test_fit_points_wave_per_cloud_equals_workgroup_per_cloud(la):
                 np.testing.assert_allclose(np_(bw)[i, :15], rec[:15], rtol=0, atol=1e-9 * max(1.0, np.abs(rec[:6]).max()))
 
 
+def test_convex_hull_on_subsampled_clouds_with_repeated_points(la):
+    """The reference's subsample draws WITH replacement (np.random.randint, src/util_3dbox.py:124): a 500-row draw from a cloud of
+    700 repeats ~150 rows, hull vertices among them.  A repeated vertex must drop out of the chain (its turn test is an exact zero:
+    both products have the same factors) - with the products fused into one fma it was the rounding error of one product and a
+    repeat could stay, adding a zero-length edge, i.e. the candidate yaw 0 that the reference never tries (round 6, found by
+    profiles/r06/fuzz_points.py: the batched sample_idx path and the scalar drop-in were both exposed).  General-position clouds at
+    irrational coordinates, in-kernel sampling and explicit repeats, both forms of the hull kernel: yaw and record follow the oracle
+    (= scipy's Qhull on these clouds) at 1e-9."""
+    rs = np.random.RandomState(1)
+    clouds, sidx = [], []
+    for N in [501, 700, 700, 1500, 2047, 3000, 5000, 600]:
+        clouds.append(rs.randn(N, 3) * [2, 1, 0.7] @ O.rotate_y(rs.uniform(-3, 3)).T + [rs.uniform(-5, 5), 0, rs.uniform(4, 30)])
+        sidx.append(rs.randint(0, N, 500))
+    sidx = np.stack(sidx).astype(np.int32)
+    ground = np.array([[0.05, -0.97, 0.1, 1.2]] * len(clouds)) + 0.02 * rs.randn(len(clouds), 4)
+    for g in (None, ground):
+        b, st, a = (np_(t) for t in la.fit_points(clouds, g, sidx, "convex_hull"))
+        # the same draws handed over as explicit clouds of 500 rows (repeats included), through the 2048-row form of the kernel
+        b2, st2, a2 = (np_(t) for t in la.fit_points([c[i] for c, i in zip(clouds, sidx)], g, None, "convex_hull", hull_512=False))
+        for n, (c, i) in enumerate(zip(clouds, sidx)):
+            rec, s_, aux = O.fit_points(c, None if g is None else g[n], i, "convex_hull")
+            assert s_ == 0 and st[n] == 0 and st2[n] == 0
+            for got, yaw in ((b[n], a[n, 0]), (b2[n], a2[n, 0])):
+                assert yaw == pytest.approx(aux["yaw"], abs=1e-9), (n, len(c))
+                assert_records(got[None], rec[None], f"hull-sampled[{n}]")
+            assert a[n, 3] == a2[n, 3] <= -3      # the same number of hull vertices either way
+
+
 def test_convex_hull_yaw_stress_duplicates_and_collinear_runs(la):
     """The convex-hull yaw runs its monotone chain in levels (16 lanes reduce chunks, 4 lanes quarters, one lane finishes): with exact
     predicates the vertex sequence is the serial chain's; the fp64 cross products are rounded, so nearly collinear points or
