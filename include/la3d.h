@@ -29,7 +29,13 @@ extern "C" {
 #define LA3D_REC 39      /* doubles per box: center_cam[3] dimensions[3]=(dz,dy,dx) R_cam[9] bbox3D_cam[8][3] */
 #define LA3D_AUX 4       /* doubles per box: yaw, n_valid, n_in (mask pixels / cloud points), eigen-gap (l1-l2)/l1;
                             with LA3D_METHOD_CONVEX_HULL aux[3] = -(hull vertices) when the hull decided the yaw
-                            and stays >= 0 when the reference's PCA fallback was taken (:222-224) */
+                            and stays >= 0 when the reference's PCA fallback was taken (:222-224).
+                            The PCA axis is conditioned like 1 / gap.  gap == 0 says "axis unresolved - any yaw is as good":
+                            an exact tie of the two eigenvalues, a footprint without any spread, or (split engine, point
+                            clouds: the paths without a second moments pass) a footprint whose spread is below ~1/360 of its
+                            distance from the origin of the sums - the raw second moments then cancel to rounding noise
+                            (kappa = (sum x^2 + sum z^2) / (n l1) > 2^17).  The instance, band and row engines resolve that
+                            case by a second moments pass about the mean and report the true gap */
 #define LA3D_NSAMPLE 500 /* reference src/util_3dbox.py:123-125 */
 
 /* call status */
