@@ -125,7 +125,7 @@ def main():
 
     assert torch.cuda.is_available(), "the campaign needs the GPU"
     np_ = lambda t: t.detach().cpu().numpy()
-    n_cloud = n_rec = n_tie = n_cap = n_hull_tied = n_hull_flat = 0
+    n_cloud = n_rec = n_tie = n_cap = n_hull_tied = n_hull_flat = n_scalar = 0
     fails = []
     t0 = time.time()
     for s in seeds:
@@ -180,11 +180,48 @@ def main():
                         fails.append((tag, f"cloud {n} ({len(c['clouds'][n])} rows, n_valid {int(aux[n, 1])}, gap {aux[n, 3]:.3g}, kappa {kap[n]:.3g}): "
                                            f"{what[0].strip() if what else 'mismatch'} | d center/dims {np.abs(b[n, :6] - rec[n, :6]).max():.3g} "
                                            f"dR {np.abs(b[n, 6:15] - rec[n, 6:15]).max():.3g} area {footprint_area(b[n]):.6g} vs {footprint_area(rec[n]):.6g}"))
+        # the scalar drop-in (la3d_estimate_bbox_host: the cloud pulled from pinned host memory into LDS by a kernel of its own): the
+        # first clouds of every full-cloud case, one call each, errors as the reference's exceptions
+        if c["sidx"] is None:
+            import contextlib
+            import io
+
+            from labelany3d_amd import util_3dbox as U
+
+            for method in ("pca", "convex_hull"):
+                rec, st, nv, kap = ref[s][method]
+                for n in range(min(c["B"], 6)):
+                    g = None if c["ground"] is None or np.isnan(c["ground"][n, 0]) else c["ground"][n]
+                    tag = f"seed {s} cloud {n} ({len(c['clouds'][n])} rows) scalar drop-in {method}"
+                    try:
+                        with contextlib.redirect_stdout(io.StringIO()):
+                            r1, a1 = U._fit_one(c["clouds"][n], g, method, subsample=False)
+                        got_st = 0
+                    except ValueError as e:   # (statuses 1 and 2 share the reference's message)
+                        got_st = [k for k, v in U._MESSAGES.items() if v == str(e)]
+                        got_st = int(st[n]) if int(st[n]) in got_st else (got_st[0] if got_st else -1)
+                    n_scalar += 1
+                    if got_st == 5 and st[n] == 0 and nv[n] > 2048 and method == "convex_hull":
+                        continue
+                    if got_st != st[n]:
+                        fails.append((tag, f"status {got_st} expected {int(st[n])}")); continue
+                    if got_st != 0 or (method == "pca" and not a1[3] >= 1e-9):
+                        continue
+                    try:
+                        assert_records(r1[None], rec[n:n + 1], tag, gap=a1[3:4] if method == "pca" else None,
+                                       noise=reference_axis_noise(kap[n:n + 1], a1[1:2], a1[3:4]) if method == "pca" else None)
+                    except AssertionError as e:
+                        ext = max(np.abs(rec[n, 3:6]).max(), 1e-300)
+                        if method == "convex_hull" and (abs(footprint_area(r1) - footprint_area(rec[n])) <= 1e-9 * max(footprint_area(rec[n]), 1e-300)
+                                                        or max(footprint_area(r1), footprint_area(rec[n])) <= 1e-9 * ext * ext):
+                            continue
+                        fails.append((tag, str(e).strip().splitlines()[-1][:200]))
     t_gpu = time.time() - t0
     lines = [f"fuzz_points: {len(seeds)} cases (seeds {seeds[0]}..{seeds[-1]}), {n_cloud} clouds, both yaw methods, {len(RUNS)} launches per case and method",
              f"oracle: {t_or:.0f} s on {a.workers} host cores; GPU runs + comparison: {t_gpu:.0f} s",
              f"records compared with the oracle: {n_rec} (+ {n_tie} PCA records with gap < 1e-9 - exact ties, no spread, or ill-conditioned for raw sums - held to status / counts; "
              f"{n_hull_tied} hull records whose minimum-area edge is tied within 1e-9 of the area, held to the area; {n_hull_flat} hull records of footprints without area (collinear within rounding: whether a hull exists is decided by the last bits), held to status / counts / height; {n_cap} hull clouds above 2048 valid rows: status 5)",
+             f"scalar drop-in (la3d_estimate_bbox_host) calls compared: {n_scalar}",
              f"failures: {len(fails)}"]
     lines += [f"  FAIL {t}: {m}" for t, m in fails[:300]]
     txt = "\n".join(lines)
