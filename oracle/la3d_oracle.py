@@ -184,19 +184,25 @@ def yaw_pca_closed_form(rotated_pc):
     return yaw_from_cov(a, b, c, n)
 
 
-def pca_kappa(rotated_pc):
-    """Conditioning of the raw-sum covariance of the (x, z) footprint: (sum x^2 + sum z^2) / (n * largest eigenvalue of the
-    centred second moments); 1 for a cloud centred on the origin, (distance / spread)^2 for a small cloud far away.  A diagnostic
-    for the tests (tolerances of n >= 20 clouds, where the reference itself works from raw sums), not part of the reference."""
+def pca_conditioning(rotated_pc):
+    """(kappa, gap) of the (x, z) footprint, from the centred second moments in long double.
+    kappa = (sum x^2 + sum z^2) / (n * largest eigenvalue): the conditioning of a covariance formed from RAW sums - 1 for a cloud
+    centred on the origin, (distance / spread)^2 for a small cloud far away; gap = (l1 - l2) / l1, the relative eigen-gap the
+    axis is conditioned by.  Diagnostics for the tests (tolerances), not part of the reference."""
     x = np.asarray(rotated_pc[:, 0], np.longdouble)
     z = np.asarray(rotated_pc[:, 2], np.longdouble)
     if len(x) == 0 or not (np.isfinite(x).all() and np.isfinite(z).all()):
-        return float("nan")
+        return float("nan"), float("nan")
     raw = float((x * x).sum() + (z * z).sum())
     xc, zc = x - x.mean(), z - z.mean()
     a, b, c = float((xc * xc).sum()), float((xc * zc).sum()), float((zc * zc).sum())
-    l1 = 0.5 * (a + c) + math.sqrt((0.5 * (a - c)) ** 2 + b * b)
-    return raw / l1 if l1 > 0 else float("inf")
+    rad = math.sqrt((0.5 * (a - c)) ** 2 + b * b)
+    l1 = 0.5 * (a + c) + rad
+    return (raw / l1, 2.0 * rad / l1) if l1 > 0 else (float("inf"), 0.0)
+
+
+def pca_kappa(rotated_pc):
+    return pca_conditioning(rotated_pc)[0]
 
 
 def yaw_convex_hull(rotated_pc):
@@ -304,7 +310,7 @@ def estimate_bbox(in_pc, cat_name=None, ground_equ=None, method="pca", rand_ind=
         dimension = [dz, dy, dx]  # :175
         R_cam = Rg.T @ rotate_y(-yaw)  # :176
     if return_aux:
-        return verts, center_cam, dimension, R_cam, dict(yaw=float(yaw), n_valid=len(rotated), kappa=pca_kappa(rotated))
+        return verts, center_cam, dimension, R_cam, dict(yaw=float(yaw), n_valid=len(rotated), kappa=pca_conditioning(rotated)[0], gap=pca_conditioning(rotated)[1])
     return verts, center_cam, dimension, R_cam
 
 
