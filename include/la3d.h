@@ -31,11 +31,12 @@ extern "C" {
                             with LA3D_METHOD_CONVEX_HULL aux[3] = -(hull vertices) when the hull decided the yaw
                             and stays >= 0 when the reference's PCA fallback was taken (:222-224).
                             The PCA axis is conditioned like 1 / gap.  gap == 0 says "axis unresolved - any yaw is as good":
-                            an exact tie of the two eigenvalues, a footprint without any spread, or (split engine, point
-                            clouds: the paths without a second moments pass) a footprint whose spread is below ~1/360 of its
-                            distance from the origin of the sums - the raw second moments then cancel to rounding noise
-                            (kappa = (sum x^2 + sum z^2) / (n l1) > 2^17).  The instance, band and row engines resolve that
-                            case by a second moments pass about the mean and report the true gap */
+                            an exact tie of the two eigenvalues or a footprint without any spread (every point at the same
+                            (x', z'): the reference's own axis is then the SVD of rounding noise).  A footprint whose spread
+                            is below ~1/360 of its distance from the origin of the sums - the raw second moments cancel to
+                            rounding noise, kappa = (sum x^2 + sum z^2) / (n l1) > 2^17 - is resolved by a second moments
+                            pass about the mean (every engine, every point-cloud kernel) and reports its true gap
+                             */
 #define LA3D_NSAMPLE 500 /* reference src/util_3dbox.py:123-125 */
 
 /* call status */

@@ -50,7 +50,8 @@ struct alignas(16) SharedP {
   int nvalid;
   int hull_n;       // number of hull vertices found (0 = method not run)
   int fill;
-  int pad;
+  int redo;         // the raw sums are ill-conditioned (axis_from_sums): a second moments pass about pivot[]
+  double pivot[2];
 };
 
 // LDS of the convex-hull method (separate struct: only the hull instantiation pays for it)
@@ -291,9 +292,12 @@ __global__ __launch_bounds__(NTP) void fit_points_kernel(const PtsParams p) {
     else if (ni > 0) st = LA3D_BOX_NONFINITE;
     else if (nn == 1) st = LA3D_BOX_TOO_FEW;
     double cy = NAN, sy = NAN, gap = NAN;
-    // (ill-conditioned raw sums - axis_from_sums - of a cloud far from the origin of its frame: the gap says "axis unresolved")
-    if (st == LA3D_BOX_OK && axis_from_sums((double)nn, s[0], s[1], s[2], s[3], s[4], &cy, &sy, &gap)) gap = 0.0;
+    // ill-conditioned raw sums (axis_from_sums: a cloud whose footprint is far thinner than its distance from the origin of its
+    // frame): the moments once more about the mean, below
+    const bool ill = st == LA3D_BOX_OK && axis_from_sums((double)nn, s[0], s[1], s[2], s[3], s[4], &cy, &sy, &gap);
     if (HULL && st == LA3D_BOX_OK && nn > HCAP) st = LA3D_BOX_UNSUPPORTED;
+    sh.redo = (ill && st == LA3D_BOX_OK) ? 1 : 0;
+    sh.pivot[0] = s[0] / (double)nn; sh.pivot[1] = s[1] / (double)nn;
     sh.cyaw = cy; sh.syaw = sy; sh.st = st; sh.nvalid = nn;
     if (p.aux) {
       double* a = p.aux + (long long)c * LA3D_AUX;
@@ -304,6 +308,43 @@ __global__ __launch_bounds__(NTP) void fit_points_kernel(const PtsParams p) {
   }
   __syncthreads();
   if (sh.st != LA3D_BOX_OK) return;
+  if (sh.redo) {   // uniform, rare
+    const double px0 = sh.pivot[0], pz0 = sh.pivot[1];
+    double t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    for (long long i = tid; i < m; i += NTP) {
+      long long row = i;
+      if (sampled) {
+        long long r = sidx[i];
+        row = r < 0 ? 0 : (r >= n_in ? n_in - 1 : r);
+      }
+      const double* q = p.points + (off + row) * 3;
+      const double a = q[0], b = q[1], cc = q[2];
+      const double x = a * R00 + b * R10 + cc * R20, y = a * R01 + b * R11 + cc * R21, z = a * R02 + b * R12 + cc * R22;
+      if (!(x != x || y != y || z != z)) {
+        const double dx = x - px0, dz = z - pz0;
+        t0 += dx; t1 += dz; t2 = fma(dx, dx, t2); t3 = fma(dx, dz, t3); t4 = fma(dz, dz, t4);
+      }
+    }
+    __syncthreads();   // (thread 0 has read part[] of the first pass)
+    {
+      const double r0 = wave_sum(t0), r1 = wave_sum(t1), r2 = wave_sum(t2), r3 = wave_sum(t3), r4 = wave_sum(t4);
+      if (lane == 0) { double* pp = sh.part[wave]; pp[0] = r0; pp[1] = r1; pp[2] = r2; pp[3] = r3; pp[4] = r4; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double s[5] = {0, 0, 0, 0, 0};
+      for (int w = 0; w < NWAVEP; ++w)
+        for (int k = 0; k < 5; ++k) s[k] += sh.part[w][k];
+      double cy = NAN, sy = NAN, gap = NAN;
+      if (axis_from_sums((double)sh.nvalid, s[0], s[1], s[2], s[3], s[4], &cy, &sy, &gap)) gap = 0.0;   // no spread at all: unresolved
+      sh.cyaw = cy; sh.syaw = sy;
+      if (p.aux) {
+        double* a = p.aux + (long long)c * LA3D_AUX;
+        a[0] = atan2(sy, cy); a[3] = gap;
+      }
+    }
+    __syncthreads();
+  }
   if constexpr (HULL) {
     double yaw;
     if (hull_yaw(&hstore.h, &sh, tid, &yaw)) {   // else: degenerate hull -> the PCA axis stands (reference :222-224)
@@ -397,7 +438,26 @@ __device__ __forceinline__ void fit_cloud_wave(const double* pts, long long n_in
   else if (ni > 0) st = LA3D_BOX_NONFINITE;
   else if (nn == 1) st = LA3D_BOX_TOO_FEW;
   double cy = NAN, sy = NAN, gap = NAN;
-  if (st == LA3D_BOX_OK && axis_from_sums((double)nn, s0, s1, s2, s3, s4, &cy, &sy, &gap)) gap = 0.0;   // (see fit_points_kernel)
+  if (st == LA3D_BOX_OK && axis_from_sums((double)nn, s0, s1, s2, s3, s4, &cy, &sy, &gap)) {   // wave-uniform, rare (see fit_points_kernel):
+    const double px0 = s0 / (double)nn, pz0 = s1 / (double)nn;                                 // the moments once more about the mean
+    double t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    for (long long i = lane; i < m; i += 64) {
+      long long row = i;
+      if (sampled) {
+        const long long r = sidx[i];
+        row = r < 0 ? 0 : (r >= n_in ? n_in - 1 : r);
+      }
+      const double* q = pts + row * 3;
+      const double a = q[0], b = q[1], cc = q[2];
+      const double x = a * Rg[0] + b * Rg[3] + cc * Rg[6], y = a * Rg[1] + b * Rg[4] + cc * Rg[7], z = a * Rg[2] + b * Rg[5] + cc * Rg[8];
+      if (!(x != x || y != y || z != z)) {
+        const double dx = x - px0, dz = z - pz0;
+        t0 += dx; t1 += dz; t2 = fma(dx, dx, t2); t3 = fma(dx, dz, t3); t4 = fma(dz, dz, t4);
+      }
+    }
+    t0 = wave_sum(t0); t1 = wave_sum(t1); t2 = wave_sum(t2); t3 = wave_sum(t3); t4 = wave_sum(t4);
+    if (axis_from_sums((double)nn, t0, t1, t2, t3, t4, &cy, &sy, &gap)) gap = 0.0;   // no spread at all: unresolved
+  }
   if (lane == 0) {
     if (aux) { aux[0] = atan2(sy, cy); aux[1] = (double)nn; aux[2] = (double)n_in; aux[3] = gap; }
     *status = st;

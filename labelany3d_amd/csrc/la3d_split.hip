@@ -498,16 +498,50 @@ __global__ __launch_bounds__(SNT) void axis_kernel(const SplitParams sp) {
   int nm = 0;
   for (int j = lane; j < sp.nband; j += 64) nm += sp.nmaskb[inst * sp.nband + j];
   nm = wave_sum_i(nm);
+  // (every lane holds the sums: status and axis are computed by all of them, so that the rare second pass below is wave-uniform)
+  const double* geo = p.geo + (long long)inst * GEO_D;
+  const int n = (int)nd;
+  int st = LA3D_BOX_OK;
+  if (geo[18] != 0.0) st = LA3D_BOX_BAD_GROUND;
+  else if (n == 0) st = LA3D_BOX_EMPTY;
+  else if (n == 1) st = LA3D_BOX_TOO_FEW;
+  double cy = NAN, sy = NAN, gap = NAN;
+  if (st == LA3D_BOX_OK && axis_from_sums((double)n, s[0], s[1], s[2], s[3], s[4], &cy, &sy, &gap)) {
+    // ill-conditioned raw sums (axis_from_sums; round 6): the instance's tiles once more by this wave, the moments about the mean -
+    // one tile per step, the checked pixel math (rare: a footprint far thinner than its distance)
+    const double px0 = s[0] / (double)n, pz0 = s[1] / (double)n;
+    const double A0[3] = {geo[0], geo[1], geo[2]}, A2[3] = {geo[6], geo[7], geo[8]};
+    const int img = p.image_index ? p.image_index[inst] : inst;
+    const float* dpl = p.depth + (long long)img * p.depth_plane_stride;
+    const int r = lane >> 3, cq = lane & 7;
+    const long long seg0 = (long long)sp.b0 * sp.nband;
+    double t[5] = {0, 0, 0, 0, 0};
+    int cnt = 0;
+    for (int b = 0; b < sp.nband; ++b) {
+      const int seg = irel * sp.nband + b;
+      const int len = sp.toff[seg + 1] - sp.toff[seg];
+      const unsigned short* lst = sp.tlist + (seg0 + seg) * sp.tpb;
+      const unsigned* wb = sp.tbits + (seg0 + seg) * sp.tpb * 8 + r;
+#pragma clang loop unroll(disable)
+      for (int k = 0; k < len; ++k) {
+        const unsigned tt = __builtin_amdgcn_readfirstlane((unsigned)lst[k]);
+        const int tx = (int)(tt & 0xffu), ty = (int)(tt >> 8);
+        const int row = ty * 8 + r;
+        const unsigned nib = row < p.H ? (wb[k * 8] >> (cq * 4)) & 0xFu : 0u;
+        if (nib) {
+          const uint4 dq = *reinterpret_cast<const uint4*>(dpl + (long long)row * p.W + tx * 32 + cq * 4);
+          const unsigned db[4] = {dq.x, dq.y, dq.z, dq.w};
+          const double vd = (double)row, ud = (double)(tx * 32 + cq * 4);
+          quad_math<0, true, false, true>(nib, db, fma(A0[0], ud, fma(A0[1], vd, A0[2])), 0.0, fma(A2[0], ud, fma(A2[1], vd, A2[2])),
+                                          A0[0], 0.0, A2[0], t, &cnt, px0, pz0);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) t[k] = wave_sum(t[k]);
+    if (axis_from_sums((double)n, t[0], t[1], t[2], t[3], t[4], &cy, &sy, &gap)) gap = 0.0;   // no spread at all: unresolved
+  }
   if (lane == 0) {
-    const double* geo = p.geo + (long long)inst * GEO_D;
-    const int n = (int)nd;
-    int st = LA3D_BOX_OK;
-    if (geo[18] != 0.0) st = LA3D_BOX_BAD_GROUND;
-    else if (n == 0) st = LA3D_BOX_EMPTY;
-    else if (n == 1) st = LA3D_BOX_TOO_FEW;
-    double cy = NAN, sy = NAN, gap = NAN;
-    // (ill-conditioned raw sums - axis_from_sums: this engine has no second moments pass, the record's gap says "axis unresolved")
-    if (st == LA3D_BOX_OK && axis_from_sums((double)n, s[0], s[1], s[2], s[3], s[4], &cy, &sy, &gap)) gap = 0.0;
     double* ax = sp.axis + (long long)inst * 4;
     ax[0] = cy; ax[1] = sy; ax[2] = (double)st; ax[3] = 0;
     if (p.aux) {
