@@ -14,8 +14,8 @@ plain and the no-cull build and with the launch order off; EVERY record of EVERY
 (oracle/la3d_oracle.py, computed beforehand on the host cores): status, n_valid, n_masked exactly, center / dims / R / corners by
 tests/test_gpu_parity.py::assert_records' rule (1e-9 of the scale, the axis conditioned by the eigen-gap; for clouds of 20 and more
 points, where the reference itself works from raw sums, its own rounding noise ~2^-52 kappa / gap on top: reference_axis_noise).
-Records whose reported eigen-gap is below 1e-9 (exact ties, clouds without any spread, and - in the engines without a second
-moments pass - clouds ill-conditioned for raw sums: the documented don't-care value) are counted and held to status / counts.
+Records whose reported eigen-gap is below 1e-9 (exact ties and clouds without any spread: the documented don't-care value)
+are counted and held to status / counts.
 
 The oracle is test infrastructure: it is the checker here.  Nothing under /root/reference is read."""
 import argparse
