@@ -541,8 +541,17 @@ __global__ __launch_bounds__(256) void align_apply_kernel(const float* __restric
   if (i >= n) return;
   const float r = rel[i];
   const bool sel = mask ? mask[i] != 0 : (__float_as_uint(r) & 0x7fffffffu) != 0x7f800000u;
-  // LinearRegression.predict on float32: X @ coef_.T (one float32 product) + intercept_
-  out[i] = sel ? __fadd_rn(__fmul_rn(r, coef), intercept) : fill;
+  // LinearRegression.predict on float32: X @ coef_.T (one float32 product, rounded) + intercept_ (rounded again).  The two roundings
+  // must survive the compiler: `__fadd_rn(__fmul_rn(..))` are plain operations for hipcc and were contracted into one fma - a last-bit
+  // difference for a non-zero intercept (the reference fits without one, depth.py:66, so its own calls never saw it; found by
+  // profiles/r06/fuzz_aux.py, round 6)
+  float y;
+  {
+#pragma clang fp contract(off)
+    const float prod = r * coef;
+    y = prod + intercept;
+  }
+  out[i] = sel ? y : fill;
 }
 
 // Sparse unprojection at match points — reference src/matching/matcher.py:70-91: depth looked up at

@@ -11,6 +11,9 @@ Per case (random frame sizes incl. widths that are no multiple of 32 / 4, height
   filters       keep_instances for both branches of the reference's rule (src/util.py:375)               -> the same decisions
   consumers     la3d_project_boxes (K shared / per box / indexed; corners behind the camera, on its plane) and la3d_iou_matrix
                 (degenerate and disjoint boxes) against oracle project_boxes / iou2d_matrix               -> 1e-12
+  depth stats   la3d_masked_ratio_median against np.median of the float32 ratios (ties, odd / even counts, 0/0, x/0), the depth-alignment
+                selection (one frame and batched) and scatter against the reference's NumPy expressions (depth.py:67-90) -> bit for bit
+  matcher       la3d_unproject_matches against the reference's expressions (src/matching/matcher.py:70-91)  -> 1e-12
 The oracle is test infrastructure: it is the checker here.  Nothing under /root/reference is read."""
 import argparse
 import os
@@ -48,7 +51,7 @@ def main():
     assert torch.cuda.is_available(), "the campaign needs the GPU"
     np_ = lambda t: t.detach().cpu().numpy()
     fails = []
-    n = dict(unproject=0, rle=0, poly=0, stats=0, keep=0, project=0, iou=0)
+    n = dict(unproject=0, rle=0, poly=0, stats=0, keep=0, project=0, iou=0, median=0, align=0, matches=0)
     t0 = time.time()
     for seed in range(a.seed, a.seed + a.cases):
         rs = np.random.RandomState(seed)
@@ -184,11 +187,78 @@ def main():
             if float(np.abs(got - ref).max()) > 1e-12:
                 fails.append((tag, f"iou2d_matrix: {float(np.abs(got - ref).max()):.3g}"))
             n["iou"] += n0 * n1
+            # ---- masked depth-ratio median (src/util.py:476-486), depth-alignment selection / scatter (depth.py:67-90), matcher ----
+            if H >= 2 and W >= 4:
+                Bm = int(rs.choice([1, 3, 9]))
+                num = np.stack([FE.one_plane(rs, H, W) for _ in range(Bm)])
+                den = np.stack([FE.one_plane(rs, H, W) for _ in range(Bm)])
+                if rs.rand() < 0.4:   # heavy ties: a handful of distinct ratios
+                    num = np.round(num).astype(np.float32); den = (np.round(np.abs(den)) + 1).astype(np.float32)
+                ma = rs.rand(Bm, H, W) < 10 ** rs.uniform(-3, 0)
+                mb = rs.rand(Bm, H, W) < rs.uniform(0.2, 1.0) if rs.rand() < 0.7 else None
+                med, cnt = (np_(t) for t in la.masked_ratio_median(num, den, ma, mb))
+                for i in range(Bm):
+                    ov = ma[i] if mb is None else ma[i] & mb[i]
+                    if cnt[i] != int(ov.sum()):
+                        fails.append((tag, f"ratio median: count {cnt[i]} expected {int(ov.sum())}")); continue
+                    with np.errstate(all="ignore"):
+                        want = np.median(num[i][ov] / den[i][ov]) if ov.any() else np.float32(np.nan)
+                    if not (np.float32(want) == med[i] or (np.isnan(want) and np.isnan(med[i]))):
+                        fails.append((tag, f"ratio median: got {med[i]!r} expected {want!r} (count {cnt[i]})"))
+                    n["median"] += 1
+                from labelany3d_amd import depth_align as DA
+
+                rel, met = num[0].copy(), np.abs(den[0]) * rs.uniform(1, 100)
+                mk = ma[0] if rs.rand() < 0.5 else None
+                cap = float(rs.choice([400.0, 50.0, 1e9]))
+                with np.errstate(all="ignore"):
+                    valid = (~np.isinf(rel)) & (met < cap) & (True if mk is None else mk)
+                r_, m_ = DA.align_select(rel, met, mk, cap)
+                if not (np.array_equal(np_(r_), rel[valid], equal_nan=True) and np.array_equal(np_(m_), met[valid], equal_nan=True)):
+                    fails.append((tag, "align_select differs"))
+                rb, mbt, cb = DA.align_select_batch(num, np.abs(den) * 3, ma if mk is not None else None, cap)
+                for i in range(Bm):
+                    with np.errstate(all="ignore"):
+                        v = (~np.isinf(num[i])) & (np.abs(den[i]) * 3 < cap) & (True if mk is None else ma[i])
+                    k = int(np_(cb)[i])
+                    if k != int(v.sum()) or not np.array_equal(np_(rb)[i, :k], num[i][v], equal_nan=True) or not np.array_equal(np_(mbt)[i, :k], (np.abs(den[i]) * 3)[v].astype(np.float32), equal_nan=True):
+                        fails.append((tag, f"align_select_batch differs at frame {i}"))
+                coef, icpt = np.float32(rs.uniform(0.1, 50)), np.float32(rs.uniform(-1, 1) * (rs.rand() < 0.5))
+                got = np_(DA.align_apply(rel, coef, icpt, mk))
+                want = np.full_like(rel, 10000.0)
+                sel = mk if mk is not None else ~np.isinf(rel)
+                with np.errstate(all="ignore"):
+                    want[sel] = rel[sel] * coef + icpt
+                if not np.array_equal(got, want, equal_nan=True):
+                    fails.append((tag, f"align_apply differs at {int((~((got == want) | (np.isnan(got) & np.isnan(want)))).sum())} pixels"))
+                n["align"] += 2 + Bm
+                # matcher unprojection (src/matching/matcher.py:70-91)
+                dm = np.abs(num[0]) + 0.5
+                dm[rs.rand(H, W) < 0.2] = -1
+                N = int(rs.choice([1, 17, 300]))
+                uv = np.stack([rs.uniform(0, W - 1e-3, N), rs.uniform(0, H - 1e-3, N)], 1)
+                Rm, Tm = (rand_rot(rs), rs.randn(3)) if rs.rand() < 0.6 else (None, None)
+                flip = float(rs.choice([512.0, 100.0])) if rs.rand() < 0.7 else None
+                fx, fy, cx, cy = rs.uniform(100, 900), rs.uniform(100, 900), rs.uniform(0, W), rs.uniform(0, H)
+                pts, vld = C.unproject_matches(dm, uv, fx, fy, cx, cy, flip, Rm, Tm)
+                pts, vld = np_(pts), np_(vld)
+                d_of = dm[uv[:, 1].astype(int), uv[:, 0].astype(int)]
+                okm = d_of != -1
+                u = (flip - uv[:, 0]) if flip is not None else uv[:, 0]
+                v = (flip - uv[:, 1]) if flip is not None else uv[:, 1]
+                p3 = np.stack(((u - cx) * d_of / fx, (v - cy) * d_of / fy, d_of), -1).astype(np.float64)
+                if Rm is not None:
+                    p3 = np.matmul(Rm, (p3.T - Tm.reshape(3, 1))).T
+                if not np.array_equal(vld, okm) or not np.isnan(pts[~okm]).all():
+                    fails.append((tag, "unproject_matches: validity differs"))
+                elif okm.any() and float(np.abs(pts[okm] - p3[okm]).max()) > 1e-12 * max(1.0, float(np.abs(p3[okm]).max())):
+                    fails.append((tag, f"unproject_matches: {float(np.abs(pts[okm] - p3[okm]).max()):.3g}"))
+                n["matches"] += N
         except Exception as e:   # noqa: BLE001 - a campaign records every failure and goes on
             fails.append((tag, f"raised {e!r}"))
     lines = [f"fuzz_aux: {a.cases} cases (seeds {a.seed}..{a.seed + a.cases - 1}) in {time.time() - t0:.0f} s",
              f"checked: {n['unproject']} unproject calls, {n['rle']} run-length masks decoded, {n['stats']} mask statistics rows, {n['keep']} filter decisions, "
-             f"{n['poly']} polygon annotations rasterised, {n['project']} boxes projected, {n['iou']} IoU entries",
+             f"{n['poly']} polygon annotations rasterised, {n['project']} boxes projected, {n['iou']} IoU entries, {n['median']} masked ratio medians, {n['align']} depth-alignment selections / scatters, {n['matches']} match points unprojected",
              f"failures: {len(fails)}"]
     lines += [f"  FAIL {t}: {m}" for t, m in fails[:300]]
     txt = "\n".join(lines)
