@@ -220,7 +220,10 @@ def oracle_case(seed):
 # the annotation entries (run lengths decoded / polygons rasterised inside the fit kernel): the same masks as run lengths for every
 # case, as polygons for the polygon cases
 ANN_RUNS = [dict(entry="rle"), dict(entry="rle", engine="instance"), dict(entry="rle", engine="split"),
-            dict(entry="poly"), dict(entry="poly", engine="instance"), dict(entry="poly", engine="split")]
+            dict(entry="poly"), dict(entry="poly", engine="instance"), dict(entry="poly", engine="split"),
+            # la3d_fit_instances_ex with everything on: the records' 2-D boxes from the record epilogue, an area hint for the launch
+            # order (right for some instances, wrong for others), and - run lengths - the reference's filter fused into the launch
+            dict(entry="ex_u8"), dict(entry="ex_rle"), dict(entry="ex_rle", engine="split")]
 RUNS = [dict(), dict(engine="instance"), dict(engine="band"), dict(engine="rows"), dict(engine="rows2"), dict(engine="split"),
         dict(build="plain"), dict(build="nocull"), dict(engine="instance", launch_order=False), dict(engine="band", launch_order=False)]
 
@@ -244,14 +247,14 @@ def main():
     import torch
 
     import labelany3d_amd as la
-    from labelany3d_amd.masks import fit_instances_poly, fit_instances_rle, pack_polygons
+    from labelany3d_amd.masks import fit_instances_ex, fit_instances_poly, fit_instances_rle, pack_polygons
     from labelany3d_amd.options import scheduling
     from oracle import la3d_oracle as O
     from tests.test_gpu_parity import assert_records, reference_axis_noise
 
     assert torch.cuda.is_available(), "the campaign needs the GPU"
     np_ = lambda t: t.detach().cpu().numpy()
-    n_inst = n_rec = n_tie = n_poly = n_refused = 0
+    n_inst = n_rec = n_tie = n_poly = n_refused = n_ex = 0
     fails = []
     all_runs = RUNS + ANN_RUNS
     per_run = {repr(r): 0 for r in all_runs}
@@ -260,7 +263,7 @@ def main():
     t0 = time.time()
     for s in seeds:
         c = make_case(s)
-        rec, st, nv, kap = ref[s]
+        rec, st_all, nv, kap = ref[s]
         n_inst += c["B"]
         n_poly += c["segs"] is not None
         nm = c["masks"].reshape(c["B"], -1).sum(1)
@@ -278,6 +281,20 @@ def main():
                         b, stg, aux = fit_instances_rle(c["depth"], rles, c["K"], **kw)
                     elif entry == "poly":
                         b, stg, aux = fit_instances_poly(c["depth"], pack_polygons(c["segs"], c["H"], c["W"]), c["K"], **kw)
+                    elif entry in ("ex_u8", "ex_rle"):
+                        ers = np.random.RandomState(s)
+                        hint = np.where(ers.rand(c["B"]) < 0.7, nm, ers.randint(0, 2 * c["H"] * c["W"], c["B"])).astype(np.int32)
+                        size = (c["W"] + int(ers.randint(0, 50)), c["H"] + int(ers.randint(0, 50)))
+                        flt = None
+                        if entry == "ex_rle":
+                            if rles is None:
+                                rles = [O.rle_encode(m) for m in c["masks"]]
+                            flt = dict(boundary_threshold=int(ers.choice([10, 1, 3])), scale_threshold=int(ers.choice([100, 1, 400])))
+                            res = fit_instances_ex(c["depth"], c["K"], rles=rles, filter=flt, image_size=size, area_hint=hint, **kw)
+                        else:
+                            res = fit_instances_ex(c["depth"], c["K"], masks=c["mb"], image_size=size, area_hint=hint, **kw)
+                        b, stg, aux = res["boxes"], res["status"], res["aux"]
+                        ex = (np_(res["boxes2d"]), None if flt is None else np_(res["stats"]), flt, size)
                     else:
                         b, stg, aux = la.fit_instances(c["depth"], c["mb"], c["K"], **kw)
                     b, stg, aux = np_(b), np_(stg), np_(aux)
@@ -290,6 +307,26 @@ def main():
                     fails.append((s, r, f"call failed: {e!r}"))
                     continue
             tag = f"seed {s} {c['H']}x{c['W']} B={c['B']} P={c['P']} skew={c['skew']} ground={'no' if c['ground'] is None else 'yes'} sample={c['sidx'] is not None} {r}"
+            st = st_all
+            if entry in ("ex_u8", "ex_rle"):
+                b2d, stats, flt, size = ex
+                if flt is not None:   # the fused filter: statistics and decisions against the oracle's, dropped instances carry status 6
+                    ref_stats = np.array([O.mask_stats(m, flt["boundary_threshold"]) for m in c["masks"]])
+                    keep = np.array([O.keep_instance(q, c["H"], True, flt["scale_threshold"]) for q in ref_stats])
+                    if not np.array_equal(stats, ref_stats):
+                        fails.append((s, r, f"fused filter: statistics differ at {np.flatnonzero((stats != ref_stats).any(1))[:4].tolist()}")); continue
+                    st = np.where(keep, st_all, 6).astype(np.int32)
+                    n_ex += int((~keep).sum())
+                okb = (st == 0)
+                Kp = c["K"] if c["image_index"] is None else c["K"][c["image_index"]]
+                want2d = O.project_boxes(b, Kp if (c["P"] > 1 or c["image_index"] is not None) else c["K"][0], size)
+                bad2d = np.flatnonzero(okb & ~(np.isclose(b2d, want2d, rtol=1e-12, atol=1e-9, equal_nan=True).all(1)))
+                # (a corner on / behind the camera plane: the projection divides by ~0 - NaN rows are reported whole, include/la3d.h)
+                bad2d = [i for i in bad2d if np.isfinite(want2d[i]).all() and np.isfinite(b2d[i]).all()]
+                if len(bad2d):
+                    fails.append((s, r, f"2-D boxes of the epilogue differ at {bad2d[:4]}: {b2d[bad2d[0]]} vs {want2d[bad2d[0]]}")); continue
+                if not np.isnan(b2d[st != 0]).all():
+                    fails.append((s, r, "2-D boxes of a rejected / filtered instance are not NaN")); continue
             if stg.tolist() != st.tolist():
                 bad = np.flatnonzero(stg != st)
                 fails.append((s, r, f"status at {bad[:5].tolist()}: got {stg[bad][:5].tolist()} expected {st[bad][:5].tolist()} (mask kinds {[c['mkind'][i] for i in bad[:5]]})"))
@@ -319,7 +356,7 @@ def main():
                                         f"gap {aux[n, 3]:.3g} kappa {kap[n]:.3g} | d center/dims {np.abs(b[n, :6] - rec[n, :6]).max():.3g} (scale {np.abs(rec[n, :6]).max():.3g}) "
                                         f"dR {np.abs(b[n, 6:15] - rec[n, 6:15]).max():.3g} dV {np.nanmax(np.abs(b[n, 15:] - rec[n, 15:])):.3g} dims {rec[n, 3:6].round(6).tolist()}"))
     t_gpu = time.time() - t0
-    lines = [f"fuzz_engines: {len(seeds)} cases (seeds {seeds[0]}..{seeds[-1]}), {n_inst} instances, {len(RUNS)} runs per case through the u8 entry + {len(ANN_RUNS)} through the annotation entries (3 as run lengths, 3 as polygons for the {n_poly} polygon cases)",
+    lines = [f"fuzz_engines: {len(seeds)} cases (seeds {seeds[0]}..{seeds[-1]}), {n_inst} instances, {len(RUNS)} runs per case through the u8 entry + {len(ANN_RUNS)} through the annotation / extended entries (3 as run lengths, 3 as polygons for the {n_poly} polygon cases, 3 through la3d_fit_instances_ex with the 2-D boxes of the epilogue, an area hint and - run lengths - the fused filter: {n_ex} instances dropped by it)",
              f"oracle: {t_or:.0f} s on {a.workers} host cores; GPU runs + comparison: {t_gpu:.0f} s",
              f"records compared with the oracle: {n_rec} (+ {n_tie} exact ties held to status / counts only)",
              f"worst relative error of center / dims among records with an eigen-gap above 1e-4: {worst:.2e}",
