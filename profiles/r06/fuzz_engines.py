@@ -32,6 +32,9 @@ sys.path.insert(0, ROOT)
 HS = [8, 16, 24, 37, 64, 96, 120, 200, 240, 375, 480, 517]
 WS = [32, 64, 96, 128, 160, 250, 320, 333, 427, 500, 640, 672]
 BS = [1, 1, 2, 3, 5, 8, 13, 16, 17, 33, 64, 100, 129, 150, 161, 200, 300]
+TINY_HS, TINY_WS = [1, 2, 3, 5, 7, 8, 9], [1, 2, 5, 17, 31, 32, 33, 40]
+if os.environ.get("LA3D_FUZZ_TINY"):
+    HS, WS = list(TINY_HS), list(TINY_WS)
 
 
 def one_mask(rs, H, W):
@@ -233,10 +236,14 @@ def main():
     ap.add_argument("--cases", type=int, default=400)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--seeds", default="", help="comma-separated seeds instead of --seed / --cases")
+    ap.add_argument("--tiny", action="store_true", help="frames of 1 ... 9 rows and 1 ... 40 columns (below one tile in either direction)")
     ap.add_argument("--workers", type=int, default=min(128, os.cpu_count() or 1))
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r06", "fuzz_engines.txt"))
     a = ap.parse_args()
     seeds = [int(x) for x in a.seeds.split(",")] if a.seeds else list(range(a.seed, a.seed + a.cases))
+    if a.tiny:   # (make_case reads the module's lists; the spawned oracle workers get the same through the environment)
+        os.environ["LA3D_FUZZ_TINY"] = "1"
+        HS[:] = TINY_HS; WS[:] = TINY_WS
     for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):   # one thread per oracle worker (the pool is the parallelism)
         os.environ[v] = "1"
     t0 = time.time()
