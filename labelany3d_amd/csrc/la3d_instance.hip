@@ -85,13 +85,6 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
 #else
 #define LA3D_STAMP(k) do { } while (0)
 #endif
-  // Experiment switch (profiles/r06/r06_ab_stage_priority.txt): issue priority 3 for the short dependent stages between the walks
-  // (list, axis, box), 0 inside the walks and the mask stream.
-#if defined(LA3D_STAGE_PRIO) && LA3D_STAGE_PRIO
-#define LA3D_PRIO(n) __builtin_amdgcn_s_setprio(n)
-#else
-#define LA3D_PRIO(n) do { } while (0)
-#endif
   LA3D_STAMP(0);
   if (!SAMPLE && p.stagger_ticks > 0 && p.order_nch > 0 && blockIdx.x < 1024) {
     // Plain build, u8 planes, size-ordered launch (round 4): the four groups of 256 workgroups that fill the chip start one
@@ -180,7 +173,6 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
   }
   __syncthreads();
   LA3D_STAMP(1);
-  LA3D_PRIO(3);
   // (from here on the instance index is re-read from LDS: live across the decode stage it costs the polygon build a spilled
   // register pair)
   const int inst_p = __builtin_amdgcn_readfirstlane(sh->order_inst);
@@ -379,7 +371,6 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
   if constexpr (LK) {
     if (sep) {   // uniform
       LA3D_STAMP(2);
-      LA3D_PRIO(0);
       unsigned* col = bits + nactive * 8;
       double sacc[5] = {0, 0, 0, 0, 0}, yx[2] = {INFINITY, -INFINITY};
       unsigned unsafe = 0u;
@@ -387,7 +378,6 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
       else sweep_sep<false>(p, dpl, bits, list, nactive, Mg, col, wave, lane, sacc, yx, &unsafe, 0, nfull);
       if (__ballot(unsafe >= 0x7f800000u) != 0ull && lane == 0) sh->sep_bad = 1;   // NaN / inf / negative depth under the mask
       // (the wave's y extent waits in scalar registers while the axis is computed: four vector registers fewer across that stage)
-      LA3D_PRIO(3);
       const double ylo_w = uniform_f64(wave_min(yx[0])), yhi_w = uniform_f64(wave_max(yx[1]));
       LA3D_STAMP(3);
       stage_moments_to_axis(sh, p, inst_p, sacc, nmask, nmask, tid, wave, lane, true);
@@ -426,7 +416,6 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
   }
 
   LA3D_STAMP(2);
-  LA3D_PRIO(0);
   // ---- pass A: moments ------------------------------------------------------------------
   double acc[5] = {0, 0, 0, 0, 0};
   int cnt = 0;
@@ -544,7 +533,6 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
   }
 
   LA3D_STAMP(3);
-  LA3D_PRIO(3);
   stage_moments_to_axis(sh, p, inst_p, acc, cnt, nmask, tid, wave, lane, true);
   if (sh->redo) {  // uniform: non-finite sums (the optimistic tiled pass) or ill-conditioned ones (axis_from_sums) - the checked pass
                    // about the pivot the stage left (zero unless the sums were ill-conditioned)
@@ -578,7 +566,6 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
 
   // ---- pass B: extents along the principal axes -----------------------------------------
   double ext[6] = {INFINITY, -INFINITY, INFINITY, -INFINITY, INFINITY, -INFINITY};  // x, y, z : lo, hi
-  LA3D_PRIO(0);
   if (sampled) {
     if (pok) {  // exactly the reference's arithmetic: rotate_y(yaw) applied to the stored point
       const double x2 = sh->cyaw * px + sh->syaw * pz;
@@ -610,7 +597,6 @@ __global__ __launch_bounds__(NT, NT / 64) void fit_instances_kernel(const FitPar
     else sweep<VEC, LDSMASK, 1>(p, dpl, mpl, bits, N0, Mg + 3, N2, wave, lane, ext, &d0, &d1);
   }
   LA3D_STAMP(5);
-  LA3D_PRIO(3);
   stage_extents_to_box(sh, p, inst_p, ext, tid, wave, lane);
   stage_status_aux(sh, p, inst_p, tid);
   LA3D_STAMP(6);
